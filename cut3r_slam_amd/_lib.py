@@ -1,0 +1,87 @@
+"""ctypes binding of libcut3r_hip.so (the C ABI declared in include/cut3r_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel returns non-zero, we raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcut3r_hip.so")
+
+c_void_p, c_int, c_float, c_ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+
+class GemmDesc(C.Structure):
+    """mirror of `cut3r_gemm_desc` (include/cut3r_hip.h)"""
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("res1", c_void_p), ("res2", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int), ("ldr1", c_int),
+        ("ldr2", c_int),
+        ("act", c_int), ("out_f16", c_int), ("res1_f16", c_int), ("res2_f16", c_int),
+        ("batch", c_int),
+        ("strideA", c_ll), ("strideB", c_ll), ("strideC", c_ll), ("strideBias", c_ll), ("strideR1", c_ll),
+        ("strideR2", c_ll),
+        ("conv_k", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("conv_stride", c_int), ("Ho", c_int),
+        ("Wo", c_int), ("relu_in", c_int),
+        ("shuf", c_int), ("shuf_cout", c_int), ("shuf_Hin", c_int), ("shuf_Win", c_int),
+        ("tile", c_int),
+    ]
+
+
+# name -> argtypes ; every function returns int (0 ok / 1 bad argument / 2 launch failure)
+SIGNATURES = {
+    "cut3r_abi_version": [],
+    "cut3r_rope2d": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_ll, c_ll, c_ll, c_float, c_float, c_void_p],
+    "cut3r_layernorm": [c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                        c_void_p, c_void_p, c_void_p],
+    "cut3r_gemm_f16": [C.POINTER(GemmDesc), c_void_p],
+    "cut3r_gemv_f16w": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                        c_void_p, c_int, c_int, c_void_p],
+    "cut3r_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                            c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_float, c_void_p],
+    "cut3r_im2col_patch": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "cut3r_cast_f32_f16": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
+    "cut3r_colmean": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "cut3r_upsample2x_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "cut3r_dpt_final": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "cut3r_postprocess_pts": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "cut3r_postprocess_pose": [c_void_p, c_int, c_void_p, c_void_p],
+    "cut3r_patch_overlap": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "cut3r_overlap_fwd": [c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p,
+                          c_void_p],
+    "cut3r_overlap_bwd": [c_void_p, c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p,
+                          c_void_p],
+    "cut3r_align_view": [c_void_p, c_void_p, c_int, c_int, C.POINTER(c_float), c_float, c_int, c_void_p, c_void_p,
+                         c_void_p, c_void_p],
+    "cut3r_logdepth_sum": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+}
+
+_lib = None
+
+
+class Cut3rHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library and bind every declared symbol (raises if the .so or a symbol is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise Cut3rHipError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise Cut3rHipError(f"{what} failed with code {rc} ({'bad argument' if rc == 1 else 'launch failure'})")

@@ -1,0 +1,227 @@
+// Fused (flash-style) attention for the CUT3R ViT on gfx950: softmax(q k^T * scale) v, no mask, fp16 I/O,
+// fp32 online softmax.  Replaces F.scaled_dot_product_attention at
+//   /root/reference/src/croco/models/blocks.py:139-145 (encoder, 16 heads x 64)
+//   /root/reference/src/dust3r/blocks.py:123-129, 233-239 (decoder self/cross: 12x64, 16x48; memory blocks 12x128)
+//
+// Structure (per workgroup = NW waves, one (batch, head), 32*NW query rows; KV tile = 64 keys):
+//   * "swapped" product S^T = K Q^T on v_mfma_f32_32x32x16_f16, so a lane owns ONE query column and its scores for
+//     16 of the tile's 32 keys sit in its own accumulator registers: the row max / row sum are 15 in-lane ops and
+//     one exchange with lane^32 -- no LDS, no 32-lane shuffle reductions.
+//   * the S^T accumulator tile is converted in registers (fp32 -> packed fp16) and used directly as the B operand
+//     of O^T += V^T P^T (accumulator rows = MFMA k index; the k permutation inside a 16-step is folded into the
+//     V^T fragment addresses), so P never touches LDS.
+//   * K tile row-major in LDS (padded rows, conflict-free ds_read_b128); V tile stored transposed [d][key] so the
+//     A fragments of the second product are two ds_read_b64 per k-step.
+//   * register prefetch of the next K/V tile overlaps the global loads with the MFMAs of the current tile.
+#include "common.h"
+#include "../../include/cut3r_hip.h"
+
+namespace {
+
+struct AttnArgs {
+    const h16* q; const h16* k; const h16* v; h16* o;
+    int Nq, Nk;
+    long long q_sb, q_sn, k_sb, k_sn, v_sb, v_sn, o_sb, o_sn;
+    float scale_log2;
+};
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
+    constexpr int NTHR = NW * 64;
+    constexpr int KT = 64;                       // keys per tile
+    constexpr int DQ = D / 16;                   // k-steps of the QK^T product
+    constexpr int DP = (D + 31) / 32;            // 32-row d-tiles of the PV product
+    constexpr int KS_LD = D + 8;                 // halves per K row in LDS (pad 16 B)
+    constexpr int VT_LD = KT + 4;                // halves per V^T row in LDS (pad 8 B)
+    constexpr int CHUNKS = KT * (D / 8);         // 16-B chunks per K (or V) tile
+    constexpr int NCH = (CHUNKS + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) h16 Ks[KT * KS_LD];
+    __shared__ __attribute__((aligned(16))) h16 Vt[DP * 32 * VT_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+    const h16* qp = a.q + (size_t)b * a.q_sb + (size_t)h * D;
+    const h16* kp = a.k + (size_t)b * a.k_sb + (size_t)h * D;
+    const h16* vp = a.v + (size_t)b * a.v_sb + (size_t)h * D;
+
+    // zero the V^T image once (covers the d >= D padding rows and the pad columns)
+    for (int i = tid; i < DP * 32 * VT_LD; i += NTHR) Vt[i] = (h16)0;
+
+    // Q fragments (B operand: element j = Q[q0+r][16 s + 8 hh + j])
+    half8_t qf[DQ];
+    {
+        int qr = q0 + r;
+        if (qr > a.Nq - 1) qr = a.Nq - 1;
+        const h16* qrow = qp + (size_t)qr * a.q_sn;
+#pragma unroll
+        for (int s = 0; s < DQ; s++) qf[s] = *reinterpret_cast<const half8_t*>(qrow + 16 * s + 8 * hh);
+    }
+
+    f32x16 ot[DP];
+#pragma unroll
+    for (int d = 0; d < DP; d++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) ot[d][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    half8_t rk[NCH], rv[NCH];
+    auto load_kv = [&](int t) {
+        const int kbase = t * KT;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            int id = tid + c * NTHR;
+            half8_t zk = {0, 0, 0, 0, 0, 0, 0, 0}, zv = zk;
+            if (id < CHUNKS) {
+                int key = id / (D / 8), ch = id - key * (D / 8);
+                int gk = kbase + key;
+                if (gk < a.Nk) {
+                    zk = *reinterpret_cast<const half8_t*>(kp + (size_t)gk * a.k_sn + ch * 8);
+                    zv = *reinterpret_cast<const half8_t*>(vp + (size_t)gk * a.v_sn + ch * 8);
+                }
+            }
+            rk[c] = zk; rv[c] = zv;
+        }
+    };
+    auto store_kv = [&]() {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            int id = tid + c * NTHR;
+            if (id < CHUNKS) {
+                int key = id / (D / 8), ch = id - key * (D / 8);
+                *reinterpret_cast<half8_t*>(&Ks[key * KS_LD + ch * 8]) = rk[c];
+#pragma unroll
+                for (int j = 0; j < 8; j++) Vt[(ch * 8 + j) * VT_LD + key] = rv[c][j];
+            }
+        }
+    };
+
+    const int ntiles = (a.Nk + KT - 1) / KT;
+    load_kv(0);
+    for (int t = 0; t < ntiles; t++) {
+        __syncthreads();
+        store_kv();
+        __syncthreads();
+        if (t + 1 < ntiles) load_kv(t + 1);
+
+        // ---- S^T = K Q^T for the two 32-key sub-tiles
+        f32x16 st[2];
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; kt2++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) st[kt2][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < DQ; s++) {
+                half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[(kt2 * 32 + r) * KS_LD + 16 * s + 8 * hh]);
+                st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[kt2], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (per query column == per lane; partner lane^32 holds the other 32 keys)
+        const int kbase = t * KT;
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; kt2++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                int key = kbase + kt2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                float s = st[kt2][i] * a.scale_log2;
+                s = key < a.Nk ? s : -INFINITY;
+                st[kt2][i] = s;
+                mloc = fmaxf(mloc, s);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; kt2++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                float p = __builtin_amdgcn_exp2f(st[kt2][i] - m_new);
+                st[kt2][i] = p;
+                lsum += p;
+            }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int d = 0; d < DP; d++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) ot[d][i] *= alpha;
+
+        // ---- O^T += V^T P^T   (B fragment of k-step s2 = accumulator registers 8 s2 .. 8 s2 + 7)
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; kt2++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                half8_t pf;
+#pragma unroll
+                for (int j = 0; j < 8; j++) pf[j] = (h16)st[kt2][8 * s2 + j];
+#pragma unroll
+                for (int d = 0; d < DP; d++) {
+                    const h16* vrow = &Vt[(d * 32 + r) * VT_LD + kt2 * 32 + 16 * s2 + 4 * hh];
+                    half4_t lo = *reinterpret_cast<const half4_t*>(vrow);
+                    half4_t hi = *reinterpret_cast<const half4_t*>(vrow + 8);
+                    half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[d], 0, 0, 0);
+                }
+            }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + r;
+    if (qr < a.Nq) {
+        h16* orow = a.o + (size_t)b * a.o_sb + (size_t)qr * a.o_sn + (size_t)h * D;
+#pragma unroll
+        for (int d = 0; d < DP; d++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                int dd = d * 32 + 8 * g4 + 4 * hh;
+                if (dd < D) {
+                    half4_t o = {(h16)(ot[d][4 * g4 + 0] * inv), (h16)(ot[d][4 * g4 + 1] * inv), (h16)(ot[d][4 * g4 + 2] * inv),
+                                 (h16)(ot[d][4 * g4 + 3] * inv)};
+                    *reinterpret_cast<half4_t*>(orow + dd) = o;
+                }
+            }
+    }
+}
+
+template <int D>
+int launch_attn(const AttnArgs& a, int B, int H, hipStream_t s) {
+    const long long blocks128 = (long long)B * H * ((a.Nq + 127) / 128);
+    if (blocks128 >= 384 || D >= 128) {
+        dim3 grid((a.Nq + 127) / 128, H, B);
+        hipLaunchKernelGGL((attn_kernel<D, 4>), grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((a.Nq + 63) / 64, H, B);
+        hipLaunchKernelGGL((attn_kernel<D, 2>), grid, dim3(128), 0, s, a);
+    }
+    return cut3r_check_launch();
+}
+
+}  // namespace
+
+extern "C" int cut3r_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
+                                   long long q_sb, long long q_sn, long long k_sb, long long k_sn, long long v_sb, long long v_sn,
+                                   long long o_sb, long long o_sn, float scale, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return CUT3R_ERR_ARG;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return CUT3R_ERR_ARG;
+    if ((uintptr_t)out & 7) return CUT3R_ERR_ARG;
+    if ((q_sn | k_sn | v_sn | q_sb | k_sb | v_sb) & 7) return CUT3R_ERR_ARG;   // 16-B vector loads
+    if ((o_sn | o_sb) & 3) return CUT3R_ERR_ARG;
+    AttnArgs a;
+    a.q = (const h16*)q; a.k = (const h16*)k; a.v = (const h16*)v; a.o = (h16*)out;
+    a.Nq = Nq; a.Nk = Nk;
+    a.q_sb = q_sb; a.q_sn = q_sn; a.k_sb = k_sb; a.k_sn = k_sn; a.v_sb = v_sb; a.v_sn = v_sn; a.o_sb = o_sb; a.o_sn = o_sn;
+    a.scale_log2 = scale * 1.44269504088896340736f;
+    hipStream_t s = (hipStream_t)stream;
+    switch (D) {
+        case 16: return launch_attn<16>(a, B, H, s);
+        case 32: return launch_attn<32>(a, B, H, s);
+        case 48: return launch_attn<48>(a, B, H, s);
+        case 64: return launch_attn<64>(a, B, H, s);
+        case 128: return launch_attn<128>(a, B, H, s);
+        default: return CUT3R_ERR_ARG;
+    }
+}

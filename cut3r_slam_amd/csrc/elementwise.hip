@@ -1,0 +1,341 @@
+// Memory-bound kernels of the ViT path on gfx950: RoPE-2D, LayerNorm(+adaLN), patch im2col, casts, column mean,
+// bilinear x2 upsample, DPT output activations.  All are HBM-bound: coalesced 8/16-byte accesses, one pass.
+#include "common.h"
+#include "../../include/cut3r_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------- RoPE-2D
+// /root/reference/src/croco/models/curope/kernels.cu:17-82.  One wave per (b, n) token, lanes sweep the H*D/2 (u,v)
+// pairs of the token; cos/sin are evaluated once per (token, X, q) in fp32 with the reference's operation order
+// (inv_freq = fwd / powf(base, q/Q); freq = pos * inv_freq) and reused across heads.
+template <typename T>
+__global__ __launch_bounds__(256) void rope2d_kernel(T* __restrict__ tok, const int64_t* __restrict__ pos, int BN, int N, int H,
+                                                     int D, long long sB, long long sN, long long sH, float base, float fwd) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= BN) return;
+    const int b = t / N, n = t - b * N;
+    const int Q = D >> 2;
+    T* p = tok + (size_t)b * sB + (size_t)n * sN;
+    const float py = (float)pos[(size_t)t * 2 + 0], px = (float)pos[(size_t)t * 2 + 1];
+    // pair index e in [0, 2Q): X = e / Q (0 = y half, 1 = x half), q = e % Q
+    for (int e = lane; e < 2 * Q; e += 64) {
+        const int X = e / Q, q = e - X * Q;
+        const float inv = fwd / powf(base, (float)q / (float)Q);
+        const float fr = (X ? px : py) * inv;
+        const float c = cosf(fr), s = sinf(fr);
+        for (int h = 0; h < H; h++) {
+            T* th = p + (size_t)h * sH + X * 2 * Q;
+            const float u = (float)th[q], v = (float)th[q + Q];
+            th[q] = (T)(u * c - v * s);
+            th[q + Q] = (T)(v * c + u * s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- LayerNorm
+// One wave per row; the row lives in registers (C <= 64*VPL*... handled by a strided loop), two-pass mean/variance
+// exactly as torch (biased variance of (x-mean)).
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, int M, int C,
+                                                        h16* __restrict__ y16, int ld16, float* __restrict__ y32, int ld32,
+                                                        const float* __restrict__ mscale, const float* __restrict__ mshift) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    constexpr int MAXV = 8;                 // supports C <= 64*4*8 = 2048
+    f32x4 v[MAXV];
+    float s = 0.f;
+    const int nv = C >> 2;                  // float4 count
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        int c4 = lane + i * 64;
+        if (c4 < nv) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c4 * 4);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        int c4 = lane + i * 64;
+        if (c4 < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        int c4 = lane + i * 64;
+        if (c4 < nv) {
+            f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
+            f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
+            if (mscale) {
+                f32x4 sc = *reinterpret_cast<const f32x4*>(mscale + c4 * 4);
+                f32x4 sh = *reinterpret_cast<const f32x4*>(mshift + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = o[e] * (1.0f + sc[e]) + sh[e];
+            }
+            if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * ld32 + c4 * 4) = o;
+            if (y16) {
+                half4_t ho = {(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
+                *reinterpret_cast<half4_t*>(y16 + (size_t)row * ld16 + c4 * 4) = ho;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- im2col (patch embed)
+// out[(b, py, px), (c, iy, ix)] = img[b, c, py*P+iy, px*P+ix]; one thread per 8 contiguous ix.
+template <bool U8>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ img, int B, int C, int H, int W, int P,
+                                                     h16* __restrict__ out) {
+    const int nh = H / P, nw = W / P;
+    const int Kp = C * P * P;
+    const size_t total = (size_t)B * nh * nw * (Kp / 8);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int kc = (int)(i % (Kp / 8));
+        const size_t m = i / (Kp / 8);
+        const int k = kc * 8;
+        const int c = k / (P * P), rem = k - c * P * P;
+        const int iy = rem / P, ix = rem - iy * P;
+        const int px = (int)(m % nw);
+        const int py = (int)((m / nw) % nh);
+        const int b = (int)(m / ((size_t)nw * nh));
+        const size_t src = (((size_t)b * C + c) * H + (py * P + iy)) * W + (px * P + ix);
+        half8_t o;
+        if (U8) {
+            const unsigned char* p = (const unsigned char*)img + src;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (h16)(((float)p[e] / 255.0f - 0.5f) / 0.5f);
+        } else {
+            const float* p = (const float*)img + src;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (h16)p[e];
+        }
+        *reinterpret_cast<half8_t*>(out + m * Kp + k) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, int ldx, h16* __restrict__ y, int ldy, int M, int C4) {
+    const size_t total = (size_t)M * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const size_t m = i / C4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + m * ldx + c * 4);
+        half4_t o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        *reinterpret_cast<half4_t*>(y + m * ldy + c * 4) = o;
+    }
+}
+
+// column mean: each block owns 64 columns; 4 waves split the rows, LDS combine.  Deterministic summation order.
+__global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ x, int ldx, int M, int C, float* __restrict__ y) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < C)
+        for (int m = w; m < M; m += 4) s += x[(size_t)m * ldx + c];
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < C) y[c] = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)M;
+}
+
+// ------------------------------------------------------------------------------------------------- bilinear x2 (align_corners)
+// /root/reference/src/croco/models/dpt_block.py:215-221: src = dst * (in-1)/(out-1).  NHWC fp16, 8 channels per thread.
+__global__ __launch_bounds__(256) void upsample2x_kernel(const h16* __restrict__ in, h16* __restrict__ out, int B, int H, int W, int C8) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const size_t total = (size_t)B * Ho * Wo * C8;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        size_t p = i / C8;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const float sy = ry * (float)oy, sx = rx * (float)ox;
+        int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const h16* base = in + (size_t)b * H * W * C8 * 8 + c * 8;
+        const half8_t v00 = *reinterpret_cast<const half8_t*>(base + ((size_t)y0 * W + x0) * C8 * 8);
+        const half8_t v01 = *reinterpret_cast<const half8_t*>(base + ((size_t)y0 * W + x1) * C8 * 8);
+        const half8_t v10 = *reinterpret_cast<const half8_t*>(base + ((size_t)y1 * W + x0) * C8 * 8);
+        const half8_t v11 = *reinterpret_cast<const half8_t*>(base + ((size_t)y1 * W + x1) * C8 * 8);
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            o[e] = (h16)(hy * (hx * (float)v00[e] + lx * (float)v01[e]) + ly * (hx * (float)v10[e] + lx * (float)v11[e]));
+        *reinterpret_cast<half8_t*>(out + i * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- output activations
+DEVINL void act_pts_conf(float x, float y, float z, float c, bool has_conf, bool pos_z, float* pts, float* conf, size_t p) {
+    if (pos_z) {
+        float sg = (z > 0.f) ? 1.f : ((z < 0.f) ? -1.f : 0.f);
+        x *= sg; y *= sg; z *= sg;
+    }
+    const float d = sqrtf(x * x + y * y + z * z);
+    const float dc = fmaxf(d, 1e-8f);
+    const float e = expm1f(d);
+    pts[3 * p + 0] = x / dc * e;
+    pts[3 * p + 1] = y / dc * e;
+    pts[3 * p + 2] = z / dc * e;
+    if (has_conf) conf[p] = 1.0f + expf(c);
+}
+
+// final 1x1 conv (Cin -> nout<=4) + activations; one wave per pixel group: each lane handles one pixel, reading its
+// Cin fp16 channels as 16-B vectors (rows are Cin*2 bytes apart -> each lane streams its own 256-B row).
+__global__ __launch_bounds__(256) void dpt_final_kernel(const h16* __restrict__ in, int P, int Cin, const float* __restrict__ w,
+                                                        const float* __restrict__ bsv, int mode, float* __restrict__ pts,
+                                                        float* __restrict__ conf) {
+    extern __shared__ float sw[];          // [nout][Cin]
+    const int nout = mode == 0 ? 4 : 3;
+    for (int i = threadIdx.x; i < nout * Cin; i += blockDim.x) sw[i] = w[i];
+    __syncthreads();
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < (size_t)P; p += (size_t)gridDim.x * blockDim.x) {
+        float a0 = bsv[0], a1 = bsv[1], a2 = bsv[2], a3 = nout == 4 ? bsv[3] : 0.f;
+        const h16* row = in + p * Cin;
+        for (int k = 0; k < Cin; k += 8) {
+            half8_t v = *reinterpret_cast<const half8_t*>(row + k);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float xv = (float)v[e];
+                a0 = fmaf(xv, sw[k + e], a0);
+                a1 = fmaf(xv, sw[Cin + k + e], a1);
+                a2 = fmaf(xv, sw[2 * Cin + k + e], a2);
+                if (nout == 4) a3 = fmaf(xv, sw[3 * Cin + k + e], a3);
+            }
+        }
+        if (mode == 0) {
+            act_pts_conf(a0, a1, a2, a3, true, false, pts, conf, p);
+        } else {
+            const float eps = 1e-6f;
+            float o[3] = {a0, a1, a2};
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                float sg = 1.0f / (1.0f + expf(-o[e]));
+                pts[3 * p + e] = ((sg * (1 - 2 * eps) + eps) - 0.5f) * 2.0f;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void postprocess_pts_kernel(const float* __restrict__ raw, int P, int nch, int pos_z,
+                                                              float* __restrict__ pts, float* __restrict__ conf) {
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < (size_t)P; p += (size_t)gridDim.x * blockDim.x) {
+        const float* r = raw + p * nch;
+        act_pts_conf(r[0], r[1], r[2], nch > 3 ? r[3] : 0.f, nch > 3, pos_z != 0, pts, conf, p);
+    }
+}
+
+__global__ void postprocess_pose_kernel(const float* __restrict__ raw, int B, float* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* r = raw + b * 7;
+    const float d = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+    float qn = sqrtf(r[3] * r[3] + r[4] * r[4] + r[5] * r[5] + r[6] * r[6]);
+    qn = fmaxf(qn, 1e-12f);                                 // F.normalize eps
+    float q[4] = {r[3] / qn, r[4] / qn, r[5] / qn, r[6] / qn};
+    const float sg = q[0] < 0.f ? -1.f : 1.f;
+    out[b * 7 + 0] = r[0] * sc; out[b * 7 + 1] = r[1] * sc; out[b * 7 + 2] = r[2] * sc;
+    for (int e = 0; e < 4; e++) out[b * 7 + 3 + e] = sg * q[e];
+}
+
+inline int grid_for(size_t total, int block = 256) {
+    size_t g = (total + block - 1) / block;
+    if (g > 2048 * 4) g = 2048 * 4;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int cut3r_abi_version(void) { return 1; }
+
+extern "C" int cut3r_rope2d(void* tokens, int dtype, const int64_t* positions, int B, int N, int H, int D, long long sB,
+                            long long sN, long long sH, float base, float fwd, void* stream) {
+    if (!tokens || !positions || B <= 0 || N <= 0 || H <= 0 || D <= 0 || (D & 3)) return CUT3R_ERR_ARG;
+    const int BN = B * N;
+    dim3 grid((BN + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == 0)
+        hipLaunchKernelGGL((rope2d_kernel<float>), grid, block, 0, s, (float*)tokens, positions, BN, N, H, D, sB, sN, sH, base, fwd);
+    else if (dtype == 1)
+        hipLaunchKernelGGL((rope2d_kernel<h16>), grid, block, 0, s, (h16*)tokens, positions, BN, N, H, D, sB, sN, sH, base, fwd);
+    else
+        return CUT3R_ERR_ARG;
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int M, int C, void* y16,
+                               int ld16, float* y32, int ld32, const float* mod_scale, const float* mod_shift, void* stream) {
+    if (!x || !gamma || !beta || M <= 0 || C <= 0 || (C & 3) || C > 2048 || (ldx & 3)) return CUT3R_ERR_ARG;
+    if (!y16 && !y32) return CUT3R_ERR_ARG;
+    if ((y16 && (ld16 & 3)) || (y32 && (ld32 & 3))) return CUT3R_ERR_ARG;
+    if ((mod_scale == nullptr) != (mod_shift == nullptr)) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, M, C,
+                       (h16*)y16, ld16, y32, ld32, mod_scale, mod_shift);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_im2col_patch(const void* img, int u8, int B, int C, int H, int W, int P, void* out, void* stream) {
+    if (!img || !out || B <= 0 || C <= 0 || P <= 0 || (P & 7) || H % P || W % P) return CUT3R_ERR_ARG;
+    const size_t total = (size_t)B * (H / P) * (W / P) * (C * P * P / 8);
+    if (u8)
+        hipLaunchKernelGGL((im2col_kernel<true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, B, C, H, W, P, (h16*)out);
+    else
+        hipLaunchKernelGGL((im2col_kernel<false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, B, C, H, W, P, (h16*)out);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_cast_f32_f16(const float* x, int ldx, void* y, int ldy, int M, int C, void* stream) {
+    if (!x || !y || M <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3)) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for((size_t)M * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, (h16*)y, ldy, M, C / 4);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_colmean(const float* x, int ldx, int M, int C, float* y, void* stream) {
+    if (!x || !y || M <= 0 || C <= 0) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(colmean_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, y);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_upsample2x_nhwc(const void* in, void* out, int B, int H, int W, int C, void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return CUT3R_ERR_ARG;
+    const size_t total = (size_t)B * 2 * H * 2 * W * (C / 8);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const h16*)in, (h16*)out, B, H, W, C / 8);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_dpt_final(const void* in, int P, int Cin, const float* w, const float* b, int mode, float* pts, float* conf,
+                               void* stream) {
+    if (!in || !w || !b || !pts || P <= 0 || Cin <= 0 || (Cin & 7) || Cin > 2048 || (mode != 0 && mode != 1)) return CUT3R_ERR_ARG;
+    if (mode == 0 && !conf) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(dpt_final_kernel, dim3(grid_for((size_t)P)), dim3(256), 4 * Cin * sizeof(float), (hipStream_t)stream,
+                       (const h16*)in, P, Cin, w, b, mode, pts, conf);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_postprocess_pts(const float* raw, int P, int nch, int pos_z, float* pts, float* conf, void* stream) {
+    if (!raw || !pts || P <= 0 || (nch != 3 && nch != 4) || (nch == 4 && !conf)) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(postprocess_pts_kernel, dim3(grid_for((size_t)P)), dim3(256), 0, (hipStream_t)stream, raw, P, nch, pos_z, pts, conf);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_postprocess_pose(const float* raw, int B, float* out, void* stream) {
+    if (!raw || !out || B <= 0) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(postprocess_pose_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, raw, B, out);
+    return cut3r_check_launch();
+}

@@ -1,0 +1,334 @@
+// MFMA GEMM family for the CUT3R ViT / DPT stack on gfx950.
+//
+//   C[M,N] = epilogue( A[M,K] (fp16, K-major) x B[N,K]^T (fp16, K-major, = nn.Linear weight layout) ), fp32 accumulate.
+//
+// One kernel template covers every dense contraction on the hot path:
+//   * nn.Linear (+bias)(+exact GELU)(+residual) of the encoder/decoder blocks
+//       /root/reference/src/croco/models/blocks.py:68-148, src/dust3r/blocks.py:87-243
+//   * 1x1 / 3x3 (stride 1|2, pad 1) convolutions of the DPT head as implicit GEMM over NHWC fp16 activations
+//       /root/reference/src/croco/models/dpt_block.py:84-232, 281-513 (optional ReLU-on-load = ResidualConvUnit pre-activation)
+//   * ConvTranspose2d with kernel == stride as GEMM + pixel-shuffle scatter epilogue (dpt_block.py:416-446)
+//
+// Design (MI355X): v_mfma_f32_16x16x32_f16, 256-thread workgroups (4 waves, 2x2), BK = 64, register-staged
+// global->LDS double buffering (loads for tile t+1 issued before the MFMAs of tile t, written after them: one
+// barrier per K-tile), XOR-swizzled 16-B LDS chunks (conflict-free ds_read_b128), epilogue staged through LDS so
+// bias / residual / output traffic is 16-B coalesced.  Tile 128x128 for large grids, 64x64 when the grid would
+// not fill 256 CUs (batch-1 decoder GEMMs).  blockIdx.z batches independent problems with element strides.
+#include "common.h"
+#include "../../include/cut3r_hip.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int KCH = BK / 8;  // 16-byte chunks per tile row
+
+struct GemmArgs {
+    const h16* A; const h16* B; void* C;
+    const float* bias; const void* res1; const void* res2;
+    int M, N, K, lda, ldb, ldc, ldr1, ldr2;
+    int act, out_f16, res1_f16, res2_f16;
+    long long sA, sB, sC, sBias, sR1, sR2;       // batch strides (elements), blockIdx.z
+    // implicit-GEMM convolution (A = NHWC fp16 [Bimg,H,W,Cin]); conv_k = 0 (plain), 1 or 3
+    int conv_k, H, W, Cin, cstride, Ho, Wo, relu_in;
+    // pixel-shuffle scatter epilogue (ConvTranspose k == stride == shuf): n = (i*shuf + j)*Cout + co
+    int shuf, shuf_cout, shuf_Hin, shuf_Win;
+};
+
+DEVINL half8_t relu8(half8_t v) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = v[i] > (h16)0 ? v[i] : (h16)0;
+    return v;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+    constexpr int WM = BM / 2, WN = BN / 2;       // wave tile
+    constexpr int MT = WM / 16, NT = WN / 16;     // 16x16 MFMA tiles per wave
+    constexpr int A_CH = BM * KCH / 256;          // 16-B chunks per thread per stage
+    constexpr int B_CH = BN * KCH / 256;
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    constexpr int CPAD = BN + 4;
+    constexpr int EPI_BYTES = BM * CPAD * 4;
+    constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.z;
+    const h16* __restrict__ A = g.A + (size_t)z * g.sA;
+    const h16* __restrict__ Bm = g.B + (size_t)z * g.sB;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int M = g.M, N = g.N, K = g.K;
+
+    // ---- per-thread loader coordinates (tile-invariant part)
+    const int ck = tid & (KCH - 1);            // chunk column within the K tile
+    int a_row[A_CH]; bool a_ok[A_CH];
+    const h16* a_base[A_CH];
+    int a_oy[A_CH], a_ox[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; i++) {
+        int r = (tid >> 3) + i * 32;
+        a_row[i] = r;
+        int gm = m0 + r;
+        a_ok[i] = gm < M;
+        if (g.conv_k == 3) {
+            int gmc = a_ok[i] ? gm : 0;
+            int hw = g.Ho * g.Wo;
+            int b = gmc / hw, rem = gmc - b * hw;
+            int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            a_oy[i] = oy * g.cstride - 1;
+            a_ox[i] = ox * g.cstride - 1;
+            a_base[i] = A + (size_t)b * g.H * g.W * g.Cin;
+        } else {
+            a_oy[i] = a_ox[i] = 0;
+            a_base[i] = A + (size_t)(a_ok[i] ? gm : 0) * g.lda;
+        }
+    }
+    const h16* b_base[B_CH]; bool b_ok[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; i++) {
+        int r = (tid >> 3) + i * 32;
+        int gn = n0 + r;
+        b_ok[i] = gn < N;
+        b_base[i] = Bm + (size_t)(b_ok[i] ? gn : 0) * g.ldb;
+    }
+
+    half8_t ra[A_CH], rb[B_CH];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + ck * 8;
+        const bool kok = k < K;
+        if (g.conv_k == 3) {
+            int tap = k / g.Cin, ci = k - tap * g.Cin;
+            int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int i = 0; i < A_CH; i++) {
+                int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
+                bool ok = kok && a_ok[i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = *reinterpret_cast<const half8_t*>(a_base[i] + ((size_t)iy * g.W + ix) * g.Cin + ci);
+                ra[i] = g.relu_in ? relu8(v) : v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_CH; i++) {
+                half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (kok && a_ok[i]) v = *reinterpret_cast<const half8_t*>(a_base[i] + k);
+                ra[i] = g.relu_in ? relu8(v) : v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; i++) {
+            half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kok && b_ok[i]) v = *reinterpret_cast<const half8_t*>(b_base[i] + k);
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE_BYTES;
+        unsigned char* sb = sa + BM * BK * 2;
+#pragma unroll
+        for (int i = 0; i < A_CH; i++) {
+            int r = a_row[i];
+            *reinterpret_cast<half8_t*>(sa + r * (BK * 2) + ((ck ^ (r & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; i++) {
+            int r = (tid >> 3) + i * 32;
+            *reinterpret_cast<half8_t*>(sb + r * (BK * 2) + ((ck ^ (r & 7)) << 4)) = rb[i];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = (K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;   // fragment row, k-chunk
+    for (int t = 0; t < nt; t++) {
+        const int cur = t & 1;
+        if (t + 1 < nt) load_tile(t + 1);
+        const unsigned char* sa = smem + cur * STAGE_BYTES;
+        const unsigned char* sb = sa + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; kk++) {
+            half8_t fa[MT], fb[NT];
+            const int ch = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < MT; i++) {
+                int r = wm * WM + i * 16 + fr;
+                fa[i] = *reinterpret_cast<const half8_t*>(sa + r * (BK * 2) + ((ch ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                int r = wn * WN + j * 16 + fr;
+                fb[j] = *reinterpret_cast<const half8_t*>(sb + r * (BK * 2) + ((ch ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32) -> coalesced fused store
+    float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                int r = wm * WM + i * 16 + fq * 4 + e;
+                int c = wn * WN + j * 16 + fr;
+                cs[r * CPAD + c] = acc[i][j][e];
+            }
+    __syncthreads();
+
+    const float* bias = g.bias ? g.bias + (size_t)z * g.sBias : nullptr;
+    constexpr int TPR = BN / 4;               // threads per output row (4 columns each)
+    constexpr int RPP = 256 / TPR;            // rows per pass
+    const int c4 = (tid % TPR) * 4;
+    const int gn = n0 + c4;
+    if (gn >= N) return;
+    for (int r = tid / TPR; r < BM; r += RPP) {
+        const int gm = m0 + r;
+        if (gm >= M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
+        int bcol = gn;
+        size_t orow_off;
+        if (g.shuf) {
+            const int ij = gn / g.shuf_cout;
+            bcol = gn - ij * g.shuf_cout;
+            const int i_ = ij / g.shuf, j_ = ij - i_ * g.shuf;
+            const int hw = g.shuf_Hin * g.shuf_Win;
+            const int b = gm / hw, rem = gm - b * hw;
+            const int y = rem / g.shuf_Win, x = rem - y * g.shuf_Win;
+            orow_off = (((size_t)b * g.shuf_Hin * g.shuf + (y * g.shuf + i_)) * (g.shuf_Win * g.shuf) + (x * g.shuf + j_)) *
+                           (size_t)g.ldc + bcol;
+        } else {
+            orow_off = (size_t)gm * g.ldc + gn;
+        }
+        if (bias) {
+            f32x4 bv = *reinterpret_cast<const f32x4*>(bias + bcol);
+            v += bv;
+        }
+        if (g.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+        } else if (g.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (g.res1) {
+            if (g.res1_f16) {
+                half4_t rv = *reinterpret_cast<const half4_t*>((const h16*)g.res1 + (size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] += (float)rv[e];
+            } else {
+                v += *reinterpret_cast<const f32x4*>((const float*)g.res1 + (size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn);
+            }
+        }
+        if (g.res2) {
+            if (g.res2_f16) {
+                half4_t rv = *reinterpret_cast<const half4_t*>((const h16*)g.res2 + (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] += (float)rv[e];
+            } else {
+                v += *reinterpret_cast<const f32x4*>((const float*)g.res2 + (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn);
+            }
+        }
+        if (g.out_f16) {
+            half4_t o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+            *reinterpret_cast<half4_t*>((h16*)g.C + (size_t)z * g.sC + orow_off) = o;
+        } else {
+            *reinterpret_cast<f32x4*>((float*)g.C + (size_t)z * g.sC + orow_off) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Skinny GEMM (M <= 8 rows): weight-read-bound GEMV.  One wave per output column block, x rows kept in registers.
+// Used for the 1-token pose-memory read, pose MLP and adaLN modulation (M = 1).
+__global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ X, int ldx, const h16* __restrict__ W, int ldw,
+                                                   const float* __restrict__ bias, float* __restrict__ Y, int ldy, int M,
+                                                   int N, int K, int act, const float* __restrict__ res, int ldr, int silu_in) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const h16* w = W + (size_t)n * ldw;
+    for (int m = 0; m < M; m++) {
+        float s = 0.f;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            half8_t wv = *reinterpret_cast<const half8_t*>(w + k);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float x = X[(size_t)m * ldx + k + e];
+                if (silu_in) x = x / (1.0f + __expf(-x));
+                // match the MFMA path: activations are rounded to fp16 before the product
+                s = fmaf((float)(h16)x, (float)wv[e], s);
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            if (bias) s += bias[n];
+            if (act == 1) s = gelu_erf(s);
+            if (res) s += res[(size_t)m * ldr + n];
+            Y[(size_t)m * ldy + n] = s;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
+    if (!d || !d->A || !d->B || !d->C) return CUT3R_ERR_ARG;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0) return CUT3R_ERR_ARG;
+    if ((d->K & 7) || (d->N & 3) || (d->ldb & 7) || (d->ldc & 3)) return CUT3R_ERR_ARG;
+    if (d->conv_k != 3 && (d->lda & 7)) return CUT3R_ERR_ARG;
+    if (d->conv_k == 3 && ((d->Cin & 7) || d->K != 9 * d->Cin)) return CUT3R_ERR_ARG;
+    if (((uintptr_t)d->A | (uintptr_t)d->B | (uintptr_t)d->C) & 15) return CUT3R_ERR_ARG;
+    if (d->res1 && (d->ldr1 & 3)) return CUT3R_ERR_ARG;
+    if (d->res2 && (d->ldr2 & 3)) return CUT3R_ERR_ARG;
+    if (d->shuf && ((d->shuf_cout & 3) || d->N != d->shuf * d->shuf * d->shuf_cout)) return CUT3R_ERR_ARG;
+    GemmArgs g;
+    g.A = (const h16*)d->A; g.B = (const h16*)d->B; g.C = d->C;
+    g.bias = d->bias; g.res1 = d->res1; g.res2 = d->res2;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr1 = d->ldr1; g.ldr2 = d->ldr2;
+    g.act = d->act; g.out_f16 = d->out_f16; g.res1_f16 = d->res1_f16; g.res2_f16 = d->res2_f16;
+    g.sA = d->strideA; g.sB = d->strideB; g.sC = d->strideC; g.sBias = d->strideBias; g.sR1 = d->strideR1; g.sR2 = d->strideR2;
+    g.conv_k = d->conv_k; g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.cstride = d->conv_stride; g.Ho = d->Ho; g.Wo = d->Wo;
+    g.relu_in = d->relu_in;
+    g.shuf = d->shuf; g.shuf_cout = d->shuf_cout; g.shuf_Hin = d->shuf_Hin; g.shuf_Win = d->shuf_Win;
+    const int batch = d->batch > 0 ? d->batch : 1;
+    hipStream_t s = (hipStream_t)stream;
+    const long long big_blocks = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
+    int tile = d->tile;
+    if (tile == 0) tile = (big_blocks >= 192) ? 128 : 64;
+    if (tile == 128) {
+        dim3 grid((d->N + 127) / 128, (d->M + 127) / 128, batch);
+        hipLaunchKernelGGL((gemm_kernel<128, 128>), grid, dim3(256), 0, s, g);
+    } else if (tile == 64) {
+        dim3 grid((d->N + 63) / 64, (d->M + 63) / 64, batch);
+        hipLaunchKernelGGL((gemm_kernel<64, 64>), grid, dim3(256), 0, s, g);
+    } else {
+        return CUT3R_ERR_ARG;
+    }
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_gemv_f16w(const float* X, int ldx, const void* W, int ldw, const float* bias, float* Y, int ldy, int M,
+                               int N, int K, int act, const float* res, int ldr, int silu_in, void* stream) {
+    if (!X || !W || !Y || M <= 0 || M > 64 || N <= 0 || K <= 0 || (K & 7) || (ldw & 7)) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(gemv_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, ldx, (const h16*)W, ldw, bias, Y, ldy,
+                       M, N, K, act, res, ldr, silu_in);
+    return cut3r_check_launch();
+}

@@ -1,0 +1,251 @@
+// HBM-bound geometry kernels of the tracking loop on gfx950 (compiled with -ffp-contract=off: every fp32 operation
+// order below is explicit and identical to oracle/oracle_geom.c, so the integer decisions are bit-exact).
+//   * reprojection-overlap counts   (hislam2/factor_graph.py:255-315 cal_overlap_batch / cal_overlap_bi)
+//   * window alignment of one view  (hislam2/track_frontend.py:193-243)
+//   * log-depth scale reduction     (hislam2/track_frontend.py:216-217)
+//   * patch-overlap keyframe test   (hislam2/util/utils.py:726-736) on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
+#include "common.h"
+#include "../../include/cut3r_hip.h"
+
+namespace {
+
+struct Cam { float fx, fy, cx, cy; int W, H; };
+
+DEVINL int proj_valid(const float* __restrict__ m, float x, float y, float z, const Cam& c, bool clamp_z) {
+    const float xc = fmaf(m[2], z, fmaf(m[1], y, fmaf(m[0], x, m[3])));
+    const float yc = fmaf(m[6], z, fmaf(m[5], y, fmaf(m[4], x, m[7])));
+    const float zc = fmaf(m[10], z, fmaf(m[9], y, fmaf(m[8], x, m[11])));
+    const float zd = clamp_z ? (zc < 1e-5f ? 1e-5f : zc) : zc;
+    const float u = rintf(c.fx * xc / zd + c.cx);
+    const float v = rintf(c.fy * yc / zd + c.cy);
+    return (u >= 0.0f) && (u < (float)c.W) && (v >= 0.0f) && (v < (float)c.H) && (zc > 0.0f);
+}
+
+// forward test: ONE pointmap, B cameras.  Each thread keeps one point in registers and sweeps all cameras (the
+// 3x4 matrices are wave-uniform -> scalar loads), so the pointmap is read from HBM exactly once.  Per-camera counts
+// are accumulated in LDS (wave popcount of the ballot) and flushed with one global atomic per (block, camera).
+constexpr int OVL_MAXB = 2048;
+__global__ __launch_bounds__(256) void overlap_fwd_kernel(const float* __restrict__ pm, int N, const float* __restrict__ w2c, int B,
+                                                          Cam cam, int32_t* __restrict__ counts) {
+    __shared__ int32_t cnt[OVL_MAXB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int p = blockIdx.x * 256 + tid;
+    const bool ok = p < N;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (ok) { x = pm[3 * (size_t)p]; y = pm[3 * (size_t)p + 1]; z = pm[3 * (size_t)p + 2]; }
+    for (int b0 = 0; b0 < B; b0 += OVL_MAXB) {
+        const int nb = min(OVL_MAXB, B - b0);
+        for (int i = tid; i < nb; i += 256) cnt[i] = 0;
+        __syncthreads();
+        for (int b = 0; b < nb; b++) {
+            const int v = ok ? proj_valid(w2c + 12 * (size_t)(b0 + b), x, y, z, cam, true) : 0;
+            const unsigned long long bal = __ballot(v);
+            if (lane == 0) atomicAdd(&cnt[b], (int)__popcll(bal));
+        }
+        __syncthreads();
+        for (int i = tid; i < nb; i += 256)
+            if (cnt[i]) atomicAdd(&counts[b0 + i], cnt[i]);
+        __syncthreads();
+    }
+}
+
+// backward test: B pointmaps, ONE camera: a pure stream over B*N*12 bytes.  Each thread handles 4 consecutive points
+// (three 16-byte loads); grid.y = pointmap, block-level reduction, one atomic per block.
+__global__ __launch_bounds__(256) void overlap_bwd_kernel(const float* __restrict__ pms, int N, const float* __restrict__ w2c,
+                                                          Cam cam, int32_t* __restrict__ counts) {
+    __shared__ int32_t wsum[4];
+    __shared__ float m[12];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 12) m[tid] = w2c[tid];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const float* pm = pms + (size_t)b * N * 3;
+    int c = 0;
+    const int nquad = N >> 2;
+    for (int qd = blockIdx.x * 256 + tid; qd < nquad; qd += gridDim.x * 256) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(pm + (size_t)qd * 12);
+        const f32x4 a = p4[0], bb = p4[1], cc = p4[2];
+        c += proj_valid(m, a[0], a[1], a[2], cam, false);
+        c += proj_valid(m, a[3], bb[0], bb[1], cam, false);
+        c += proj_valid(m, bb[2], bb[3], cc[0], cam, false);
+        c += proj_valid(m, cc[1], cc[2], cc[3], cam, false);
+    }
+    if (blockIdx.x == 0)
+        for (int p = (nquad << 2) + tid; p < N; p += 256) c += proj_valid(m, pm[3 * p], pm[3 * p + 1], pm[3 * p + 2], cam, false);
+    c = wave_sum_i(c);
+    if (lane == 0) wsum[wave] = c;
+    __syncthreads();
+    if (tid == 0) {
+        const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t) atomicAdd(&counts[b], t);
+    }
+}
+
+struct AlignArgs { float P[12]; float s; };
+
+__global__ __launch_bounds__(256) void align_depth_kernel(const float* __restrict__ pts, int n, float s, float* __restrict__ depth) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * blockDim.x)
+        depth[i] = s * pts[3 * i + 2];
+}
+
+__global__ __launch_bounds__(256) void align_ds_kernel(const float* __restrict__ pts, const float* __restrict__ conf, int H, int W,
+                                                       AlignArgs a, int ds, float* __restrict__ pm_ds, float* __restrict__ conf_ds) {
+    const int Hd = H / ds, Wd = W / ds;
+    const size_t total = (size_t)Hd * Wd;
+    for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(o / Wd), x = (int)(o - (size_t)y * Wd);
+        const size_t i = (size_t)(y * ds) * W + (size_t)(x * ds);
+        const float px = a.s * pts[3 * i], py = a.s * pts[3 * i + 1], pz = a.s * pts[3 * i + 2];
+        pm_ds[3 * o + 0] = fmaf(a.P[2], pz, fmaf(a.P[1], py, fmaf(a.P[0], px, a.P[3])));
+        pm_ds[3 * o + 1] = fmaf(a.P[6], pz, fmaf(a.P[5], py, fmaf(a.P[4], px, a.P[7])));
+        pm_ds[3 * o + 2] = fmaf(a.P[10], pz, fmaf(a.P[9], py, fmaf(a.P[8], px, a.P[11])));
+        conf_ds[o] = 1.0f - 1.0f / conf[i];
+    }
+}
+
+// sum(log prev - log z): per-thread double accumulation, wave shuffle + one double atomic per block.
+__global__ __launch_bounds__(256) void logdepth_kernel(const float* __restrict__ prev, const float* __restrict__ pts, int n,
+                                                       double* __restrict__ out) {
+    __shared__ double wsum[4];
+    double acc = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * blockDim.x)
+        acc += (double)logf(prev[i]) - (double)logf(pts[3 * i + 2]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ patch overlap
+// F.normalize(x, dim=1): x / max(||x||, 1e-12); one wave per row; rows 1.. only (row 0 dropped by the reference).
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ f, int Nv, int C, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Nv) return;
+    const float* x = f + (size_t)(row + 1) * C;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    for (int c = lane * 4; c < C; c += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+        v[0] /= nrm; v[1] /= nrm; v[2] /= nrm; v[3] /= nrm;
+        *reinterpret_cast<f32x4*>(out + (size_t)row * C + c) = v;
+    }
+}
+
+// one wave per (32-row tile of f0, 32-row tile of f1): exact-fp32 MFMA 32x32x2; the k order is permuted identically
+// for both operands (lane half h takes k = 8j + 4h + s), which lets every lane stream 16-byte pieces of its own row.
+__global__ __launch_bounds__(64) void simmax_kernel(const float* __restrict__ f0, const float* __restrict__ f1, int Nv, int C,
+                                                    unsigned int* __restrict__ rowmax_bits) {
+    const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5;
+    const int rt = blockIdx.y, ct = blockIdx.x;
+    const int ra = min(rt * 32 + r, Nv - 1), rb = min(ct * 32 + r, Nv - 1);
+    const float* pa = f0 + (size_t)ra * C + 4 * hh;
+    const float* pb = f1 + (size_t)rb * C + 4 * hh;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    for (int j = 0; j < C; j += 8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pa + j);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pb + j);
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    }
+    const bool colok = (ct * 32 + r) < Nv;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        float v = colok ? acc[i] : 0.f;
+        v = fmaxf(v, 0.f);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));   // max over the 32 lanes of this half
+        const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (r == 0 && row < Nv) atomicMax(&rowmax_bits[row], __float_as_uint(v));
+    }
+}
+
+__global__ __launch_bounds__(256) void count_gt_kernel(const unsigned int* __restrict__ rowmax_bits, int Nv, float thr,
+                                                       int32_t* __restrict__ count) {
+    int c = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Nv; i += gridDim.x * 256) c += __uint_as_float(rowmax_bits[i]) > thr;
+    c = wave_sum_i(c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+inline int grid_for(size_t total, int block = 256) {
+    size_t g = (total + block - 1) / block;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int cut3r_overlap_fwd(const float* pm, int N, const float* w2c, int B, float fx, float fy, float cx, float cy, int W,
+                                 int H, int32_t* counts, void* stream) {
+    if (!pm || !w2c || !counts || N <= 0 || B <= 0) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * B, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    Cam cam{fx, fy, cx, cy, W, H};
+    hipLaunchKernelGGL(overlap_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, pm, N, w2c, B, cam, counts);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_overlap_bwd(const float* pms, int B, int N, const float* w2c, float fx, float fy, float cx, float cy, int W,
+                                 int H, int32_t* counts, void* stream) {
+    if (!pms || !w2c || !counts || N <= 0 || B <= 0 || B > 65535) return CUT3R_ERR_ARG;
+    if ((uintptr_t)pms & 15 || ((size_t)N * 12) & 15) return CUT3R_ERR_ARG;   // 16-B loads per pointmap
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * B, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    Cam cam{fx, fy, cx, cy, W, H};
+    int gx = ((N >> 2) + 255) / 256;
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(overlap_bwd_kernel, dim3(gx, B), dim3(256), 0, s, pms, N, w2c, cam, counts);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_align_view(const float* pts, const float* conf, int H, int W, const float* P_host, float s, int ds,
+                                float* pm_ds, float* conf_ds, float* depth, void* stream) {
+    if (!pts || !conf || !P_host || !pm_ds || !conf_ds || !depth || H <= 0 || W <= 0 || ds <= 0) return CUT3R_ERR_ARG;
+    AlignArgs a;
+    for (int i = 0; i < 12; i++) a.P[i] = P_host[i];
+    a.s = s;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(align_depth_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, st, pts, H * W, s, depth);
+    hipLaunchKernelGGL(align_ds_kernel, dim3(grid_for((size_t)(H / ds) * (W / ds))), dim3(256), 0, st, pts, conf, H, W, a, ds, pm_ds,
+                       conf_ds);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_logdepth_sum(const float* prev_depth, const float* pts, int n, double* out, void* stream) {
+    if (!prev_depth || !pts || !out || n <= 0) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(double), s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    int g = grid_for((size_t)n);
+    if (g > 512) g = 512;
+    hipLaunchKernelGGL(logdepth_kernel, dim3(g), dim3(256), 0, s, prev_depth, pts, n, out);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_patch_overlap(const float* feat0, const float* feat1, int N, int C, float thr, void* ws, int32_t* count,
+                                   void* stream) {
+    if (!feat0 || !feat1 || !ws || !count || N < 2 || C <= 0 || (C & 7)) return CUT3R_ERR_ARG;
+    if (((uintptr_t)feat0 | (uintptr_t)feat1 | (uintptr_t)ws) & 15) return CUT3R_ERR_ARG;
+    const int Nv = N - 1;
+    hipStream_t s = (hipStream_t)stream;
+    float* n0 = (float*)ws;
+    float* n1 = n0 + (size_t)Nv * C;
+    unsigned int* rmax = (unsigned int*)(n1 + (size_t)Nv * C);
+    if (hipMemsetAsync(rmax, 0, sizeof(unsigned int) * Nv, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    if (hipMemsetAsync(count, 0, sizeof(int32_t), s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    hipLaunchKernelGGL(rownorm_kernel, dim3((Nv + 3) / 4), dim3(256), 0, s, feat0, Nv, C, n0);
+    hipLaunchKernelGGL(rownorm_kernel, dim3((Nv + 3) / 4), dim3(256), 0, s, feat1, Nv, C, n1);
+    const int T = (Nv + 31) / 32;
+    hipLaunchKernelGGL(simmax_kernel, dim3(T, T), dim3(64), 0, s, n0, n1, Nv, C, rmax);
+    hipLaunchKernelGGL(count_gt_kernel, dim3(grid_for((size_t)Nv)), dim3(256), 0, s, rmax, Nv, thr, count);
+    return cut3r_check_launch();
+}

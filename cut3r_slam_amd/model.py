@@ -1,0 +1,595 @@
+"""MI355X runtime of the CUT3R pointmap network behind the reference's model interface.
+
+Mirrors (same names / argument meaning / outputs) the surface the SLAM trackers use:
+    ARCroco3DStereo.from_pretrained(path)          /root/reference/src/dust3r/model.py:305-318
+    .normalize(img)                                 :1111-1114
+    .encode_image(view) -> (feat, pos, shape)       :1102-1109
+    .forward(views, ret_state) / __call__           :894-900, 816-892
+and loads the reference state_dict schema (cut3r_slam_amd.config.state_dict_schema).
+
+Execution model: weights are converted once to fp16 [N,K] panels resident in HBM; every operator is a hand-written
+gfx950 kernel launched through the C ABI (cut3r_slam_amd.ops); the residual streams stay fp32, GEMM/attention
+operands are fp16 with fp32 accumulation (the MI355X has no TF32: fp16-in/fp32-acc MFMA carries the same 10-bit
+mantissa the reference's TF32 matmuls do).  The six encoder passes of a window run as ONE batched pass, the DPT
+head runs once per window over all views (it does not feed the recurrence), and the dummy zero ray-map encode
+(model.py:644-653, multiplied by 0.0) is skipped.
+"""
+from __future__ import annotations
+
+import math
+import re
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .config import Cut3rConfig, production_config, state_dict_schema
+
+F16, F32 = torch.float16, torch.float32
+
+
+@dataclass
+class ARCroco3DStereoOutput:          # model.py:50-56 (ModelOutput with ress, views)
+    ress: Optional[List[dict]] = None
+    views: Optional[List[dict]] = None
+
+
+class _Lin:
+    """fp16 [N,K] weight panel + fp32 bias, N padded up to a multiple of 4 for the vector epilogue."""
+
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], dev):
+        n = w.shape[0]
+        self.n = n
+        pad = (-n) % 4
+        w2 = w.reshape(n, -1).to(F32)
+        if pad:
+            w2 = torch.cat([w2, torch.zeros(pad, w2.shape[1])], 0)
+            if b is not None:
+                b = torch.cat([b.to(F32), torch.zeros(pad)], 0)
+        self.w = w2.to(device=dev, dtype=F16).contiguous()
+        self.b = b.to(device=dev, dtype=F32).contiguous() if b is not None else None
+        self.npad = n + pad
+        self.k = self.w.shape[1]
+
+
+class Cut3rModel:
+    def __init__(self, cfg: Cut3rConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", minimal: bool = False):
+        """minimal=True computes only what the SLAM trackers consume (pts3d_in_self_view, conf_self, camera_pose:
+        hislam2/track_frontend.py:81-100) and skips dpt_cross / dpt_rgb / final_transform."""
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.minimal = minimal
+        schema = state_dict_schema(cfg)
+        missing = [k for k in schema if k not in state_dict]
+        if missing:
+            raise KeyError(f"state_dict is missing {len(missing)} tensors, e.g. {missing[:4]}")
+        for k, shp in schema.items():
+            if tuple(state_dict[k].shape) != tuple(shp):
+                raise ValueError(f"{k}: shape {tuple(state_dict[k].shape)} != schema {tuple(shp)}")
+        self._buf: Dict[tuple, torch.Tensor] = {}
+        self._prep(state_dict)
+
+    # ------------------------------------------------------------------ reference-compatible constructors
+    @classmethod
+    def from_state_dict(cls, cfg, sd, device="cuda:0", **kw):
+        return cls(cfg, sd, device, **kw)
+
+    @classmethod
+    def from_pretrained(cls, path: str, config: Optional[Cut3rConfig] = None, device="cuda:0", **kw):
+        """Load a reference checkpoint (ckpt['model'] = state_dict; ckpt['args'].model = constructor string,
+        model.py:72-92).  Only weights_only loading is used; the constructor string is parsed, never eval'd."""
+        import argparse
+        import os
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"{path}: no checkpoint (this runtime never fetches from a hub)")
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        sd = ckpt["model"] if "model" in ckpt else ckpt
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        if not any(k.startswith("dec_blocks_state") for k in sd):       # model.py:390-393
+            for k in list(sd):
+                if k.startswith("dec_blocks"):
+                    sd[k.replace("dec_blocks", "dec_blocks_state")] = sd[k]
+        if config is None:
+            config = production_config()
+            args = getattr(ckpt.get("args", None), "model", "") if isinstance(ckpt, dict) else ""
+            config = _config_from_ctor_string(args, config)
+        return cls(config, sd, device, **kw)
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ weight preparation
+    def _prep(self, sd):
+        cfg, dev = self.cfg, self.device
+        f32 = lambda k: sd[k].to(device=dev, dtype=F32).contiguous()
+        self.w: Dict[str, object] = {}
+
+        def lin(name, key=None):
+            key = key or name
+            self.w[name] = _Lin(sd[key + ".weight"], sd.get(key + ".bias"), dev)
+
+        def ln(name):
+            self.w[name] = (f32(name + ".weight"), f32(name + ".bias"))
+
+        def enc_block(p):
+            ln(p + ".norm1"); lin(p + ".attn.qkv"); lin(p + ".attn.proj"); ln(p + ".norm2")
+            lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
+
+        def dec_block(p):
+            ln(p + ".norm1"); lin(p + ".attn.qkv"); lin(p + ".attn.proj")
+            ln(p + ".norm2"); ln(p + ".norm3"); ln(p + ".norm_y")
+            lin(p + ".cross_attn.projq"); lin(p + ".cross_attn.proj")
+            wkv = torch.cat([sd[p + ".cross_attn.projk.weight"], sd[p + ".cross_attn.projv.weight"]], 0)
+            bkv = torch.cat([sd[p + ".cross_attn.projk.bias"], sd[p + ".cross_attn.projv.bias"]], 0)
+            self.w[p + ".cross_attn.projkv"] = _Lin(wkv, bkv, dev)
+            lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
+
+        self.w["patch_embed"] = _Lin(sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], dev)
+        for i in range(cfg.enc_depth):
+            enc_block(f"enc_blocks.{i}")
+        ln("enc_norm")
+        lin("decoder_embed"); lin("decoder_embed_state")
+        for i in range(cfg.dec_depth):
+            dec_block(f"dec_blocks.{i}"); dec_block(f"dec_blocks_state.{i}")
+        ln("dec_norm"); ln("dec_norm_state")
+        lin("pose_retriever.proj_q")
+        for i in range(2):
+            dec_block(f"pose_retriever.write_blocks.{i}"); dec_block(f"pose_retriever.read_blocks.{i}")
+        self.pose_token = f32("pose_token").reshape(1, -1)
+        self.masked_token = f32("pose_retriever.masked_token").reshape(1, -1)
+        self.mem0 = f32("pose_retriever.mem").reshape(cfg.local_mem_size, -1)
+        self.register_tokens16 = sd["register_tokens.weight"].to(device=dev, dtype=F16).contiguous()
+        w = cfg.state_width
+        i = torch.arange(cfg.state_size)
+        self.state_pos = torch.stack([i // w, i % w], -1)[None].to(dev).contiguous()       # int64 [1,S,2]
+        h = "downstream_head"
+        lin(h + ".pose_head.mlp.fc1"); lin(h + ".pose_head.mlp.fc2")
+        if cfg.head_type == "dpt":
+            self._prep_dpt(sd, h + ".dpt_self", 4)
+            if not self.minimal:
+                self._prep_dpt(sd, h + ".dpt_cross", 4)
+                if cfg.rgb_head:
+                    self._prep_dpt(sd, h + ".dpt_rgb", 3)
+        else:
+            lin(h + ".proj.fc1"); lin(h + ".proj.fc2")
+            if not self.minimal:
+                lin(h + ".cross_proj.fc1"); lin(h + ".cross_proj.fc2")
+                if cfg.rgb_head:
+                    lin(h + ".rgb_proj.fc1"); lin(h + ".rgb_proj.fc2")
+        if not self.minimal:
+            for i in range(2):
+                p = f"{h}.final_transform.{i}"
+                for n in ("norm1", "norm2"):
+                    ln(f"{p}.{n}.norm"); lin(f"{p}.{n}.mlp.1")
+                lin(p + ".attn.qkv"); lin(p + ".attn.proj"); lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
+
+    def _prep_dpt(self, sd, p, nch):
+        dev = self.device
+
+        def c3(name):
+            w = sd[name + ".weight"]                                  # [Cout,Cin,3,3] -> [Cout,(ky,kx,ci)]
+            self.w[name] = _Lin(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), sd.get(name + ".bias"), dev)
+
+        def c1(name):
+            w = sd[name + ".weight"]
+            self.w[name] = _Lin(w.reshape(w.shape[0], -1), sd.get(name + ".bias"), dev)
+
+        def ct(name):
+            w = sd[name + ".weight"]                                  # [Cin,Cout,k,k] -> [(i,j,co), ci]
+            k = w.shape[2]
+            l = _Lin(w.permute(2, 3, 1, 0).reshape(k * k * w.shape[1], w.shape[0]), None, dev)
+            l.b = sd[name + ".bias"].to(device=dev, dtype=F32).contiguous()
+            l.s = k
+            self.w[name] = l
+
+        a = p + ".act_postprocess"
+        c1(a + ".0.0"); ct(a + ".0.1"); c1(a + ".1.0"); ct(a + ".1.1"); c1(a + ".2.0"); c1(a + ".3.0"); c3(a + ".3.1")
+        for i in range(4):
+            c3(f"{p}.scratch.layer_rn.{i}")
+        for r in (1, 2, 3, 4):
+            q = f"{p}.scratch.refinenet{r}"
+            c1(q + ".out_conv")
+            for u in ("resConfUnit1", "resConfUnit2"):
+                c3(f"{q}.{u}.conv1"); c3(f"{q}.{u}.conv2")
+        c3(p + ".head.0"); c3(p + ".head.2")
+        self.w[p + ".head.4.w"] = sd[p + ".head.4.weight"].reshape(nch, -1).to(device=dev, dtype=F32).contiguous()
+        self.w[p + ".head.4.b"] = sd[p + ".head.4.bias"].to(device=dev, dtype=F32).contiguous()
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, name, shape, dtype):
+        key = (name, tuple(shape), dtype)
+        t = self._buf.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._buf[key] = t
+        return t
+
+    # ------------------------------------------------------------------ primitives
+    def _linear(self, x16, name, out, act=0, res1=None, res2=None):
+        L = self.w[name]
+        return ops.linear(x16, L.w, out, L.b, act, res1, res2)
+
+    def _ln(self, x, name, out16=None, out32=None, mod=None):
+        g, b = self.w[name]
+        ops.layernorm(x, g, b, self.cfg.ln_eps, out16, out32, mod[0] if mod else None, mod[1] if mod else None)
+
+    def _rope(self, t, pos):
+        ops.rope_2d(t, pos, self.cfg.rope_freq, 1.0)
+
+    def _self_attn(self, tag, x_ln16, B, N, heads, pos, p, out, res):
+        """x_ln16 fp16 [B*N,C] -> out(fp32) = res + proj(attn(qkv(x)))"""
+        Cc = x_ln16.shape[1]
+        D = Cc // heads
+        qkv = self.buf(tag + ".qkv", (B * N, 3 * Cc), F16)
+        self._linear(x_ln16, p + ".qkv", qkv)
+        v5 = qkv.view(B, N, 3, heads, D)
+        q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
+        if pos is not None:
+            self._rope(q, pos)
+            self._rope(k, pos)
+        a = self.buf(tag + ".attn", (B, N, heads, D), F16)
+        ops.attention(q, k, v, a, D ** -0.5)
+        self._linear(a.view(B * N, Cc), p + ".proj", out, res1=res)
+
+    def _mlp(self, tag, x_ln16, p, out, res):
+        M = x_ln16.shape[0]
+        hdim = self.w[p + ".fc1"].npad
+        h = self.buf(tag + ".mlp_h", (M, hdim), F16)
+        self._linear(x_ln16, p + ".fc1", h, act=1)
+        self._linear(h, p + ".fc2", out, res1=res)
+
+    # ------------------------------------------------------------------ encoder
+    def _encode(self, img: torch.Tensor):
+        """img [B,3,H,W] (fp32 normalised, or uint8 -> normalisation fused).  Returns fp32 feat [B,N,E], fp16 copy."""
+        cfg = self.cfg
+        B, _, H, W = img.shape
+        P, E = cfg.patch_size, cfg.enc_embed_dim
+        nh, nw = H // P, W // P
+        N = nh * nw
+        M = B * N
+        tag = f"enc{B}x{N}"
+        patches = self.buf(tag + ".patches", (M, 3 * P * P), F16)
+        ops.im2col_patch(img.contiguous(), P, patches)
+        x = self.buf(tag + ".x", (M, E), F32)
+        self._linear(patches, "patch_embed", x)
+        y, xx = torch.meshgrid(torch.arange(nh, device=self.device), torch.arange(nw, device=self.device), indexing="ij")
+        pos = torch.stack([y.reshape(-1), xx.reshape(-1)], -1)[None].expand(B, -1, -1).contiguous()
+        ln16 = self.buf(tag + ".ln16", (M, E), F16)
+        for i in range(cfg.enc_depth):
+            p = f"enc_blocks.{i}"
+            self._ln(x, p + ".norm1", out16=ln16)
+            self._self_attn(tag, ln16, B, N, cfg.enc_num_heads, pos, p + ".attn", x, x)
+            self._ln(x, p + ".norm2", out16=ln16)
+            self._mlp(tag, ln16, p + ".mlp", x, x)
+        feat = torch.empty((B, N, E), dtype=F32, device=self.device)
+        feat16 = torch.empty((B, N, E), dtype=F16, device=self.device)
+        self._ln(x, "enc_norm", out16=feat16.view(M, E), out32=feat.view(M, E))
+        return feat, feat16, pos
+
+    def normalize(self, img_tensor):
+        return (img_tensor / 255.0 - 0.5) / 0.5
+
+    def encode_image(self, view):
+        img = view["img"]
+        if not img.is_cuda:
+            img = img.to(self.device)
+        B = img.shape[0]
+        im_shape = view.get("true_shape", torch.tensor(img.shape[-2:])[None].repeat(B, 1))
+        feat, _, pos = self._encode(img.to(F32) if img.dtype != torch.uint8 else img)
+        return feat, pos, im_shape
+
+    # ------------------------------------------------------------------ decoder block
+    def _dec_block(self, tag, p, x, y, xpos, ypos, heads, out):
+        """x fp32 [Nx,C], y fp32 [Ny,C] -> out fp32 [Nx,C]   (dust3r/blocks.py:292-297); batch = 1."""
+        Nx, Cc = x.shape
+        Ny = y.shape[0]
+        D = Cc // heads
+        ln16 = self.buf(tag + ".ln16", (Nx, Cc), F16)
+        self._ln(x, p + ".norm1", out16=ln16)
+        self._self_attn(tag, ln16, 1, Nx, heads, xpos, p + ".attn", out, x)
+        y16 = self.buf(tag + ".y16", (Ny, Cc), F16)
+        self._ln(y, p + ".norm_y", out16=y16)
+        self._ln(out, p + ".norm2", out16=ln16)
+        q = self.buf(tag + ".q", (1, Nx, heads, D), F16)
+        self._linear(ln16, p + ".cross_attn.projq", q.view(Nx, Cc))
+        kv = self.buf(tag + ".kv", (Ny, 2 * Cc), F16)
+        self._linear(y16, p + ".cross_attn.projkv", kv)
+        kv4 = kv.view(1, Ny, 2, heads, D)
+        k, v = kv4[:, :, 0], kv4[:, :, 1]
+        if xpos is not None:
+            self._rope(q, xpos)
+        if ypos is not None:
+            self._rope(k, ypos)
+        a = self.buf(tag + ".cattn", (1, Nx, heads, D), F16)
+        ops.attention(q, k, v, a, D ** -0.5)
+        self._linear(a.view(Nx, Cc), p + ".cross_attn.proj", out, res1=out)
+        self._ln(out, p + ".norm3", out16=ln16)
+        self._mlp(tag, ln16, p + ".mlp", out, out)
+        return out
+
+    # ------------------------------------------------------------------ pose memory
+    def _mem_inquire(self, gfeat16, mem):
+        cfg = self.cfg
+        D = cfg.dec_embed_dim
+        x = self.buf("memr.x", (1, 2 * D), F32)
+        self._linear(gfeat16, "pose_retriever.proj_q", x[:, :D])
+        x[:, D:] = self.masked_token
+        a, b = x, self.buf("memr.x2", (1, 2 * D), F32)
+        for i in range(2):
+            self._dec_block("memr", f"pose_retriever.read_blocks.{i}", a, mem, None, None, cfg.dec_num_heads, b)
+            a, b = b, a
+        return a[:, D:]
+
+    def _mem_update(self, mem, gfeat16, pose_out, out):
+        cfg = self.cfg
+        D = cfg.dec_embed_dim
+        f = self.buf("memw.f", (1, 2 * D), F32)
+        self._linear(gfeat16, "pose_retriever.proj_q", f[:, :D])
+        f[:, D:] = pose_out
+        tmp = self.buf("memw.tmp", tuple(mem.shape), F32)
+        self._dec_block("memw", "pose_retriever.write_blocks.0", mem, f, None, None, cfg.dec_num_heads, tmp)
+        self._dec_block("memw", "pose_retriever.write_blocks.1", tmp, f, None, None, cfg.dec_num_heads, out)
+        return out
+
+    # ------------------------------------------------------------------ heads
+    def _conv3(self, x, name, stride=1, relu_in=False, act=0, res1=None, res2=None, tag=None):
+        L = self.w[name]
+        B, H, W, _ = x.shape
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        out = self.buf(tag or name, (B, Ho, Wo, L.npad), F16)
+        return ops.conv3x3_nhwc(x, L.w, out, L.b, stride, relu_in, act, res1, res2)
+
+    def _conv1(self, x, name, tag=None):
+        L = self.w[name]
+        B, H, W, Cc = x.shape
+        out = self.buf(tag or name, (B, H, W, L.npad), F16)
+        ops.linear(x.view(-1, Cc), L.w, out.view(-1, L.npad), L.b)
+        return out
+
+    def _convT(self, x, name):
+        L = self.w[name]
+        B, H, W, Cc = x.shape
+        cout = L.npad // (L.s * L.s)
+        out = self.buf(name, (B, H * L.s, W * L.s, cout), F16)
+        return ops.conv_transpose_nhwc(x, L.w, out, L.b, L.s)
+
+    def _up2(self, x, tag):
+        B, H, W, Cc = x.shape
+        return ops.upsample2x(x, self.buf(tag, (B, 2 * H, 2 * W, Cc), F16))
+
+    def _rcu(self, x, p, res2=None):
+        t = self._conv3(x, p + ".conv1", relu_in=True, act=2)
+        return self._conv3(t, p + ".conv2", res1=x, res2=res2)
+
+    def _fusion(self, p, x0, x1=None):
+        out = x0 if x1 is None else self._rcu(x1, p + ".resConfUnit1", res2=x0)
+        out = self._rcu(out, p + ".resConfUnit2")
+        out = self._up2(out, p + ".up")
+        return self._conv1(out, p + ".out_conv")
+
+    def _dpt(self, p, toks16: List[torch.Tensor], B, nh, nw):
+        """toks16: 4 fp16 tensors [B*nh*nw, C_i] (NHWC token maps).  Returns fp16 [B*H*W, last_dim] features."""
+        a = p + ".act_postprocess"
+        t = [x.view(B, nh, nw, -1) for x in toks16]
+        l0 = self._convT(self._conv1(t[0], a + ".0.0"), a + ".0.1")
+        l1 = self._convT(self._conv1(t[1], a + ".1.0"), a + ".1.1")
+        l2 = self._conv1(t[2], a + ".2.0")
+        l3 = self._conv3(self._conv1(t[3], a + ".3.0"), a + ".3.1", stride=2)
+        L = [self._conv3(l, f"{p}.scratch.layer_rn.{i}") for i, l in enumerate((l0, l1, l2, l3))]
+        p4 = self._fusion(p + ".scratch.refinenet4", L[3])
+        if p4.shape[1] != L[2].shape[1] or p4.shape[2] != L[2].shape[2]:
+            p4 = p4[:, : L[2].shape[1], : L[2].shape[2]].contiguous()          # dpt_head.py:63-65 crop
+        p3 = self._fusion(p + ".scratch.refinenet3", p4, L[2])
+        p2 = self._fusion(p + ".scratch.refinenet2", p3, L[1])
+        p1 = self._fusion(p + ".scratch.refinenet1", p2, L[0])
+        o = self._conv3(p1, p + ".head.0")
+        o = self._up2(o, p + ".head.up")
+        o = self._conv3(o, p + ".head.2", act=2)
+        return o
+
+    def _dpt_pts(self, p, toks16, B, nh, nw, H, W, key_pts, key_conf, res):
+        o = self._dpt(p, toks16, B, nh, nw)
+        pts = torch.empty((B, H, W, 3), dtype=F32, device=self.device)
+        conf = torch.empty((B, H, W), dtype=F32, device=self.device)
+        ops.dpt_final(o.view(B * H * W, -1), self.w[p + ".head.4.w"], self.w[p + ".head.4.b"], 0, pts, conf)
+        res[key_pts], res[key_conf] = pts, conf
+
+    # ------------------------------------------------------------------ window forward
+    @torch.no_grad()
+    def forward_window(self, imgs: torch.Tensor, return_taps: bool = False):
+        """imgs [V,3,H,W] on the GPU (fp32 normalised or uint8).  Returns (list of V pred dicts, taps)."""
+        cfg = self.cfg
+        V, _, H, W = imgs.shape
+        P, E, D, Ld = cfg.patch_size, cfg.enc_embed_dim, cfg.dec_embed_dim, cfg.dec_depth
+        nh, nw = H // P, W // P
+        N, S = nh * nw, cfg.state_size
+        feat, feat16, pos = self._encode(imgs)
+        taps = {"enc_feat": feat} if return_taps else None
+
+        # state init (model.py:538-568, 705-711)
+        st = [self.buf("dec.state0", (S, D), F32), self.buf("dec.state1", (S, D), F32)]
+        self._linear(self.register_tokens16, "decoder_embed_state", st[0])
+        im = [self.buf("dec.img0", (N + 1, D), F32), self.buf("dec.img1", (N + 1, D), F32)]
+        mem = [self.buf("dec.mem0", tuple(self.mem0.shape), F32), self.buf("dec.mem1", tuple(self.mem0.shape), F32)]
+        mem[0].copy_(self.mem0)
+        pose_pos = -torch.ones(1, 1, 2, dtype=torch.int64, device=self.device)
+        h1, h2 = Ld * 2 // 4, Ld * 3 // 4
+        tok1 = self.buf("head.tok1", (V, N, D), F16)
+        tok2 = self.buf("head.tok2", (V, N, D), F16)
+        tok3 = self.buf("head.tok3", (V, N, D), F16)
+        tok3_32 = self.buf("head.tok3_32", (V, N, D), F32) if not self.minimal else None
+        pose_tok = self.buf("head.pose_tok", (V, D), F32)
+        pose_tok16 = self.buf("head.pose_tok16", (V, D), F16)
+        g32 = self.buf("dec.g32", (1, E), F32)
+        g16 = self.buf("dec.g16", (1, E), F16)
+        dn32 = self.buf("dec.dn32", (N + 1, D), F32)
+        dn16 = self.buf("dec.dn16", (N + 1, D), F16)
+        states = []
+        cs, cm = 0, 0             # current state / mem buffer index
+        for i in range(V):
+            pos_i = pos[i:i + 1]
+            pos_img = torch.cat([pose_pos, pos_i], dim=1).contiguous()
+            ops.colmean(feat[i], g32.view(-1))
+            ops.cast_f16(g32, g16)
+            a, b = im[0], im[1]
+            if i == 0:
+                a[0:1] = self.pose_token
+            else:
+                a[0:1] = self._mem_inquire(g16, mem[cm])
+            self._linear(feat16[i], "decoder_embed", a[1:])
+            s_a, s_b = st[cs], st[cs ^ 1]
+            for l in range(Ld):
+                self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, self.state_pos, pos_img, cfg.state_dec_num_heads, s_b)
+                self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, self.state_pos, cfg.dec_num_heads, b)
+                s_a, s_b = s_b, s_a
+                a, b = b, a
+                if l + 1 == h1:
+                    ops.cast_f16(a[1:], tok1[i])
+                if l + 1 == h2:
+                    ops.cast_f16(a[1:], tok2[i])
+            # final norms (model.py:694-697): new state = dec_norm_state(state), img = dec_norm(img)
+            self._ln(s_a, "dec_norm_state", out32=s_b)
+            new_state = s_b
+            self._ln(a, "dec_norm", out16=dn16, out32=dn32)
+            tok3[i].copy_(dn16[1:])
+            if tok3_32 is not None:
+                tok3_32[i].copy_(dn32[1:])
+            pose_tok[i].copy_(dn32[0])
+            pose_tok16[i].copy_(dn16[0])
+            self._mem_update(mem[cm], g16, dn32[0:1], mem[cm ^ 1])
+            cm ^= 1
+            # the state ping-pong: make st[cs] hold the new state for the next view
+            cs = 0 if new_state is st[0] else 1
+            if return_taps:
+                states.append((new_state.clone(), mem[cm].clone()))
+        if return_taps:
+            taps["states"] = states
+
+        # ---- heads, batched over the V views of the window
+        preds = [dict() for _ in range(V)]
+        h = "downstream_head"
+        ph = self.buf("head.pose_h", (V, self.w[h + ".pose_head.mlp.fc1"].npad), F16)
+        self._linear(pose_tok16, h + ".pose_head.mlp.fc1", ph, act=1)
+        praw = self.buf("head.pose_raw", (V, 8), F32)
+        self._linear(ph, h + ".pose_head.mlp.fc2", praw)
+        pose = torch.empty((V, 7), dtype=F32, device=self.device)
+        ops.postprocess_pose(praw[:, :7].contiguous(), pose)
+        res: Dict[str, torch.Tensor] = {"camera_pose": pose}
+        toks = [feat16.view(V * N, E), tok1.view(V * N, D), tok2.view(V * N, D), tok3.view(V * N, D)]
+        if cfg.head_type == "dpt":
+            self._dpt_pts(h + ".dpt_self", toks, V, nh, nw, H, W, "pts3d_in_self_view", "conf_self", res)
+        else:
+            self._linear_head(h + ".proj", tok3.view(V * N, D), V, nh, nw, True, "pts3d_in_self_view", "conf_self", res)
+        if not self.minimal:
+            self._cross_heads(toks, tok3_32, pose_tok, pos, V, nh, nw, H, W, res)
+        for i in range(V):
+            for k, v in res.items():
+                preds[i][k] = v[i:i + 1]
+        return preds, taps
+
+    def _linear_head(self, p, tok16, V, nh, nw, pos_z, key_pts, key_conf, res, rgb=False):
+        P = self.cfg.patch_size
+        hdim = self.w[p + ".fc1"].npad
+        hb = self.buf(p + ".h", (tok16.shape[0], hdim), F16)
+        self._linear(tok16, p + ".fc1", hb, act=1)
+        nout = self.w[p + ".fc2"].npad
+        raw = self.buf(p + ".raw", (tok16.shape[0], nout), F32)
+        self._linear(hb, p + ".fc2", raw)
+        nch = nout // (P * P)
+        # pixel shuffle: token (py,px), channel (c,iy,ix) -> pixel (py*P+iy, px*P+ix), channel c   (linear_head.py:310-313)
+        fmap = raw.view(V, nh, nw, nch, P, P).permute(0, 1, 4, 2, 5, 3).reshape(V * nh * P * nw * P, nch).contiguous()
+        H, W = nh * P, nw * P
+        pts = torch.empty((V, H, W, 3), dtype=F32, device=self.device)
+        if rgb:
+            res[key_pts] = ((torch.sigmoid(fmap) * (1 - 2e-6) + 1e-6 - 0.5) * 2).view(V, H, W, 3)
+            return
+        conf = torch.empty((V, H, W), dtype=F32, device=self.device)
+        ops.postprocess_pts(fmap, pos_z, pts, conf)
+        res[key_pts], res[key_conf] = pts, conf
+
+    def _cross_heads(self, toks, tok3_32, pose_tok, pos, V, nh, nw, H, W, res):
+        """pts3d_in_other_view / conf / rgb (dpt_head.py:219-259, linear_head.py:299-346); not consumed by SLAM."""
+        cfg = self.cfg
+        h = "downstream_head"
+        D, N = cfg.dec_embed_dim, nh * nw
+        heads = cfg.dec_num_heads
+        x = self.buf("ft.x", (V * N, D), F32)
+        x.copy_(tok3_32.view(V * N, D))
+        ln16 = self.buf("ft.ln16", (V * N, D), F16)
+        mod = self.buf("ft.mod", (V, 2 * D), F32)
+        for i in range(2):
+            p = f"{h}.final_transform.{i}"
+            for n, fn in (("norm1", "attn"), ("norm2", "mlp")):
+                L = self.w[f"{p}.{n}.mlp.1"]
+                ops.gemv(pose_tok, L.w, mod, L.b, silu_in=True)
+                for v in range(V):            # modulation vectors are per view (batch element)
+                    sh, sc = mod[v, :D].contiguous(), mod[v, D:].contiguous()
+                    g, b = self.w[f"{p}.{n}.norm"]
+                    ops.layernorm(x[v * N:(v + 1) * N], g, b, cfg.ln_eps, ln16[v * N:(v + 1) * N], None, sc, sh)
+                if fn == "attn":
+                    self._self_attn("ft", ln16, V, N, heads, pos, p + ".attn", x, x)
+                else:
+                    self._mlp("ft", ln16, p + ".mlp", x, x)
+        tc16 = self.buf("ft.tc16", (V * N, D), F16)
+        ops.cast_f16(x, tc16)
+        if cfg.head_type == "dpt":
+            if cfg.rgb_head:
+                p = h + ".dpt_rgb"
+                o = self._dpt(p, toks, V, nh, nw)
+                rgb = torch.empty((V, H, W, 3), dtype=F32, device=self.device)
+                ops.dpt_final(o.view(V * H * W, -1), self.w[p + ".head.4.w"], self.w[p + ".head.4.b"], 1, rgb, None)
+                res["rgb"] = rgb
+            self._dpt_pts(h + ".dpt_cross", toks[:3] + [tc16], V, nh, nw, H, W, "pts3d_in_other_view", "conf", res)
+        else:
+            if cfg.rgb_head:
+                self._linear_head(h + ".rgb_proj", toks[3], V, nh, nw, False, "rgb", None, res, rgb=True)
+            self._linear_head(h + ".cross_proj", tc16, V, nh, nw, False, "pts3d_in_other_view", "conf", res)
+
+    # ------------------------------------------------------------------ reference-shaped entry points
+    @torch.no_grad()
+    def forward(self, views, ret_state=False):
+        """views: list of view dicts (hislam2/track_frontend.py:51-72); only the SLAM mode is supported
+        (img_mask=True, ray_mask=False, update=True, reset=False for every view, batch 1)."""
+        for v in views:
+            if v["img"].shape[0] != 1:
+                raise NotImplementedError("batch size per view must be 1 (as in the SLAM trackers)")
+            if not bool(v["img_mask"].all()) or bool(v["ray_mask"].any()) or bool(v["reset"].any()) or \
+                    (v.get("update") is not None and not bool(v["update"].all())):
+                raise NotImplementedError("only img_mask=True, ray_mask=False, update=True, reset=False is supported")
+        imgs = torch.cat([v["img"] for v in views], 0).to(self.device, F32)
+        preds, _ = self.forward_window(imgs)
+        out = ARCroco3DStereoOutput(ress=preds, views=views)
+        return (out, None) if ret_state else out
+
+    __call__ = forward
+
+
+# name aliases so `from cut3r_slam_amd.model import ARCroco3DStereo` reads like the reference import
+ARCroco3DStereo = Cut3rModel
+
+
+def _config_from_ctor_string(s: str, base: Cut3rConfig) -> Cut3rConfig:
+    """Parse 'ARCroco3DStereo(ARCroco3DStereoConfig(state_size=768, ..., enc_embed_dim=1024, ...))' without eval."""
+    if not s:
+        return base
+    d = base.to_dict()
+    for key in ("state_size", "local_mem_size", "enc_embed_dim", "enc_depth", "enc_num_heads", "dec_embed_dim",
+                "dec_depth", "dec_num_heads", "state_dec_num_heads", "ray_enc_depth"):
+        m = re.search(rf"\b{key}\s*=\s*(\d+)", s)
+        if m:
+            d[key] = int(m.group(1))
+    m = re.search(r"head_type\s*=\s*['\"](\w+)['\"]", s)
+    if m:
+        d["head_type"] = m.group(1)
+    m = re.search(r"img_size\s*=\s*\((\d+)\s*,\s*(\d+)\)", s)
+    if m:
+        d["img_size"] = (int(m.group(1)), int(m.group(2)))
+    m = re.search(r"rgb_head\s*=\s*(True|False)", s)
+    if m:
+        d["rgb_head"] = m.group(1) == "True"
+    return Cut3rConfig.from_dict(d)

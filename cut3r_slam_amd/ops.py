@@ -1,0 +1,319 @@
+"""Thin torch-tensor front ends over the C ABI (include/cut3r_hip.h).  torch is used only for device memory and
+the current HIP stream; every computation is a hand-written gfx950 kernel in libcut3r_hip.so.
+
+All functions validate shapes/dtypes/strides on the host BEFORE launching (a faulting kernel can reset the GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+F16, F32 = torch.float16, torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _req(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+def _cuda(*ts):
+    for t in ts:
+        if t is not None:
+            _req(t.is_cuda, "tensor must live on the GPU (no CPU fallback in the product path)")
+
+
+# ------------------------------------------------------------------------------------------------ RoPE
+def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
+    """Drop-in for curope.rope_2d (reference src/croco/models/curope/curope.cpp:49-65): in place on a (B,N,H,D)
+    view; same checks/errors as the reference's TORCH_CHECKs (RuntimeError on violation)."""
+    if tokens.dim() != 4:
+        raise RuntimeError("tokens must have 4 dimensions")
+    if positions.dim() != 3:
+        raise RuntimeError("positions must have 3 dimensions")
+    if tokens.size(0) != positions.size(0):
+        raise RuntimeError("batch size differs between tokens & positions")
+    if tokens.size(1) != positions.size(1):
+        raise RuntimeError("seq_length differs between tokens & positions")
+    if positions.size(2) != 2:
+        raise RuntimeError("positions.shape[2] must be equal to 2")
+    if tokens.is_cuda != positions.is_cuda:
+        raise RuntimeError("tokens and positions are not on the same device")
+    if not tokens.is_cuda:
+        raise RuntimeError("cut3r_slam_amd.rope_2d: GPU tensors only (HIP kernel; no CPU path in the product)")
+    B, N, H, D = tokens.shape
+    if tokens.stride(3) != 1 or tokens.stride(2) != D:
+        raise RuntimeError("tokens are not contiguous")
+    if not positions.is_contiguous():
+        raise RuntimeError("positions are not contiguous")
+    if D % 4 != 0:
+        raise RuntimeError("token dim must be multiple of 4")
+    if positions.dtype != torch.int64:
+        raise RuntimeError("positions must be int64")
+    dt = {F32: 0, F16: 1}.get(tokens.dtype)
+    if dt is None:
+        raise RuntimeError(f"unsupported token dtype {tokens.dtype}")
+    lib = _lib.load()
+    check(lib.cut3r_rope2d(_p(tokens), dt, _p(positions), B, N, H, D, tokens.stride(0), tokens.stride(1),
+                           tokens.stride(2), float(base), float(fwd), _stream()), "cut3r_rope2d")
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def layernorm(x, gamma, beta, eps=1e-6, out16=None, out32=None, mod_scale=None, mod_shift=None):
+    _cuda(x, gamma, beta, out16, out32, mod_scale, mod_shift)
+    _req(x.dtype == F32 and x.dim() == 2 and x.stride(1) == 1, "x must be fp32 [M,C] with unit inner stride")
+    M, Cc = x.shape
+    _req(gamma.dtype == F32 and beta.dtype == F32 and gamma.numel() == Cc and beta.numel() == Cc, "gamma/beta [C] fp32")
+    _req(gamma.is_contiguous() and beta.is_contiguous(), "gamma/beta contiguous")
+    for o, dt in ((out16, F16), (out32, F32)):
+        if o is not None:
+            _req(o.dtype == dt and o.shape == x.shape and o.stride(1) == 1, "bad LN output tensor")
+    for m in (mod_scale, mod_shift):
+        if m is not None:
+            _req(m.dtype == F32 and m.numel() == Cc and m.is_contiguous(), "modulation vectors must be fp32 [C]")
+    lib = _lib.load()
+    check(lib.cut3r_layernorm(_p(x), x.stride(0), _p(gamma), _p(beta), float(eps), M, Cc,
+                              _p(out16), out16.stride(0) if out16 is not None else 0,
+                              _p(out32), out32.stride(0) if out32 is not None else 0,
+                              _p(mod_scale), _p(mod_shift), _stream()), "cut3r_layernorm")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _fill_common(d, A, Bw, out, bias, res1, res2, act, tile):
+    d.A, d.B, d.C = A.data_ptr(), Bw.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.act = act
+    d.out_f16 = 1 if out.dtype == F16 else 0
+    d.batch = 1
+    d.tile = tile
+    for i, r in ((1, res1), (2, res2)):
+        if r is not None:
+            _req(r.dtype in (F16, F32) and r.stride(-1) == 1, "residual must be fp16/fp32 with unit inner stride")
+            setattr(d, f"res{i}", r.data_ptr())
+            setattr(d, f"ldr{i}", r.stride(-2))
+            setattr(d, f"res{i}_f16", 1 if r.dtype == F16 else 0)
+
+
+def linear(A, W, out, bias=None, act=0, res1=None, res2=None, tile=0):
+    """out[M,N] = act(A[M,K] @ W[N,K]^T + bias) (+res1)(+res2).  A,W fp16; out fp16|fp32 (any row stride)."""
+    _cuda(A, W, out, bias, res1, res2)
+    _req(A.dtype == F16 and W.dtype == F16 and A.dim() == 2 and W.dim() == 2, "A,W must be 2-D fp16")
+    M, K = A.shape
+    N = W.shape[0]
+    _req(W.shape[1] == K and out.shape == (M, N), f"shape mismatch A{tuple(A.shape)} W{tuple(W.shape)} out{tuple(out.shape)}")
+    _req(A.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1, "unit inner strides required")
+    _req(out.dtype in (F16, F32), "out must be fp16 or fp32")
+    if bias is not None:
+        _req(bias.dtype == F32 and bias.numel() == N and bias.is_contiguous(), "bias fp32 [N]")
+    for r in (res1, res2):
+        if r is not None:
+            _req(r.shape == (M, N), "residual shape")
+    d = GemmDesc()
+    _fill_common(d, A, W, out, bias, res1, res2, act, tile)
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, A.stride(0), W.stride(0), out.stride(0)
+    lib = _lib.load()
+    check(lib.cut3r_gemm_f16(C.byref(d), _stream()), f"cut3r_gemm_f16 M={M} N={N} K={K}")
+    return out
+
+
+def conv3x3_nhwc(x, Wk, out, bias=None, stride=1, relu_in=False, act=0, res1=None, res2=None, tile=0):
+    """3x3 / pad 1 convolution as implicit GEMM.  x fp16 [B,H,W,Cin] contiguous; Wk fp16 [Cout, 9*Cin] ordered
+    (ky,kx,ci); out fp16 [B,Ho,Wo,Cout] contiguous."""
+    _cuda(x, Wk, out, bias, res1, res2)
+    _req(x.dtype == F16 and x.dim() == 4 and x.is_contiguous(), "x must be contiguous NHWC fp16")
+    Bn, H, Wd, Cin = x.shape
+    Cout = Wk.shape[0]
+    Ho, Wo = (H + 2 - 3) // stride + 1, (Wd + 2 - 3) // stride + 1
+    _req(Wk.dtype == F16 and Wk.shape == (Cout, 9 * Cin) and Wk.is_contiguous(), "Wk must be fp16 [Cout, 9*Cin]")
+    _req(out.shape == (Bn, Ho, Wo, Cout) and out.is_contiguous() and out.dtype in (F16, F32), "bad conv output")
+    M = Bn * Ho * Wo
+    r1 = res1.reshape(M, Cout) if res1 is not None else None
+    r2 = res2.reshape(M, Cout) if res2 is not None else None
+    d = GemmDesc()
+    _fill_common(d, x, Wk, out, bias, r1, r2, act, tile)
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, Cout, 9 * Cin, Cin, 9 * Cin, Cout
+    d.conv_k, d.H, d.W, d.Cin, d.conv_stride, d.Ho, d.Wo, d.relu_in = 3, H, Wd, Cin, stride, Ho, Wo, int(relu_in)
+    lib = _lib.load()
+    check(lib.cut3r_gemm_f16(C.byref(d), _stream()), f"cut3r_gemm_f16(conv3x3) M={M} N={Cout} K={9*Cin}")
+    return out
+
+
+def conv_transpose_nhwc(x, Wt, out, bias, s):
+    """ConvTranspose2d(kernel == stride == s).  x fp16 [B,H,W,Cin]; Wt fp16 [s*s*Cout, Cin] ordered (i,j,co);
+    out fp16 [B,H*s,W*s,Cout]."""
+    _cuda(x, Wt, out, bias)
+    Bn, H, Wd, Cin = x.shape
+    Cout = Wt.shape[0] // (s * s)
+    _req(x.dtype == F16 and x.is_contiguous() and Wt.dtype == F16 and Wt.is_contiguous(), "fp16 contiguous inputs")
+    _req(Wt.shape == (s * s * Cout, Cin) and out.shape == (Bn, H * s, Wd * s, Cout) and out.is_contiguous(), "bad shapes")
+    _req(bias is not None and bias.numel() == Cout, "bias [Cout]")
+    d = GemmDesc()
+    _fill_common(d, x, Wt, out, bias, None, None, 0, 0)
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = Bn * H * Wd, s * s * Cout, Cin, Cin, Cin, Cout
+    d.shuf, d.shuf_cout, d.shuf_Hin, d.shuf_Win = s, Cout, H, Wd
+    lib = _lib.load()
+    check(lib.cut3r_gemm_f16(C.byref(d), _stream()), "cut3r_gemm_f16(convT)")
+    return out
+
+
+def gemv(X, W, out, bias=None, act=0, res=None, silu_in=False):
+    """out[M,N] = act(X[M,K] @ W[N,K]^T + bias) (+res); X,out fp32, W fp16, M <= 64."""
+    _cuda(X, W, out, bias, res)
+    _req(X.dtype == F32 and W.dtype == F16 and out.dtype == F32, "dtypes: X fp32, W fp16, out fp32")
+    M, K = X.shape
+    N = W.shape[0]
+    _req(W.shape[1] == K and out.shape == (M, N) and X.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1, "shapes")
+    if bias is not None:
+        _req(bias.dtype == F32 and bias.numel() == N, "bias")
+    if res is not None:
+        _req(res.dtype == F32 and res.shape == (M, N) and res.stride(1) == 1, "res")
+    lib = _lib.load()
+    check(lib.cut3r_gemv_f16w(_p(X), X.stride(0), _p(W), W.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, act,
+                              _p(res), res.stride(0) if res is not None else 0, int(silu_in), _stream()), "cut3r_gemv_f16w")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attention(q, k, v, out, scale):
+    """q [B,Nq,H,D], k/v [B,Nk,H,D] fp16 views with unit d-stride and head stride D; out [B,Nq,H,D] fp16."""
+    _cuda(q, k, v, out)
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    for t in (q, k, v, out):
+        _req(t.dtype == F16 and t.dim() == 4 and t.stride(3) == 1 and t.stride(2) == D, "attention operands: fp16 (B,N,H,D) views")
+    _req(k.shape == (B, Nk, H, D) and v.shape == (B, Nk, H, D) and out.shape == (B, Nq, H, D), "attention shapes")
+    _req(D in (16, 32, 48, 64, 128), f"unsupported head dim {D}")
+    lib = _lib.load()
+    check(lib.cut3r_attention_f16(_p(q), _p(k), _p(v), _p(out), B, H, Nq, Nk, D, q.stride(0), q.stride(1), k.stride(0),
+                                  k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1), float(scale),
+                                  _stream()), f"cut3r_attention_f16 B={B} H={H} Nq={Nq} Nk={Nk} D={D}")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def im2col_patch(img, P, out):
+    _cuda(img, out)
+    _req(img.dim() == 4 and img.is_contiguous() and img.dtype in (F32, torch.uint8), "img [B,C,H,W] fp32|u8 contiguous")
+    B, Cc, H, W = img.shape
+    _req(out.dtype == F16 and out.is_contiguous() and out.shape == (B * (H // P) * (W // P), Cc * P * P), "im2col out shape")
+    lib = _lib.load()
+    check(lib.cut3r_im2col_patch(_p(img), int(img.dtype == torch.uint8), B, Cc, H, W, P, _p(out), _stream()), "cut3r_im2col_patch")
+    return out
+
+
+def cast_f16(x, out):
+    _cuda(x, out)
+    _req(x.dtype == F32 and out.dtype == F16 and x.shape == out.shape and x.dim() == 2, "cast: 2-D fp32 -> fp16")
+    _req(x.stride(1) == 1 and out.stride(1) == 1, "unit inner stride")
+    lib = _lib.load()
+    check(lib.cut3r_cast_f32_f16(_p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], x.shape[1], _stream()), "cut3r_cast_f32_f16")
+    return out
+
+
+def colmean(x, out):
+    _cuda(x, out)
+    _req(x.dtype == F32 and x.dim() == 2 and x.stride(1) == 1 and out.dtype == F32 and out.numel() == x.shape[1], "colmean")
+    lib = _lib.load()
+    check(lib.cut3r_colmean(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _stream()), "cut3r_colmean")
+    return out
+
+
+def upsample2x(x, out):
+    _cuda(x, out)
+    B, H, W, Cc = x.shape
+    _req(x.dtype == F16 and x.is_contiguous() and out.dtype == F16 and out.is_contiguous() and out.shape == (B, 2 * H, 2 * W, Cc), "upsample2x")
+    lib = _lib.load()
+    check(lib.cut3r_upsample2x_nhwc(_p(x), _p(out), B, H, W, Cc, _stream()), "cut3r_upsample2x_nhwc")
+    return out
+
+
+def dpt_final(x, w, b, mode, pts, conf=None):
+    _cuda(x, w, b, pts, conf)
+    P, Cin = x.shape
+    nout = 4 if mode == 0 else 3
+    _req(x.dtype == F16 and x.is_contiguous() and w.dtype == F32 and w.shape == (nout, Cin) and w.is_contiguous(), "dpt_final in/w")
+    _req(b.dtype == F32 and b.numel() == nout and pts.dtype == F32 and pts.numel() == 3 * P and pts.is_contiguous(), "dpt_final b/pts")
+    if mode == 0:
+        _req(conf is not None and conf.dtype == F32 and conf.numel() == P and conf.is_contiguous(), "conf")
+    lib = _lib.load()
+    check(lib.cut3r_dpt_final(_p(x), P, Cin, _p(w), _p(b), mode, _p(pts), _p(conf), _stream()), "cut3r_dpt_final")
+
+
+def postprocess_pts(raw, pos_z, pts, conf=None):
+    _cuda(raw, pts, conf)
+    P, nch = raw.shape
+    _req(raw.dtype == F32 and raw.is_contiguous() and pts.dtype == F32 and pts.numel() == 3 * P and pts.is_contiguous(), "postprocess_pts")
+    if nch == 4:
+        _req(conf is not None and conf.numel() == P and conf.dtype == F32 and conf.is_contiguous(), "conf")
+    lib = _lib.load()
+    check(lib.cut3r_postprocess_pts(_p(raw), P, nch, int(pos_z), _p(pts), _p(conf), _stream()), "cut3r_postprocess_pts")
+
+
+def postprocess_pose(raw, out):
+    _cuda(raw, out)
+    _req(raw.dtype == F32 and raw.is_contiguous() and raw.shape[-1] == 7 and out.shape == raw.shape and out.is_contiguous(), "pose")
+    lib = _lib.load()
+    check(lib.cut3r_postprocess_pose(_p(raw), raw.numel() // 7, _p(out), _stream()), "cut3r_postprocess_pose")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ geometry
+def patch_overlap_count(feat0, feat1, thr, ws, count):
+    _cuda(feat0, feat1, ws, count)
+    N, Cc = feat0.shape
+    _req(feat0.dtype == F32 and feat1.dtype == F32 and feat1.shape == (N, Cc) and feat0.is_contiguous() and feat1.is_contiguous(), "features fp32 [N,C]")
+    _req(ws.dtype == F32 and ws.numel() >= 2 * (N - 1) * Cc + (N - 1) and count.dtype == torch.int32, "workspace/count")
+    lib = _lib.load()
+    check(lib.cut3r_patch_overlap(_p(feat0), _p(feat1), N, Cc, float(thr), _p(ws), _p(count), _stream()), "cut3r_patch_overlap")
+
+
+def overlap_fwd(pm, w2c, K4, W, H, counts):
+    _cuda(pm, w2c, counts)
+    N = pm.numel() // 3
+    B = w2c.shape[0]
+    _req(pm.dtype == F32 and pm.is_contiguous() and w2c.dtype == F32 and w2c.shape == (B, 12) and w2c.is_contiguous(), "overlap_fwd inputs")
+    _req(counts.dtype == torch.int32 and counts.numel() >= B, "counts int32[B]")
+    lib = _lib.load()
+    check(lib.cut3r_overlap_fwd(_p(pm), N, _p(w2c), B, *[float(v) for v in K4], int(W), int(H), _p(counts), _stream()), "cut3r_overlap_fwd")
+
+
+def overlap_bwd(pms, w2c, K4, W, H, counts):
+    _cuda(pms, w2c, counts)
+    B = pms.shape[0]
+    N = pms[0].numel() // 3
+    _req(pms.dtype == F32 and pms.is_contiguous() and w2c.dtype == F32 and w2c.numel() == 12 and w2c.is_contiguous(), "overlap_bwd inputs")
+    _req(counts.dtype == torch.int32 and counts.numel() >= B, "counts int32[B]")
+    lib = _lib.load()
+    check(lib.cut3r_overlap_bwd(_p(pms), B, N, _p(w2c), *[float(v) for v in K4], int(W), int(H), _p(counts), _stream()), "cut3r_overlap_bwd")
+
+
+def align_view(pts, conf, P12, s, ds, pm_ds, conf_ds, depth):
+    _cuda(pts, conf, pm_ds, conf_ds, depth)
+    H, W = conf.shape[-2:]
+    _req(pts.dtype == F32 and pts.is_contiguous() and pts.numel() == H * W * 3 and conf.dtype == F32 and conf.is_contiguous(), "align inputs")
+    _req(pm_ds.is_contiguous() and pm_ds.numel() == (H // ds) * (W // ds) * 3 and conf_ds.is_contiguous() and conf_ds.numel() == (H // ds) * (W // ds), "align ds outputs")
+    _req(depth.is_contiguous() and depth.numel() == H * W and depth.dtype == F32, "depth output")
+    arr = (C.c_float * 12)(*[float(v) for v in P12])
+    lib = _lib.load()
+    check(lib.cut3r_align_view(_p(pts), _p(conf), H, W, arr, float(s), int(ds), _p(pm_ds), _p(conf_ds), _p(depth), _stream()), "cut3r_align_view")
+
+
+def logdepth_sum(prev_depth, pts, out):
+    _cuda(prev_depth, pts, out)
+    n = prev_depth.numel()
+    _req(prev_depth.dtype == F32 and prev_depth.is_contiguous() and pts.dtype == F32 and pts.is_contiguous() and pts.numel() == 3 * n, "logdepth inputs")
+    _req(out.dtype == torch.float64 and out.numel() == 1, "out fp64[1]")
+    lib = _lib.load()
+    check(lib.cut3r_logdepth_sum(_p(prev_depth), _p(pts), n, _p(out), _stream()), "cut3r_logdepth_sum")

@@ -1,0 +1,68 @@
+"""Seeded synthetic weights through the reference key schema.
+
+There is no checkpoint in the reference tree and none may be fetched, so parity tests,
+smoke and bench all run on weights generated here: each tensor is drawn from its own PCG64 stream keyed
+by (seed, crc32(key)), so the same (config, seed) gives bit-identical tensors on any machine without
+the reference ever travelling.  Scales are fan-in normalised so activations stay O(1) through the
+24+12-layer stack (a 0.02-std init would make every LayerNorm input vanish and hide kernel errors).
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .config import Cut3rConfig, state_dict_schema
+
+
+def _stream(seed: int, key: str) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, zlib.crc32(key.encode())])))
+
+
+def synth_tensor(key: str, shape, seed: int) -> np.ndarray:
+    g = _stream(seed, key)
+    z = g.standard_normal(size=shape, dtype=np.float32)
+    last = key.rsplit(".", 1)[-1]
+    is_norm = ("norm" in key.split(".")[-2]) if "." in key else False
+    if key.endswith("register_tokens.weight"):
+        return z                                                # nn.Embedding default N(0,1)
+    if key in ("pose_token", "masked_img_token", "masked_ray_map_token") or key.endswith(
+            ("pose_retriever.masked_token", "pose_retriever.mem")):
+        return (0.2 * z).astype(np.float32)
+    if len(shape) == 1:
+        if last == "weight" and is_norm:
+            return (1.0 + 0.1 * z).astype(np.float32)
+        return (0.05 * z).astype(np.float32)
+    if len(shape) == 4:
+        # ConvTranspose2d weights ('.act_postprocess.{0,1}.1.weight') are (Cin, Cout, k, k) with k == stride
+        if ".act_postprocess.0.1." in key or ".act_postprocess.1.1." in key:
+            fan_in = shape[0]
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+    else:
+        fan_in = shape[-1]
+    gain = 1.0
+    # keep the raw xyz/conf logits O(0.3) so expm1/exp stay in a metric range (real depths are 1-5 m)
+    if key.endswith((".head.4.weight", "downstream_head.proj.fc2.weight", "downstream_head.cross_proj.fc2.weight",
+                     "downstream_head.pose_head.mlp.fc2.weight")):
+        gain = 0.25
+    return (z * (gain / np.sqrt(float(fan_in)))).astype(np.float32)
+
+
+def synth_state_dict(cfg: Cut3rConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    sd = OrderedDict()
+    schema = state_dict_schema(cfg)
+    alias = {}
+    for k, shp in schema.items():
+        # scratch.layer_rn.{i} and scratch.layer{i+1}_rn are the same parameter in the reference
+        if ".scratch.layer_rn." in k:
+            head, idx_rest = k.split(".scratch.layer_rn.")
+            idx, rest = idx_rest.split(".", 1)
+            alias[k] = f"{head}.scratch.layer{int(idx) + 1}_rn.{rest}"
+            continue
+        sd[k] = torch.from_numpy(synth_tensor(k, shp, seed))
+    for k, src in alias.items():
+        sd[k] = sd[src]
+    return OrderedDict((k, sd[k]) for k in schema)

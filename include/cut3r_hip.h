@@ -1,0 +1,127 @@
+/* cut3r_hip.h -- C ABI of libcut3r_hip.so: the MI355X (gfx950) kernels behind the CUT3R-SLAM hot path.
+ *
+ * Plain pointers + sizes only (device pointers unless stated), `stream` is a hipStream_t passed as void*.
+ * Every entry point returns 0 on success, 1 on an argument/shape/alignment violation (nothing launched),
+ * 2 if the launch itself failed.  Nothing here allocates, synchronises or touches the default stream, so every
+ * call can be captured into a hipGraph.
+ *
+ * Each function cites the reference interface it replaces (paths relative to /root/reference).
+ */
+#ifndef CUT3R_HIP_H
+#define CUT3R_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- version / probe ------------------------------------------------------------------------------------- */
+int cut3r_abi_version(void);                         /* bumps when a signature changes */
+
+/* ---- RoPE-2D -------------------------------------------------------------------------------------------------
+ * replaces curope.rope_2d(tokens, positions, base, fwd)  (src/croco/models/curope/curope.cpp:49-67,
+ * kernels.cu:17-108).  In place on a (B,N,H,D) view: element (b,n,h,d) at tokens + b*sB + n*sN + h*sH + d
+ * (strides in elements; the reference requires sH == D, stride(3) == 1).  positions: int64 [B,N,2] contiguous,
+ * may be negative.  dtype: 0 = fp32, 1 = fp16 (fp32 math, rounded on store -- the CUDA kernel's contract). */
+int cut3r_rope2d(void* tokens, int dtype, const int64_t* positions, int B, int N, int H, int D,
+                 long long sB, long long sN, long long sH, float base, float fwd, void* stream);
+
+/* ---- LayerNorm (+adaLN modulation) -------------------------------------------------------------------------
+ * replaces nn.LayerNorm(eps=1e-6) calls in croco/models/blocks.py:187-190, dust3r/blocks.py:292-297 and
+ * ModLN (dust3r/blocks.py:356-379: y = LN(x)*(1+scale)+shift).  x fp32 [M,C] (row stride ldx).  Writes any of:
+ * y16 (fp16, ld16) and y32 (fp32, ld32).  mod_scale/mod_shift: optional fp32 [C] (NULL = plain LN). */
+int cut3r_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int M, int C,
+                    void* y16, int ld16, float* y32, int ld32, const float* mod_scale, const float* mod_shift,
+                    void* stream);
+
+/* ---- GEMM family ---------------------------------------------------------------------------------------------
+ * replaces nn.Linear / nn.Conv2d / nn.ConvTranspose2d(+bias)(+GELU|ReLU)(+residual) in the ViT and DPT stacks
+ * (croco/models/blocks.py:68-148, dust3r/blocks.py:87-243, croco/models/dpt_block.py:84-232,281-513).
+ * C[M,N] = epi(A[M,K] * B[N,K]^T); A,B fp16, fp32 accumulate (v_mfma_f32_16x16x32_f16). */
+typedef struct cut3r_gemm_desc {
+    const void* A;        /* fp16 [M,K] row-major (lda) -- or NHWC [Bimg,H,W,Cin] when conv_k == 3 */
+    const void* B;        /* fp16 [N,K] row-major (ldb) == nn.Linear.weight; conv: [Cout][ky][kx][Cin] */
+    void* C;              /* fp16 or fp32 [M,N] (ldc) */
+    const float* bias;    /* fp32 [N] or NULL */
+    const void* res1;     /* optional residual [M,N] (ldr1), fp32 or fp16 */
+    const void* res2;     /* optional second residual */
+    int M, N, K, lda, ldb, ldc, ldr1, ldr2;
+    int act;              /* 0 none, 1 exact GELU (erf), 2 ReLU */
+    int out_f16, res1_f16, res2_f16;
+    int batch;            /* >= 1: independent problems on blockIdx.z with the element strides below */
+    long long strideA, strideB, strideC, strideBias, strideR1, strideR2;
+    int conv_k;           /* 0/1 = plain GEMM (1x1 conv is a plain GEMM over pixels), 3 = implicit 3x3, pad 1 */
+    int H, W, Cin, conv_stride, Ho, Wo;   /* conv_k == 3: input/output spatial sizes, M = Bimg*Ho*Wo, K = 9*Cin */
+    int relu_in;          /* apply ReLU to A on load (ResidualConvUnit pre-activation) */
+    int shuf;             /* > 0: ConvTranspose(k == stride == shuf) scatter; N = shuf*shuf*shuf_cout, ldc = Cout */
+    int shuf_cout, shuf_Hin, shuf_Win;
+    int tile;             /* 0 = auto, 64 or 128 */
+} cut3r_gemm_desc;
+int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream);
+
+/* skinny M<=64 path: Y[M,N] = act(X[M,K] (fp32, optional SiLU on load) * W[N,K]^T (fp16) + bias) (+res) */
+int cut3r_gemv_f16w(const float* X, int ldx, const void* W, int ldw, const float* bias, float* Y, int ldy,
+                    int M, int N, int K, int act, const float* res, int ldr, int silu_in, void* stream);
+
+/* ---- fused attention ---------------------------------------------------------------------------------------------
+ * replaces F.scaled_dot_product_attention(q,k,v, scale) (no mask, p=0) at croco/models/blocks.py:139-145 and
+ * dust3r/blocks.py:123-129,233-239.  fp16 q/k/v, fp32 online softmax, fp16 out.
+ * Element (b,n,h,d) of q lives at q + b*q_sb + n*q_sn + h*D + d (same for k,v with their strides; out likewise).
+ * D in {16,32,48,64,128}. */
+int cut3r_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
+                        long long q_sb, long long q_sn, long long k_sb, long long k_sn, long long v_sb, long long v_sn,
+                        long long o_sb, long long o_sn, float scale, void* stream);
+
+/* ---- elementwise / layout helpers of the ViT path -------------------------------------------------------------- */
+/* PatchEmbed conv 16x16/s16 as im2col (src/dust3r/patch_embed.py:18-32): img fp32 [B,C,H,W] -> fp16 [B*(H/P)*(W/P), C*P*P],
+ * k ordered (c,py,px) == Conv2d weight.flatten(1).  If u8 != 0 the input is uint8 and (x/255-0.5)/0.5
+ * (model.py:1111-1114 `normalize`) is fused into the load. */
+int cut3r_im2col_patch(const void* img, int u8, int B, int C, int H, int W, int P, void* out, void* stream);
+/* fp32 -> fp16 cast of a 2-D view (row strides in elements) */
+int cut3r_cast_f32_f16(const float* x, int ldx, void* y, int ldy, int M, int C, void* stream);
+/* column mean over rows: y[c] = mean_m x[m,c]  (model.py:732 `_get_img_level_feat`) ; x fp32 [M,C] */
+int cut3r_colmean(const float* x, int ldx, int M, int C, float* y, void* stream);
+
+/* ---- DPT head helpers (NHWC fp16 activations) ------------------------------------------------------------------ */
+/* bilinear x2 upsample, align_corners=True (dpt_block.py:215-221, :262-268): in [B,H,W,C] -> out [B,2H,2W,C] */
+int cut3r_upsample2x_nhwc(const void* in, void* out, int B, int H, int W, int C, void* stream);
+/* final 1x1 conv (Cin -> 4 or 3) + output activations (heads/postprocess.py:11-28,113-151):
+ * mode 0: pts3d = xyz/|xyz| * expm1(|xyz|), conf = 1 + exp(c)   -> pts [P,3] fp32, conf [P] fp32
+ * mode 1: rgb = (sigmoid(x)*(1-2e-6)+1e-6 - 0.5)*2              -> pts [P,3] fp32
+ * in: fp16 [P,Cin]; w: fp32 [nout,Cin]; b: fp32 [nout] */
+int cut3r_dpt_final(const void* in, int P, int Cin, const float* w, const float* b, int mode, float* pts, float* conf,
+                    void* stream);
+/* postprocess on raw fp32 [P,4|3] maps (linear head path, pos_z option: linear_head.py:316) */
+int cut3r_postprocess_pts(const float* raw, int P, int nch, int pos_z, float* pts, float* conf, void* stream);
+/* camera pose activation (heads/postprocess.py:30-63): in fp32 [B,7] -> out [B,7] (t*expm1|t|/|t|, unit quat w>=0) */
+int cut3r_postprocess_pose(const float* raw, int B, float* out, void* stream);
+
+/* ---- keyframe selection ---------------------------------------------------------------------------------------------
+ * replaces compute_patch_overlap_ratio (hislam2/util/utils.py:726-736): rows 1.. of feat0/feat1 fp32 [N,C] are
+ * L2-normalised, sim = f0 f1^T (exact fp32 MFMA), count = #rows with max_j sim > thr.  count: int32[1] (device),
+ * zeroed by the call.  ws: 16-B aligned fp32 workspace of 2*(N-1)*C + (N-1) elements. */
+int cut3r_patch_overlap(const float* feat0, const float* feat1, int N, int C, float thr, void* ws, int32_t* count,
+                        void* stream);
+
+/* ---- covisibility graph geometry ------------------------------------------------------------------------------------
+ * replaces FactorGraph.cal_overlap_batch / cal_overlap_bi (hislam2/factor_graph.py:255-315).
+ * w2c: fp32 [B,12] = top 3x4 of inverse(c2w) row-major; K4 = (fx,fy,cx,cy) HOST floats; counts int32[B] (device).
+ * fwd: ONE pointmap pm [N,3] projected into B cameras (z clamped at 1e-5 for the divide, :272).
+ * bwd: B pointmaps pms [B,N,3] projected into ONE camera (raw z divide, :304). */
+int cut3r_overlap_fwd(const float* pm, int N, const float* w2c, int B, float fx, float fy, float cx, float cy, int W, int H,
+                      int32_t* counts, void* stream);
+int cut3r_overlap_bwd(const float* pms, int B, int N, const float* w2c, float fx, float fy, float cx, float cy, int W, int H,
+                      int32_t* counts, void* stream);
+
+/* ---- window alignment -----------------------------------------------------------------------------------------------
+ * replaces the per-view tensor math of TrackFrontend.track (hislam2/track_frontend.py:193-243): pointmap = P*(s*pts),
+ * conf <- 1-1/conf, depth = s*z, stride-`ds` downsample.  P_host: 12 HOST floats (chained c2w 3x4, row-major), s by value
+ * (both are products of tiny 4x4 host math on the 7-float camera poses, exactly as in the reference). */
+int cut3r_align_view(const float* pts, const float* conf, int H, int W, const float* P_host, float s, int ds,
+                     float* pm_ds, float* conf_ds, float* depth, void* stream);
+/* sum_i log(prev_depth[i]) - log(pts[i].z) -> out[0] (fp64 accumulate, device double[1], zeroed by the call) */
+int cut3r_logdepth_sum(const float* prev_depth, const float* pts, int n, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front end of oracle/_build/liboracle_c.so (oracle/oracle_geom.c) plus numpy
+restatements of the small host-side geometry of the reference.  Never imported by the product."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle_c.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "_build/liboracle_c.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.oracle_logdepth_sum.restype = C.c_double
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def rope2d(tokens, pos, base=100.0, fwd=1.0):
+    """tokens [B,N,H,D] fp32 -> rotated copy (CUDA-kernel operation order, kernels.cu:43-54)."""
+    t = _f(tokens).copy()
+    p = np.ascontiguousarray(pos, dtype=np.int64)
+    B, N, H, D = t.shape
+    lib().oracle_rope2d_f32(_ptr(t), _ptr(p, C.c_int64), B, N, H, D, C.c_float(base), C.c_float(fwd))
+    return t
+
+
+def w2c_rows(c2w):
+    """inverse of rigid/affine c2w [B,4,4] in float64, returned as fp32 [B,12] (top 3x4, row-major)."""
+    c2w = np.asarray(c2w, dtype=np.float64).reshape(-1, 4, 4)
+    inv = np.linalg.inv(c2w)
+    return np.ascontiguousarray(inv[:, :3, :].reshape(-1, 12), dtype=np.float32)
+
+
+def overlap_fwd(pm, w2c12, K4, W, H):
+    pm = _f(pm).reshape(-1, 3)
+    w = _f(w2c12).reshape(-1, 12)
+    k = _f(K4)
+    out = np.zeros(w.shape[0], np.int32)
+    lib().oracle_overlap_fwd(_ptr(pm), pm.shape[0], _ptr(w), w.shape[0], _ptr(k), int(W), int(H), _ptr(out, C.c_int32))
+    return out
+
+
+def overlap_bwd(pms, w2c12, K4, W, H):
+    pms = _f(pms)
+    B = pms.shape[0]
+    N = pms[0].size // 3
+    w = _f(w2c12).reshape(12)
+    k = _f(K4)
+    out = np.zeros(B, np.int32)
+    lib().oracle_overlap_bwd(_ptr(pms), B, N, _ptr(w), _ptr(k), int(W), int(H), _ptr(out, C.c_int32))
+    return out
+
+
+def align_view(pts, conf, P12, s, ds):
+    pts, conf = _f(pts), _f(conf)
+    H, W = conf.shape
+    pm = np.zeros((H // ds, W // ds, 3), np.float32)
+    cd = np.zeros((H // ds, W // ds), np.float32)
+    dp = np.zeros((H, W), np.float32)
+    P = _f(P12).reshape(12)
+    lib().oracle_align_view(_ptr(pts), _ptr(conf), H, W, _ptr(P), C.c_float(s), int(ds), _ptr(pm), _ptr(cd), _ptr(dp))
+    return pm, cd, dp
+
+
+def logdepth_sum(prev_depth, pts):
+    a, b = _f(prev_depth), _f(pts)
+    return float(lib().oracle_logdepth_sum(_ptr(a), _ptr(b), a.size))
+
+
+def patch_overlap_ratio(feat0, feat1, thr=0.7):
+    """hislam2/util/utils.py:726-736 in float64 (the decision both fp32 evaluations approximate)."""
+    a = np.asarray(feat0, np.float64)[1:]
+    b = np.asarray(feat1, np.float64)[1:]
+    a = a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-12)
+    b = b / np.maximum(np.linalg.norm(b, axis=1, keepdims=True), 1e-12)
+    mx = (a @ b.T).max(axis=1)
+    return float((mx > thr).mean()), mx

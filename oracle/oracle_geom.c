@@ -1,0 +1,103 @@
+/* TEST INFRASTRUCTURE ONLY -- plain-C restatement of the byte/index-exact geometry on the hot path.
+ * Compiled by oracle/Makefile into oracle/_build/liboracle_c.so; used by tests/, smoke() and bench.py's
+ * cpu_baseline leg as the checker for the HIP kernels.  Never linked into the product.
+ *
+ * Every function fixes ONE fp32 evaluation order (explicit fmaf chains, IEEE divide, rintf = round-half-even
+ * like torch.round) so the HIP kernels can be bit-exact against it.  The reference evaluates the same formulas
+ * through torch.bmm/torch.inverse (hislam2/factor_graph.py:255-315), whose summation order is backend-defined;
+ * tests/test_oracle_golden.py pins these functions against the reference's own outputs (tests/golden/graph.npz).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+
+/* rope_2d: /root/reference/src/croco/models/curope/kernels.cu:17-82 (the CUDA order: inv_freq first, then pos*inv_freq).
+ * tokens [B,N,H,D] fp32 contiguous, pos [B,N,2] int64. */
+void oracle_rope2d_f32(float *tok, const int64_t *pos, int B, int N, int H, int D, float base, float fwd) {
+    int Q = D / 4;
+    for (int b = 0; b < B; b++)
+        for (int n = 0; n < N; n++)
+            for (int X = 0; X < 2; X++) {
+                float p = (float)pos[((size_t)b * N + n) * 2 + X];
+                for (int q = 0; q < Q; q++) {
+                    float inv = fwd / powf(base, (float)q / (float)Q);
+                    float fr = p * inv;
+                    float c = cosf(fr), s = sinf(fr);
+                    for (int h = 0; h < H; h++) {
+                        float *t = tok + (((size_t)b * N + n) * H + h) * D + X * 2 * Q;
+                        float u = t[q], v = t[q + Q];
+                        t[q] = u * c - v * s;
+                        t[q + Q] = v * c + u * s;
+                    }
+                }
+            }
+}
+
+/* One projected point: returns 1 if it lands inside [0,W)x[0,H) with z>0.
+ * w2c is the 3x4 top of a world->camera matrix, row-major. clamp_z mirrors `.clamp(min=1e-5)` in
+ * cal_overlap_batch (factor_graph.py:272) -- cal_overlap_bi (:304) divides by the raw z. */
+static inline int proj_valid(const float *w2c, float x, float y, float z, float fx, float fy, float cx, float cy,
+                             int W, int H, int clamp_z) {
+    float xc = fmaf(w2c[2], z, fmaf(w2c[1], y, fmaf(w2c[0], x, w2c[3])));
+    float yc = fmaf(w2c[6], z, fmaf(w2c[5], y, fmaf(w2c[4], x, w2c[7])));
+    float zc = fmaf(w2c[10], z, fmaf(w2c[9], y, fmaf(w2c[8], x, w2c[11])));
+    float zd = clamp_z ? (zc < 1e-5f ? 1e-5f : zc) : zc;
+    float u = rintf(fx * xc / zd + cx);
+    float v = rintf(fy * yc / zd + cy);
+    return (u >= 0.0f) && (u < (float)W) && (v >= 0.0f) && (v < (float)H) && (zc > 0.0f);
+}
+
+/* cal_overlap_batch (factor_graph.py:255-282): project ONE pointmap [N,3] into B cameras; counts[b] = #valid. */
+void oracle_overlap_fwd(const float *pm, int N, const float *w2c, int B, const float *K4, int W, int H,
+                        int32_t *counts) {
+    for (int b = 0; b < B; b++) {
+        int c = 0;
+        for (int n = 0; n < N; n++)
+            c += proj_valid(w2c + 12 * b, pm[3 * n], pm[3 * n + 1], pm[3 * n + 2], K4[0], K4[1], K4[2], K4[3], W, H, 1);
+        counts[b] = c;
+    }
+}
+
+/* cal_overlap_bi with B2 == 1 (factor_graph.py:284-315 as called at :186 and :566): project B pointmaps
+ * [B,N,3] into ONE camera. */
+void oracle_overlap_bwd(const float *pms, int B, int N, const float *w2c, const float *K4, int W, int H,
+                        int32_t *counts) {
+    for (int b = 0; b < B; b++) {
+        int c = 0;
+        const float *pm = pms + (size_t)b * N * 3;
+        for (int n = 0; n < N; n++)
+            c += proj_valid(w2c, pm[3 * n], pm[3 * n + 1], pm[3 * n + 2], K4[0], K4[1], K4[2], K4[3], W, H, 0);
+        counts[b] = c;
+    }
+}
+
+/* Window alignment of one view (hislam2/track_frontend.py:193-243): given pose P (3x4 row-major c2w, already
+ * chained), scale s, full-res pts [H,W,3] and conf [H,W]:
+ *   pointmap = P * (s*pts)  (geotrf, src/dust3r/utils/geometry.py:49-115), conf' = 1 - 1/conf,
+ *   depth' = s * pts_z, outputs stride-`ds` downsampled pointmap/conf and full-res depth. */
+void oracle_align_view(const float *pts, const float *conf, int H, int W, const float *P, float s, int ds,
+                       float *pm_ds, float *conf_ds, float *depth) {
+    int Hd = H / ds, Wd = W / ds;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            size_t i = (size_t)y * W + x;
+            depth[i] = s * pts[3 * i + 2];
+        }
+    for (int y = 0; y < Hd; y++)
+        for (int x = 0; x < Wd; x++) {
+            size_t i = (size_t)(y * ds) * W + (x * ds), o = (size_t)y * Wd + x;
+            float px = s * pts[3 * i], py = s * pts[3 * i + 1], pz = s * pts[3 * i + 2];
+            pm_ds[3 * o + 0] = fmaf(P[2], pz, fmaf(P[1], py, fmaf(P[0], px, P[3])));
+            pm_ds[3 * o + 1] = fmaf(P[6], pz, fmaf(P[5], py, fmaf(P[4], px, P[7])));
+            pm_ds[3 * o + 2] = fmaf(P[10], pz, fmaf(P[9], py, fmaf(P[8], px, P[11])));
+            conf_ds[o] = 1.0f - 1.0f / conf[i];
+        }
+}
+
+/* sum over pixels of log(prev_depth) - log(pts_z) in double (track_frontend.py:216-217 takes the fp32 mean;
+ * the double sum is the exact value both fp32 evaluations approximate). */
+double oracle_logdepth_sum(const float *prev_depth, const float *pts, int n) {
+    double acc = 0.0;
+    for (int i = 0; i < n; i++) acc += (double)logf(prev_depth[i]) - (double)logf(pts[3 * i + 2]);
+    return acc;
+}
