@@ -25,14 +25,22 @@ DEVINL int proj_valid(const float* __restrict__ m, float x, float y, float z, co
 // 3x4 matrices are wave-uniform -> scalar loads), so the pointmap is read from HBM exactly once.  Per-camera counts
 // are accumulated in LDS (wave popcount of the ballot) and flushed with one global atomic per (block, camera).
 constexpr int OVL_MAXB = 2048;
+struct AlignArgs { float P[12]; float s; };
+
 __global__ __launch_bounds__(256) void overlap_fwd_kernel(const float* __restrict__ pm, int N, const float* __restrict__ w2c, int B,
-                                                          Cam cam, int32_t* __restrict__ counts) {
+                                                          Cam cam, int32_t* __restrict__ counts, int has_align, AlignArgs al) {
     __shared__ int32_t cnt[OVL_MAXB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int p = blockIdx.x * 256 + tid;
     const bool ok = p < N;
     float x = 0.f, y = 0.f, z = 0.f;
     if (ok) { x = pm[3 * (size_t)p]; y = pm[3 * (size_t)p + 1]; z = pm[3 * (size_t)p + 2]; }
+    if (has_align) {   // same operation order as align_ds_kernel / oracle_align_view: the full-res pointmap is never stored
+        const float px = al.s * x, py = al.s * y, pz = al.s * z;
+        x = fmaf(al.P[2], pz, fmaf(al.P[1], py, fmaf(al.P[0], px, al.P[3])));
+        y = fmaf(al.P[6], pz, fmaf(al.P[5], py, fmaf(al.P[4], px, al.P[7])));
+        z = fmaf(al.P[10], pz, fmaf(al.P[9], py, fmaf(al.P[8], px, al.P[11])));
+    }
     for (int b0 = 0; b0 < B; b0 += OVL_MAXB) {
         const int nb = min(OVL_MAXB, B - b0);
         for (int i = tid; i < nb; i += 256) cnt[i] = 0;
@@ -51,15 +59,16 @@ __global__ __launch_bounds__(256) void overlap_fwd_kernel(const float* __restric
 
 // backward test: B pointmaps, ONE camera: a pure stream over B*N*12 bytes.  Each thread handles 4 consecutive points
 // (three 16-byte loads); grid.y = pointmap, block-level reduction, one atomic per block.
-__global__ __launch_bounds__(256) void overlap_bwd_kernel(const float* __restrict__ pms, int N, const float* __restrict__ w2c,
-                                                          Cam cam, int32_t* __restrict__ counts) {
+__global__ __launch_bounds__(256) void overlap_bwd_kernel(const float* __restrict__ pms, int N, int grp, int grp_stride,
+                                                          const float* __restrict__ w2c, Cam cam, int32_t* __restrict__ counts) {
     __shared__ int32_t wsum[4];
     __shared__ float m[12];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 12) m[tid] = w2c[tid];
     __syncthreads();
     const int b = blockIdx.y;
-    const float* pm = pms + (size_t)b * N * 3;
+    const int slot = grp > 0 ? (b / grp) * grp_stride + (b % grp) : b;
+    const float* pm = pms + (size_t)slot * N * 3;
     int c = 0;
     const int nquad = N >> 2;
     for (int qd = blockIdx.x * 256 + tid; qd < nquad; qd += gridDim.x * 256) {
@@ -80,8 +89,6 @@ __global__ __launch_bounds__(256) void overlap_bwd_kernel(const float* __restric
         if (t) atomicAdd(&counts[b], t);
     }
 }
-
-struct AlignArgs { float P[12]; float s; };
 
 __global__ __launch_bounds__(256) void align_depth_kernel(const float* __restrict__ pts, int n, float s, float* __restrict__ depth) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * blockDim.x)
@@ -184,19 +191,22 @@ inline int grid_for(size_t total, int block = 256) {
 
 }  // namespace
 
-extern "C" int cut3r_overlap_fwd(const float* pm, int N, const float* w2c, int B, float fx, float fy, float cx, float cy, int W,
-                                 int H, int32_t* counts, void* stream) {
+extern "C" int cut3r_overlap_fwd(const float* pm, int N, const float* P_host, float s_align, const float* w2c, int B, float fx,
+                                 float fy, float cx, float cy, int W, int H, int32_t* counts, void* stream) {
     if (!pm || !w2c || !counts || N <= 0 || B <= 0) return CUT3R_ERR_ARG;
+    AlignArgs al;
+    for (int i = 0; i < 12; i++) al.P[i] = P_host ? P_host[i] : 0.f;
+    al.s = s_align;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(counts, 0, sizeof(int32_t) * B, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
     Cam cam{fx, fy, cx, cy, W, H};
-    hipLaunchKernelGGL(overlap_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, pm, N, w2c, B, cam, counts);
+    hipLaunchKernelGGL(overlap_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, pm, N, w2c, B, cam, counts, P_host ? 1 : 0, al);
     return cut3r_check_launch();
 }
 
-extern "C" int cut3r_overlap_bwd(const float* pms, int B, int N, const float* w2c, float fx, float fy, float cx, float cy, int W,
-                                 int H, int32_t* counts, void* stream) {
-    if (!pms || !w2c || !counts || N <= 0 || B <= 0 || B > 65535) return CUT3R_ERR_ARG;
+extern "C" int cut3r_overlap_bwd(const float* pms, int B, int N, int grp, int grp_stride, const float* w2c, float fx, float fy,
+                                 float cx, float cy, int W, int H, int32_t* counts, void* stream) {
+    if (!pms || !w2c || !counts || N <= 0 || B <= 0 || B > 65535 || grp < 0 || (grp > 0 && grp_stride < grp)) return CUT3R_ERR_ARG;
     if ((uintptr_t)pms & 15 || ((size_t)N * 12) & 15) return CUT3R_ERR_ARG;   // 16-B loads per pointmap
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(counts, 0, sizeof(int32_t) * B, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
@@ -204,7 +214,7 @@ extern "C" int cut3r_overlap_bwd(const float* pms, int B, int N, const float* w2
     int gx = ((N >> 2) + 255) / 256;
     if (gx < 1) gx = 1;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(overlap_bwd_kernel, dim3(gx, B), dim3(256), 0, s, pms, N, w2c, cam, counts);
+    hipLaunchKernelGGL(overlap_bwd_kernel, dim3(gx, B), dim3(256), 0, s, pms, N, grp, grp_stride, w2c, cam, counts);
     return cut3r_check_launch();
 }
 

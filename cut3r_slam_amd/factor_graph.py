@@ -1,0 +1,233 @@
+"""Covisibility graph of the tracker, same interface and edge ORDER as the reference `FactorGraph`
+(/root/reference/hislam2/factor_graph.py:17-117, 148-197, 255-341, 503-582).
+
+Design differences (results identical, topology bit-exact):
+  * the edge list lives on the host (a Python set + ordered lists): the reference's duplicate filter does two
+    `.item()` device syncs per existing and per new edge (factor_graph.py:29-39); here `add()` costs ONE small
+    device->host copy (the int32 overlap counts of the new keyframe).
+  * the reprojection tests are two HIP kernels over pointmaps that already sit in HBM (ops.overlap_fwd / overlap_bwd);
+    nothing is re-uploaded and no [B,N,4] intermediates are materialised.
+`ii`, `jj`, `age` are exposed as int64 tensors on `device`, rebuilt lazily.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import geom_host as gh
+from . import ops
+
+
+class AlignedPoints:
+    """A chained full-resolution pointmap P*(s*pts) that is never materialised: `pts` [H,W,3] are the network's
+    camera-frame points, P the 3x4 chained c2w (12 floats), s the window scale (track_frontend.py:234,259)."""
+
+    def __init__(self, pts, P12, s):
+        self.pts, self.P12, self.s = pts, [float(v) for v in np.asarray(P12).reshape(-1)], float(s)
+        self.shape = tuple(pts.shape)
+
+
+class SubmapStore:
+    """Keyframe-ordered view of the resident [submap][6 slots][h][w][3] store: keyframe j < n lives at slot
+    (j//5)*6 + j%5 (track_frontend.py:251-255) -- what the reference gathers into `all_pointmaps` with a copy."""
+
+    def __init__(self, submap_ds, n):
+        self.store, self.n = submap_ds, int(n)
+        self.shape = (self.n,) + tuple(submap_ds.shape[2:])
+
+
+class HipOverlapBackend:
+    """Default (and only product) backend: counts from the gfx950 kernels.  Raises if the library is missing."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def fwd(self, pointmap, w2c_rows, K4, W, H):
+        B = w2c_rows.shape[0]
+        cnt = torch.empty(B, dtype=torch.int32, device=self.device)
+        if isinstance(pointmap, AlignedPoints):
+            ops.overlap_fwd(pointmap.pts.contiguous(), w2c_rows, K4, W, H, cnt, pointmap.P12, pointmap.s)
+        else:
+            ops.overlap_fwd(pointmap.contiguous(), w2c_rows, K4, W, H, cnt)
+        return cnt
+
+    def bwd(self, pointmaps, w2c_row, K4, W, H):
+        if isinstance(pointmaps, SubmapStore):
+            B = pointmaps.n
+            cnt = torch.empty(B, dtype=torch.int32, device=self.device)
+            ops.overlap_bwd(pointmaps.store, w2c_row, K4, W, H, cnt, B=B, N=W * H, grp=5, grp_stride=6)
+        else:
+            B = pointmaps.shape[0]
+            cnt = torch.empty(B, dtype=torch.int32, device=self.device)
+            ops.overlap_bwd(pointmaps.contiguous(), w2c_row, K4, W, H, cnt)
+        return cnt
+
+
+class FactorGraph:
+    def __init__(self, keyframes, device="cuda:0", max_factors=-1, backend=None):
+        self.keyframes = keyframes
+        self.device = device
+        self.max_factors = max_factors
+        self._ii, self._jj, self._age = [], [], []
+        self._eset = set()
+        self._cache = None
+        self.backend = backend if backend is not None else HipOverlapBackend(device)
+
+    # ------------------------------------------------------------------ tensor views (reference attribute names)
+    def _tensors(self):
+        if self._cache is None:
+            mk = lambda v: torch.as_tensor(np.asarray(v, dtype=np.int64), dtype=torch.long, device=self.device)
+            self._cache = (mk(self._ii), mk(self._jj), mk(self._age))
+        return self._cache
+
+    @property
+    def ii(self):
+        return self._tensors()[0]
+
+    @property
+    def jj(self):
+        return self._tensors()[1]
+
+    @property
+    def age(self):
+        return self._tensors()[2]
+
+    def edges_numpy(self):
+        return (np.asarray(self._ii, np.int64), np.asarray(self._jj, np.int64), np.asarray(self._age, np.int64))
+
+    # ------------------------------------------------------------------ edge maintenance
+    @staticmethod
+    def _as_list(x):
+        if isinstance(x, torch.Tensor):
+            return [int(v) for v in x.reshape(-1).tolist()]
+        return [int(v) for v in np.asarray(x).reshape(-1).tolist()]
+
+    def add_factors(self, ii, jj, remove=False):
+        """factor_graph.py:59-81: drop pairs already present (NOT duplicates inside the new batch), append in order."""
+        ii, jj = self._as_list(ii), self._as_list(jj)
+        new = [(i, j) for i, j in zip(ii, jj) if (i, j) not in self._eset]
+        if not new:
+            return
+        if self.max_factors > 0 and len(self._ii) + len(new) > self.max_factors and remove:
+            order = np.argsort(np.asarray(self._age), kind="stable")
+            ix = np.arange(len(self._age))[order]
+            self.rm_factors(ix >= self.max_factors - len(new))
+        for i, j in new:
+            self._ii.append(i)
+            self._jj.append(j)
+            self._age.append(0)
+            self._eset.add((i, j))
+        self._cache = None
+
+    def rm_factors(self, mask, store=False):
+        m = mask.cpu().numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
+        keep = ~m.astype(bool)
+        self._ii = [v for v, k in zip(self._ii, keep) if k]
+        self._jj = [v for v, k in zip(self._jj, keep) if k]
+        self._age = [v for v, k in zip(self._age, keep) if k]
+        self._eset = set(zip(self._ii, self._jj))
+        self._cache = None
+
+    def clear_edges(self):
+        self.rm_factors(np.ones(len(self._ii), bool))
+
+    def add_neighborhood_factors(self, t0, t1, r=3):
+        """factor_graph.py:109-117 (row-major meshgrid order)."""
+        ii, jj = [], []
+        for i in range(t0, t1):
+            for j in range(t0, t1):
+                if 0 < abs(i - j) <= r:
+                    ii.append(i)
+                    jj.append(j)
+        self.add_factors(ii, jj)
+
+    # ------------------------------------------------------------------ reprojection overlap
+    @staticmethod
+    def _K4(K):
+        K = np.asarray(K, dtype=np.float64)
+        if K.shape == (3, 3):
+            return [float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])]
+        return [float(v) for v in K.reshape(-1)[:4]]
+
+    def cal_overlap_batch(self, pointmap_i, T_j_batch, K, w2c_rows=None):
+        """factor_graph.py:255-282 -> fp32 ratios [B] (device).  T_j_batch: c2w [B,4,4] (tensor/ndarray)."""
+        H, W, _ = pointmap_i.shape
+        if w2c_rows is None:
+            c2w = T_j_batch.detach().cpu().numpy() if isinstance(T_j_batch, torch.Tensor) else np.asarray(T_j_batch)
+            w2c_rows = torch.from_numpy(gh.w2c_rows(c2w)).to(self.device)
+        cnt = self.backend.fwd(pointmap_i, w2c_rows.contiguous(), self._K4(K), W, H)
+        return cnt.float() / float(H * W)
+
+    def cal_overlap_bi(self, pointmap_i, T_j_batch, K, w2c_row=None):
+        """factor_graph.py:284-315 with B2 == 1 (its only call shape) -> fp32 ratios [B1,1] (device)."""
+        B1, H, W, _ = pointmap_i.shape
+        if w2c_row is None:
+            c2w = T_j_batch.detach().cpu().numpy() if isinstance(T_j_batch, torch.Tensor) else np.asarray(T_j_batch)
+            if c2w.reshape(-1, 4, 4).shape[0] != 1:
+                raise NotImplementedError("cal_overlap_bi: one target camera (the reference never passes more)")
+            w2c_row = torch.from_numpy(gh.w2c_rows(c2w)[0]).to(self.device)
+        cnt = self.backend.bwd(pointmap_i, w2c_row.contiguous(), self._K4(K), W, H)
+        return (cnt.float() / float(H * W)).reshape(B1, 1)
+
+    def add(self, current_idx, all_poses, all_pointmaps, current_pose, current_pointmap, K,
+            all_w2c_rows=None, current_w2c_row=None):
+        """factor_graph.py:148-197.  all_poses [i,4,4] c2w, all_pointmaps [i,h,w,3], current_pose [4,4],
+        current_pointmap [H,W,3] (tensors, or the AlignedPoints / SubmapStore descriptors of resident data);
+        optional precomputed world->camera rows avoid any host inverse."""
+        c2w = all_poses.detach().cpu().numpy() if isinstance(all_poses, torch.Tensor) else np.asarray(all_poses)
+        cur = current_pose.detach().cpu().numpy() if isinstance(current_pose, torch.Tensor) else np.asarray(current_pose)
+        c2w = c2w.astype(np.float32).reshape(-1, 4, 4)
+        cur = cur.astype(np.float32).reshape(4, 4)
+        d = c2w[:, :3, 3] - cur[None, :3, 3]
+        dists = np.sqrt((d * d).sum(axis=1, dtype=np.float32), dtype=np.float32)
+        cond1 = dists <= np.float32(1.0)
+        n = c2w.shape[0]
+        if all_w2c_rows is None:
+            all_w2c_rows = torch.from_numpy(gh.w2c_rows(c2w)).to(self.device)
+        if current_w2c_row is None:
+            current_w2c_row = torch.from_numpy(gh.w2c_rows(cur[None])[0]).to(self.device)
+        H, W, _ = current_pointmap.shape
+        K4 = self._K4(K)
+        # ONE forward launch over every previous camera and ONE backward stream over every previous pointmap (the
+        # reference launches per distance class and gathers copies; counts are per camera, so the decisions are the same)
+        cnt_f = self.backend.fwd(current_pointmap, all_w2c_rows[:n].contiguous(), K4, W, H)
+        idx2 = np.nonzero(~cond1)[0]
+        cnt_b = None
+        hb, wb = all_pointmaps.shape[1], all_pointmaps.shape[2]
+        if idx2.size:
+            cnt_b = self.backend.bwd(all_pointmaps, current_w2c_row.contiguous(), K4, wb, hb)
+        # single device->host hop for the decisions
+        if cnt_b is not None:
+            both = torch.cat([cnt_f.reshape(-1), cnt_b.reshape(-1)]).cpu().numpy()
+            cf, cb = both[:n], both[n:][idx2]
+        else:
+            cf, cb = cnt_f.cpu().numpy(), None
+        ratio_f = cf.astype(np.float32) / np.float32(H * W)
+        idx1 = np.nonzero(cond1)[0]
+        if idx1.size:
+            jj = idx1[ratio_f[idx1] > np.float32(0.3)]
+            if jj.size:
+                ii = np.full_like(jj, current_idx)
+                self.add_factors(ii, jj)
+                self.add_factors(jj, ii)
+        if idx2.size:
+            ratio_b = cb.astype(np.float32) / np.float32(hb * wb)
+            mask = (ratio_f[idx2] > np.float32(0.3)) | (ratio_b > np.float32(0.3))
+            jj = idx2[mask]
+            if jj.size:
+                ii = np.full_like(jj, current_idx)
+                self.add_factors(ii, jj)
+                self.add_factors(jj, ii)
+        self._age = [a + 1 for a in self._age]
+        self._cache = None
+
+    # ------------------------------------------------------------------ loop detection (factor_graph.py:503-543)
+    def detect_loop(self, current_idx, current_featI=None, all_featI=None, temporal_window=8, feat_th=0.7,
+                    small_loop_candidates=False):
+        covisible = set(j for i, j in zip(self._ii, self._jj) if i == current_idx)
+        cand = [i for i in covisible if abs(i - current_idx) > temporal_window]
+        if cand:
+            return min(cand) if small_loop_candidates else np.array(cand)
+        return None

@@ -279,24 +279,35 @@ def patch_overlap_count(feat0, feat1, thr, ws, count):
     check(lib.cut3r_patch_overlap(_p(feat0), _p(feat1), N, Cc, float(thr), _p(ws), _p(count), _stream()), "cut3r_patch_overlap")
 
 
-def overlap_fwd(pm, w2c, K4, W, H, counts):
+def overlap_fwd(pm, w2c, K4, W, H, counts, P12=None, s_align=1.0):
+    """counts[b] = #points of pm (optionally mapped p <- P*(s*p) first) that land inside camera b's W x H image."""
     _cuda(pm, w2c, counts)
     N = pm.numel() // 3
     B = w2c.shape[0]
     _req(pm.dtype == F32 and pm.is_contiguous() and w2c.dtype == F32 and w2c.shape == (B, 12) and w2c.is_contiguous(), "overlap_fwd inputs")
     _req(counts.dtype == torch.int32 and counts.numel() >= B, "counts int32[B]")
+    arr = (C.c_float * 12)(*[float(v) for v in P12]) if P12 is not None else None
     lib = _lib.load()
-    check(lib.cut3r_overlap_fwd(_p(pm), N, _p(w2c), B, *[float(v) for v in K4], int(W), int(H), _p(counts), _stream()), "cut3r_overlap_fwd")
+    check(lib.cut3r_overlap_fwd(_p(pm), N, arr, float(s_align), _p(w2c), B, *[float(v) for v in K4], int(W), int(H),
+                                _p(counts), _stream()), "cut3r_overlap_fwd")
 
 
-def overlap_bwd(pms, w2c, K4, W, H, counts):
+def overlap_bwd(pms, w2c, K4, W, H, counts, B=None, N=None, grp=0, grp_stride=0):
+    """counts[b] = #points of pointmap b inside the ONE camera w2c.  pms: contiguous [B,N,3]-like store; with grp > 0
+    pointmap b sits at slot (b//grp)*grp_stride + b%grp of a [slots, N, 3] store (keyframe order of submap_ds)."""
     _cuda(pms, w2c, counts)
-    B = pms.shape[0]
-    N = pms[0].numel() // 3
+    if B is None:
+        B = pms.shape[0]
+    if N is None:
+        N = pms[0].numel() // 3
     _req(pms.dtype == F32 and pms.is_contiguous() and w2c.dtype == F32 and w2c.numel() == 12 and w2c.is_contiguous(), "overlap_bwd inputs")
+    nslots = pms.numel() // (3 * N)
+    last = (B - 1) if grp == 0 else ((B - 1) // grp) * grp_stride + (B - 1) % grp
+    _req(B >= 1 and last < nslots, "overlap_bwd: pointmap store too small for B")
     _req(counts.dtype == torch.int32 and counts.numel() >= B, "counts int32[B]")
     lib = _lib.load()
-    check(lib.cut3r_overlap_bwd(_p(pms), B, N, _p(w2c), *[float(v) for v in K4], int(W), int(H), _p(counts), _stream()), "cut3r_overlap_bwd")
+    check(lib.cut3r_overlap_bwd(_p(pms), B, N, int(grp), int(grp_stride), _p(w2c), *[float(v) for v in K4], int(W), int(H),
+                                _p(counts), _stream()), "cut3r_overlap_bwd")
 
 
 def align_view(pts, conf, P12, s, ds, pm_ds, conf_ds, depth):

@@ -1,0 +1,133 @@
+"""Window tracker: same control flow, state updates and graph calls as the reference `TrackFrontend`
+(/root/reference/hislam2/track_frontend.py:17-330), re-hosted on HBM-resident buffers and HIP kernels.
+
+Per window the reference copies every predicted map to the CPU, does the chaining with CPU tensor ops and
+re-uploads all previous pointmaps for every keyframe.  Here the only device->host traffic per window is the V x 7
+camera poses + one fp64 scalar (the log-depth sum); pointmaps, confidences and depths never leave HBM.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import geom_host as gh
+from . import ops
+from .factor_graph import AlignedPoints, SubmapStore
+
+
+def make_views(model, images_u8):
+    """View dicts exactly as the reference builds them (track_frontend.py:47-75), for the `inference()` entry point."""
+    images = model.normalize(images_u8.float())
+    views = []
+    for i in range(len(images)):
+        views.append({
+            "img": images[i][None],
+            "ray_map": torch.full((1, 6, images[i].shape[-2], images[i].shape[-1]), torch.nan),
+            "true_shape": torch.from_numpy(np.int32([images[i].shape[-2], images[i].shape[-1]])),
+            "idx": i, "instance": str(i),
+            "camera_pose": torch.from_numpy(np.eye(4, dtype=np.float32)).unsqueeze(0),
+            "img_mask": torch.tensor(True).unsqueeze(0), "ray_mask": torch.tensor(False).unsqueeze(0),
+            "update": torch.tensor(True).unsqueeze(0), "reset": torch.tensor(False).unsqueeze(0)})
+    return views
+
+
+class TrackFrontend:
+    def __init__(self, slam, keyframes, config, device="cuda:0"):
+        self.device = device
+        self.keyframes = keyframes
+        self.model = slam.model
+        self.graph = slam.graph
+        self.t1 = 0
+        self.warmup = 6
+        self.frontend_nms = config.get("frontend_nms", 1)
+        self.keyframe_thresh = config.get("keyframe_thresh", 4.0)
+        self.frontend_window = config.get("frontend_window", 25)
+        self.frontend_thresh = config.get("frontend_thresh", 16.0)
+        self.frontend_radius = config.get("frontend_radius", 2)
+        self.keyframes.mono_depth_alpha = config.get("mono_depth_alpha", 0.01)
+        self.downsample_ratio = slam.downsample_ratio
+        self._lsum = torch.zeros(1, dtype=torch.float64, device=device)
+
+    def prepare_input(self, images):
+        return make_views(self.model, images)
+
+    # ------------------------------------------------------------------ one window
+    def infer(self, imgs_u8):
+        """model outputs consumed by SLAM (track_frontend.py:81-100 keeps only these three)."""
+        preds, _ = self.model.forward_window(imgs_u8)
+        pts = torch.cat([p["pts3d_in_self_view"] for p in preds], 0)       # [V,H,W,3]
+        conf = torch.cat([p["conf_self"] for p in preds], 0)               # [V,H,W]
+        pose_enc = torch.cat([p["camera_pose"] for p in preds], 0)         # [V,7] (t, q wxyz)
+        return pts.contiguous(), conf.contiguous(), pose_enc
+
+    def track(self, t0, t1, init=False, outputs=None):
+        """track_frontend.py:166-262.  `outputs` = (pts, conf, pose_enc) lets callers (tests, the multi-GPU
+        driver) supply precomputed network outputs."""
+        kf, graph, ds = self.keyframes, self.graph, self.downsample_ratio
+        if init:
+            graph.add_neighborhood_factors(0, 3, r=3)
+        pts, conf, pose_enc = outputs if outputs is not None else self.infer(kf.image[t0:t1])
+        V, H, W, _ = pts.shape
+        lsum = None
+        if not init:
+            ops.logdepth_sum(kf.depth[t0], pts[0], self._lsum)           # window k's view 0 == previous window's last KF
+        host = pose_enc.detach().cpu().numpy()                             # the one sync point of the window
+        if not init:
+            lsum = float(self._lsum.item())
+        poses = gh.pose_encoding_to_camera(host)
+        first_w2c = gh.inv4(poses[0])
+        sub_num = t0 // 5
+        align = None
+        if not init:
+            align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
+            prev_c2w = gh.pose_vec_to_matrix(kf.pose[t0].numpy()[None])[0]
+            align = (prev_c2w[:3, :3], prev_c2w[:3, 3], align_s)
+        for i in range(t0, t1):
+            if not init:
+                graph.add_neighborhood_factors(i - 3, i + 1, r=3)
+            v = i - t0
+            if init:
+                pose = gh.chain_pose(first_w2c, poses[v])
+                s = np.float32(1.0)
+            else:
+                pose = gh.chain_pose(first_w2c, poses[v], *align)
+                s = align[2]
+            ops.align_view(pts[v], conf[v], pose[:3, :4].reshape(-1), float(s), ds,
+                           kf.submap_ds[sub_num, v], kf.conf_ds[sub_num, v], kf.depth[i])
+            kf.set_pose(i, gh.matrix_to_pose_vec(pose))
+            if i > 2:
+                # current pointmap at full resolution as the reference passes it (track_frontend.py:259), fused into
+                # the projection kernel; previous pointmaps are read in place from the resident submap store
+                cur_pm = AlignedPoints(pts[v], pose[:3, :4], float(s))
+                all_c2w = gh.pose_vec_to_matrix(kf.pose[:i].numpy())
+                cur_c2w = gh.pose_vec_to_matrix(kf.pose[i].numpy()[None])[0]
+                intr = kf.intrinsic[i].numpy()
+                K = np.array([[intr[0], 0, intr[2]], [0, intr[1], intr[3]], [0, 0, 1]])
+                graph.add(i, all_c2w, SubmapStore(kf.submap_ds, i), cur_c2w, cur_pm, K,
+                          all_w2c_rows=kf.w2c[:i], current_w2c_row=kf.w2c[i])
+
+    # ------------------------------------------------------------------ scheduling (track_frontend.py:285-330)
+    def run(self, tstamp, last_frame=False):
+        kf = self.keyframes
+        if not kf.is_initialized and kf.counter.value - 1 == self.warmup:
+            t1 = kf.counter.value - 1
+            self.track(0, t1, init=True)
+            kf.is_initialized = True
+            self.t1 = t1
+            return False, range(0, t1), 0
+        elif kf.is_initialized and self.t1 < kf.counter.value - 5:
+            t0 = self.t1 - 1
+            t1 = kf.counter.value - 1
+            self.track(t0, t1)
+            self.t1 = t1
+            return (t1 > 10), range(t0, t1), t0 // 5
+        elif last_frame and kf.is_initialized:
+            t0 = self.t1 - 1
+            t1 = kf.counter.value - 1
+            if t1 > t0:
+                self.track(t0, t1)
+                self.t1 = t1
+            return False, range(t0, t1), t0 // 5
+        return False, None, None

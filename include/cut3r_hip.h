@@ -105,12 +105,16 @@ int cut3r_patch_overlap(const float* feat0, const float* feat1, int N, int C, fl
 /* ---- covisibility graph geometry ------------------------------------------------------------------------------------
  * replaces FactorGraph.cal_overlap_batch / cal_overlap_bi (hislam2/factor_graph.py:255-315).
  * w2c: fp32 [B,12] = top 3x4 of inverse(c2w) row-major; K4 = (fx,fy,cx,cy) HOST floats; counts int32[B] (device).
- * fwd: ONE pointmap pm [N,3] projected into B cameras (z clamped at 1e-5 for the divide, :272).
- * bwd: B pointmaps pms [B,N,3] projected into ONE camera (raw z divide, :304). */
-int cut3r_overlap_fwd(const float* pm, int N, const float* w2c, int B, float fx, float fy, float cx, float cy, int W, int H,
-                      int32_t* counts, void* stream);
-int cut3r_overlap_bwd(const float* pms, int B, int N, const float* w2c, float fx, float fy, float cx, float cy, int W, int H,
-                      int32_t* counts, void* stream);
+ * fwd: ONE pointmap pm [N,3] projected into B cameras (z clamped at 1e-5 for the divide, :272).  If P_host != NULL the
+ *      points are first mapped p <- P*(s_align*p) (12 HOST floats, 3x4 row-major): the tracker's chained full-resolution
+ *      pointmap (track_frontend.py:234,259) is then never materialised.
+ * bwd: B pointmaps projected into ONE camera (raw z divide, :304).  Pointmap b starts at
+ *      pms + slot(b)*N*3 with slot(b) = b when grp == 0, else (b/grp)*grp_stride + b%grp -- the keyframe order of the
+ *      [submap][6 slots] store (hislam2/keyframe.py:28, track_frontend.py:251-255) without gathering a copy. */
+int cut3r_overlap_fwd(const float* pm, int N, const float* P_host, float s_align, const float* w2c, int B, float fx, float fy,
+                      float cx, float cy, int W, int H, int32_t* counts, void* stream);
+int cut3r_overlap_bwd(const float* pms, int B, int N, int grp, int grp_stride, const float* w2c, float fx, float fy, float cx,
+                      float cy, int W, int H, int32_t* counts, void* stream);
 
 /* ---- window alignment -----------------------------------------------------------------------------------------------
  * replaces the per-view tensor math of TrackFrontend.track (hislam2/track_frontend.py:193-243): pointmap = P*(s*pts),

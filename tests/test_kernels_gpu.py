@@ -1,0 +1,350 @@
+"""GPU parity of every HIP kernel (called through the C ABI) against the oracle / a torch fp32 statement of the op.
+
+Tolerances: operands are rounded to fp16 before the MFMA and accumulated in fp32, so against an fp32 evaluation on
+the SAME fp16-rounded operands the error is accumulation-order only (<= 2e-3 relative to the output scale for the
+fp16-stored outputs, which carry 2^-11 rounding).  Integer/byte results are exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cut3r_slam_amd import ops  # noqa: E402
+from oracle import cut3r_oracle as O  # noqa: E402
+from oracle import geom as G  # noqa: E402
+
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _report(name, got, ref, tol):
+    err = _rel(got, ref)
+    if not err <= tol:
+        d = (got.double().cpu() - ref.double().cpu()).abs()
+        idx = np.unravel_index(int(d.argmax()), d.shape)
+        nbad = int((d > tol * ref.double().abs().max()).sum())
+        raise AssertionError(f"{name}: rel err {err:.3e} > {tol:.1e}; worst at {idx}: got {got.cpu()[idx].item():.6f} "
+                             f"ref {ref.cpu()[idx].item():.6f}; {nbad}/{d.numel()} elements out of tolerance; "
+                             f"nan={bool(torch.isnan(got).any())}")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K,tile", [
+    (768, 1024, 1024, 0), (769, 768, 768, 0), (4608, 3072, 1024, 128), (4608, 1024, 4096, 0), (1, 1536, 1536, 0),
+    (6, 64, 48, 0), (13, 144, 48, 64), (256, 4608, 1536, 0), (130, 8, 192, 0), (200, 132, 72, 128)])
+def test_gemm_bias_gelu_residual(M, N, K, tile):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g).half()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = A.float() @ W.float().t() + bias
+    for act, use_res, out_dt in ((0, False, torch.float32), (1, False, torch.float16), (0, True, torch.float32), (2, True, torch.float16)):
+        r = ref
+        if act == 1:
+            r = F.gelu(r)
+        if act == 2:
+            r = F.relu(r)
+        if use_res:
+            r = r + res
+        out = torch.full((M, N), float("nan"), dtype=out_dt, device=DEV)
+        ops.linear(A.to(DEV), W.to(DEV), out, bias.to(DEV), act, res.to(DEV) if use_res else None, tile=tile)
+        torch.cuda.synchronize()
+        _report(f"gemm M{M} N{N} K{K} act{act} res{use_res} {out_dt}", out.float(), r, 2e-3 if out_dt == torch.float16 else 2e-5)
+
+
+def test_gemm_strided_output_and_inplace_residual():
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 70, 96, 64
+    A = torch.randn(M, K, generator=g).half().to(DEV)
+    W = torch.randn(N, K, generator=g).half().to(DEV)
+    big = torch.zeros(M + 1, 2 * N, device=DEV)
+    x = torch.randn(M, N, generator=g).to(DEV)
+    big[1:, :N] = x
+    ops.linear(A, W, big[1:, :N], None, 0, res1=big[1:, :N])            # in place: out == res1, row stride 2N, row offset 1
+    torch.cuda.synchronize()
+    _report("gemm strided/in-place", big[1:, :N], x + A.float() @ W.float().t(), 2e-5)
+    assert float(big[0].abs().max()) == 0 and float(big[:, N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,relu_in", [
+    (1, 12, 16, 256, 256, 1, True), (2, 5, 7, 96, 256, 1, False), (1, 24, 32, 768, 768, 2, False), (3, 2, 3, 256, 128, 1, False),
+    (1, 1, 2, 256, 256, 1, True), (2, 9, 9, 128, 128, 2, False)])
+def test_conv3x3_implicit_gemm(B, H, W, Cin, Cout, stride, relu_in):
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.randn(B, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).half()
+    b = torch.randn(Cout, generator=g)
+    xin = F.relu(x.float()) if relu_in else x.float()
+    ref = F.conv2d(xin, w.float(), b, stride=stride, padding=1)
+    r1 = torch.randn_like(ref).half()
+    ref = (ref + r1.float()).permute(0, 2, 3, 1)
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    out = torch.full(ref.shape, float("nan"), dtype=torch.float16, device=DEV)
+    ops.conv3x3_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wk.to(DEV), out, b.to(DEV), stride, relu_in, 0,
+                     res1=r1.permute(0, 2, 3, 1).contiguous().to(DEV))
+    torch.cuda.synchronize()
+    _report(f"conv3x3 {B}x{H}x{W} {Cin}->{Cout} s{stride}", out.float(), ref, 2e-3)
+
+
+@pytest.mark.parametrize("s,Cin,Cout,H,W", [(4, 96, 96, 2, 3), (2, 192, 192, 6, 8), (4, 96, 96, 24, 32)])
+def test_conv_transpose_pixel_shuffle(s, Cin, Cout, H, W):
+    g = torch.Generator().manual_seed(s)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cin, Cout, s, s, generator=g) / Cin ** 0.5).half()
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose2d(x.float(), w.float(), b, stride=s).permute(0, 2, 3, 1)
+    wt = w.permute(2, 3, 1, 0).reshape(s * s * Cout, Cin).contiguous()
+    out = torch.full(ref.shape, float("nan"), dtype=torch.float16, device=DEV)
+    ops.conv_transpose_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wt.to(DEV), out, b.to(DEV), s)
+    torch.cuda.synchronize()
+    _report(f"convT s{s}", out.float(), ref, 2e-3)
+
+
+def test_gemv_silu():
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(6, 768, generator=g)
+    W = (torch.randn(1536, 768, generator=g) / 768 ** 0.5).half()
+    b = torch.randn(1536, generator=g)
+    out = torch.empty(6, 1536, device=DEV)
+    ops.gemv(X.to(DEV), W.to(DEV), out, b.to(DEV), silu_in=True)
+    torch.cuda.synchronize()
+    ref = F.silu(X).half().float() @ W.float().t() + b
+    _report("gemv", out, ref, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [
+    (1, 16, 768, 768, 64), (2, 16, 768, 768, 64), (1, 12, 769, 769, 64), (1, 16, 768, 769, 48), (1, 12, 769, 768, 64),
+    (1, 12, 256, 256, 128), (1, 12, 256, 1, 128), (1, 12, 1, 256, 128), (1, 12, 1, 1, 128), (3, 4, 6, 6, 16),
+    (1, 3, 7, 12, 16), (1, 3, 8, 1, 32), (6, 16, 768, 768, 64), (1, 2, 100, 333, 32)])
+def test_attention_vs_sdpa(B, H, Nq, Nk, D):
+    g = torch.Generator().manual_seed(Nq * 3 + Nk + D)
+    q = (torch.randn(B, Nq, H, D, generator=g) * 1.5).half()
+    k = (torch.randn(B, Nk, H, D, generator=g) * 1.5).half()
+    v = torch.randn(B, Nk, H, D, generator=g).half()
+    k[0, 0, 0] *= 6.0                                # a spiked key: exercises the running-max rescale
+    if Nk > 70:
+        k[0, 69, -1] *= 8.0                          # ... in a later KV tile as well
+    scale = D ** -0.5
+    ref = F.scaled_dot_product_attention(q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3),
+                                         v.float().permute(0, 2, 1, 3), scale=scale).permute(0, 2, 1, 3)
+    # fused-buffer strides, like the model: q/k/v are slices of one [B,N,3,H,D] buffer when Nq == Nk
+    out = torch.full((B, Nq, H, D), float("nan"), dtype=torch.float16, device=DEV)
+    if Nq == Nk:
+        qkv = torch.stack([q, k, v], dim=2).contiguous().to(DEV)
+        ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out, scale)
+    else:
+        ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), out, scale)
+    torch.cuda.synchronize()
+    _report(f"attention B{B} H{H} Nq{Nq} Nk{Nk} D{D}", out.float(), ref, 3e-3)
+
+
+# ------------------------------------------------------------------------------------------------ RoPE / LN / helpers
+def test_rope_matches_reference_golden_and_oracle():
+    f = np.load(os.path.join(GOLD, "rope2d.npz"))
+    for D in (16, 48, 64):
+        tok, pos = torch.from_numpy(f[f"D{D}_tok"]), torch.from_numpy(f[f"D{D}_pos"])
+        for F0 in (1, -1):
+            t = tok.clone().to(DEV)
+            ops.rope_2d(t, pos.to(DEV), 100.0, float(F0))
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(t.cpu().numpy(), f[f"D{D}_F{F0}_out"], rtol=0, atol=1e-5)   # reference CPU op
+            np.testing.assert_allclose(t.cpu().numpy(), G.rope2d(tok.numpy(), pos.numpy(), 100.0, float(F0)), rtol=0, atol=2e-6)
+
+
+def test_rope_strided_half_view_like_the_model():
+    g = torch.Generator().manual_seed(0)
+    B, N, H, D = 2, 769, 12, 64
+    qkv = torch.randn(B, N, 3, H, D, generator=g).half()
+    pos = torch.randint(-1, 32, (B, N, 2), generator=g)
+    dev = qkv.to(DEV)
+    ops.rope_2d(dev[:, :, 0], pos.to(DEV), 100.0, 1.0)
+    ops.rope_2d(dev[:, :, 1], pos.to(DEV), 100.0, 1.0)
+    torch.cuda.synchronize()
+    for j in range(2):
+        ref = O.rope2d(qkv[:, :, j].permute(0, 2, 1, 3), pos).permute(0, 2, 1, 3)
+        _report(f"rope half slice {j}", dev[:, :, j].float().cpu(), ref.float(), 1.5e-3)
+    assert torch.equal(dev[:, :, 2].cpu(), qkv[:, :, 2])                  # v untouched
+    with pytest.raises(RuntimeError):
+        ops.rope_2d(dev[:, :, 0].transpose(1, 2), pos.to(DEV), 100.0, 1.0)    # reference's stride check
+
+
+@pytest.mark.parametrize("M,C", [(768, 1024), (769, 768), (5, 48), (256, 1536), (1, 1536)])
+def test_layernorm_and_adaln(M, C):
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(M, C, generator=g) * 3 + 0.5
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    sc, sh = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), w, b, 1e-6)
+    o16 = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    o32 = torch.empty(M, C, device=DEV)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, o16, o32)
+    torch.cuda.synchronize()
+    _report("ln fp32", o32, ref, 5e-6)
+    _report("ln fp16", o16.float(), ref, 1e-3)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, None, o32, sc.to(DEV), sh.to(DEV))
+    torch.cuda.synchronize()
+    _report("adaLN", o32, ref * (1 + sc) + sh, 5e-6)
+
+
+def test_im2col_cast_colmean_upsample():
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(2, 3, 32, 48, generator=g)
+    out = torch.empty(2 * 2 * 3, 768, dtype=torch.float16, device=DEV)
+    ops.im2col_patch(img.to(DEV), 16, out)
+    ref = F.unfold(img, 16, stride=16).transpose(1, 2).reshape(-1, 768)
+    torch.cuda.synchronize()
+    _report("im2col", out.float(), ref.half().float(), 0)
+    u8 = torch.randint(0, 256, (1, 3, 16, 32), generator=g, dtype=torch.uint8)
+    out2 = torch.empty(2, 768, dtype=torch.float16, device=DEV)
+    ops.im2col_patch(u8.to(DEV), 16, out2)
+    ref2 = F.unfold((u8.float() / 255.0 - 0.5) / 0.5, 16, stride=16).transpose(1, 2).reshape(-1, 768)
+    torch.cuda.synchronize()
+    _report("im2col u8", out2.float(), ref2.half().float(), 1e-3)
+    x = torch.randn(769, 768, generator=g)
+    y = torch.empty(768, 768, dtype=torch.float16, device=DEV)
+    ops.cast_f16(x.to(DEV)[1:], y)
+    m = torch.empty(768, device=DEV)
+    ops.colmean(x.to(DEV), m)
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), x[1:].half())
+    _report("colmean", m, x.mean(0), 1e-5)
+    t = torch.randn(2, 16, 5, 7, generator=g).half()
+    up = torch.empty(2, 10, 14, 16, dtype=torch.float16, device=DEV)
+    ops.upsample2x(t.permute(0, 2, 3, 1).contiguous().to(DEV), up)
+    torch.cuda.synchronize()
+    refu = F.interpolate(t.float(), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    _report("upsample2x", up.float(), refu, 1.5e-3)
+
+
+def test_output_activations():
+    g = torch.Generator().manual_seed(9)
+    P, Cin = 1000, 128
+    x = torch.randn(P, Cin, generator=g).half()
+    w = torch.randn(4, Cin, generator=g) * 0.05
+    b = torch.randn(4, generator=g) * 0.1
+    raw = x.float() @ w.t() + b
+    pts, conf = torch.empty(P, 3, device=DEV), torch.empty(P, device=DEV)
+    ops.dpt_final(x.to(DEV), w.to(DEV), b.to(DEV), 0, pts, conf)
+    torch.cuda.synchronize()
+    _report("dpt_final pts", pts, O.reg_dense_depth_exp(raw[:, :3]), 1e-5)
+    _report("dpt_final conf", conf, 1 + raw[:, 3].exp(), 1e-5)
+    rgb = torch.empty(P, 3, device=DEV)
+    ops.dpt_final(x.to(DEV), w[:3].contiguous().to(DEV), b[:3].contiguous().to(DEV), 1, rgb, None)
+    torch.cuda.synchronize()
+    _report("dpt_final rgb", rgb, (torch.sigmoid(raw[:, :3]) * (1 - 2e-6) + 1e-6 - 0.5) * 2, 1e-5)
+    ops.postprocess_pts(raw.contiguous().to(DEV), True, pts, conf)
+    torch.cuda.synchronize()
+    _report("postprocess pos_z", pts, O.reg_dense_depth_exp(raw[:, :3].clone(), pos_z=True), 1e-5)
+    pr = torch.randn(5, 7, generator=g)
+    po = torch.empty(5, 7, device=DEV)
+    ops.postprocess_pose(pr.to(DEV), po)
+    torch.cuda.synchronize()
+    _report("postprocess_pose", po, O.postprocess_pose(pr), 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ geometry (bit-exact)
+def _scene(n, H, W, seed):
+    g = np.random.default_rng(seed)
+    from scipy.spatial.transform import Rotation
+    c2w = np.tile(np.eye(4), (n, 1, 1))
+    for i in range(n):
+        c2w[i, :3, :3] = Rotation.from_euler("yxz", g.normal(0, 0.2, 3)).as_matrix()
+        c2w[i, :3, 3] = g.normal(0, 0.7, 3)
+    fx = fy = 0.9 * W
+    K4 = [fx, fy, W / 2 - 0.5, H / 2 - 0.5]
+    depth = g.uniform(2.0, 3.0, size=(n, H, W))
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    cam = np.stack([(xs - K4[2]) / fx * depth, (ys - K4[3]) / fy * depth, depth, np.ones_like(depth)], -1)
+    pm = np.einsum("nij,nhwj->nhwi", c2w, cam)[..., :3].astype(np.float32)
+    pm[0, 0, 0] = [0, 0, -5]          # behind-camera / z <= 0 cases
+    return c2w, pm, K4
+
+
+@pytest.mark.parametrize("n,H,W", [(9, 24, 32), (50, 192, 256), (3, 5, 7)])
+def test_overlap_counts_bit_exact(n, H, W):
+    c2w, pm, K4 = _scene(n, H, W, n)
+    w2c = G.w2c_rows(c2w)
+    i = n - 1
+    cnt = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    ops.overlap_fwd(torch.from_numpy(pm[i]).to(DEV), torch.from_numpy(w2c[:i]).to(DEV), K4, W, H, cnt)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(cnt[:i].cpu().numpy(), G.overlap_fwd(pm[i], w2c[:i], K4, W, H))
+    if (H * W) % 4 == 0:
+        cnt2 = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+        ops.overlap_bwd(torch.from_numpy(pm[:i]).to(DEV), torch.from_numpy(w2c[i]).to(DEV), K4, W, H, cnt2)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(cnt2[:i].cpu().numpy(), G.overlap_bwd(pm[:i], w2c[i], K4, W, H))
+
+
+def test_overlap_matches_reference_golden_decisions():
+    f = np.load(os.path.join(GOLD, "graph.npz"))
+    pm, c2w, K = f["pointmaps"], f["c2w"], f["K"]
+    n, H, W, _ = pm.shape
+    K4 = [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]
+    i = n - 1
+    w2c = G.w2c_rows(c2w)
+    cnt = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ops.overlap_fwd(torch.from_numpy(pm[i]).to(DEV), torch.from_numpy(w2c[:i]).to(DEV), K4, W, H, cnt)
+    cb = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ops.overlap_bwd(torch.from_numpy(pm[:i]).to(DEV), torch.from_numpy(w2c[i]).to(DEV), K4, W, H, cb)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(cnt[:i].cpu().numpy() / (H * W) > 0.3, f["ovl_batch_last"] > 0.3)
+    np.testing.assert_array_equal(cb[:i].cpu().numpy() / (H * W) > 0.3, f["ovl_bi_last"].reshape(-1) > 0.3)
+
+
+def test_align_view_bit_exact_and_logdepth():
+    g = np.random.default_rng(2)
+    H, W = 48, 64
+    pts = g.normal(0, 1, (H, W, 3)).astype(np.float32)
+    pts[..., 2] = np.abs(pts[..., 2]) + 0.5
+    conf = (1 + np.exp(g.normal(0, 1, (H, W)))).astype(np.float32)
+    P = g.normal(0, 1, 12).astype(np.float32)
+    s = 1.37
+    pm_ds = torch.empty(H // 2, W // 2, 3, device=DEV)
+    cf_ds = torch.empty(H // 2, W // 2, device=DEV)
+    dp = torch.empty(H, W, device=DEV)
+    ops.align_view(torch.from_numpy(pts).to(DEV), torch.from_numpy(conf).to(DEV), P, s, 2, pm_ds, cf_ds, dp)
+    torch.cuda.synchronize()
+    rpm, rcf, rdp = G.align_view(pts, conf, P, s, 2)
+    np.testing.assert_array_equal(pm_ds.cpu().numpy(), rpm)
+    np.testing.assert_array_equal(cf_ds.cpu().numpy(), rcf)
+    np.testing.assert_array_equal(dp.cpu().numpy(), rdp)
+    prev = (np.abs(g.normal(2, 0.3, (H, W))) + 0.1).astype(np.float32)
+    out = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ops.logdepth_sum(torch.from_numpy(prev).to(DEV), torch.from_numpy(pts).to(DEV), out)
+    torch.cuda.synchronize()
+    ref = G.logdepth_sum(prev, pts)
+    assert abs(out.item() - ref) <= 2e-6 * H * W          # device logf vs libm logf: <= 2 ulp per term
+
+
+def test_patch_overlap_count_matches_oracle_and_reference():
+    f = np.load(os.path.join(GOLD, "graph.npz"))
+    f0 = torch.from_numpy(f["feat0"]).to(DEV)
+    N, C = f0.shape
+    ws = torch.empty(2 * (N - 1) * C + N, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for k, ref in enumerate(f["patch_ratios"]):
+        ops.patch_overlap_count(f0, torch.from_numpy(f[f"feat1_{k}"]).to(DEV), 0.7, ws, cnt)
+        torch.cuda.synchronize()
+        assert abs(cnt.item() / (N - 1) - ref) < 1e-6, (k, cnt.item(), ref)
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(768, 1024, generator=g)
+    b = a[torch.randperm(768, generator=g)] + 0.9 * torch.randn(768, 1024, generator=g)
+    ws = torch.empty(2 * 767 * 1024 + 768, device=DEV)
+    ops.patch_overlap_count(a.to(DEV), b.to(DEV), 0.7, ws, cnt)
+    torch.cuda.synchronize()
+    ratio, mx = G.patch_overlap_ratio(a.numpy(), b.numpy())
+    border = int((np.abs(mx - 0.7) < 1e-5).sum())
+    assert abs(cnt.item() - round(ratio * 767)) <= border
