@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Throughput of the CUT3R-SLAM tracking hot path on MI355X (BASELINE.json metric: frames/s on 640x480 input).
+
+Workload (BASELINE configs[1], "Replica room0 640x480: ViT pointmap + factor-graph step, tracking only, GS off"):
+synthetic 640x480 stream -> tracking resolution 384x512 (demo_s.py:69-73), production-shape network (ViT-L encoder,
+768-d dual decoder, DPT head; seeded random weights -- no checkpoint exists), fixed keyframe cadence kf_every=10
+(hislam2/motion_filter.py:83,109,124).  One STEP = one steady-state tracking window = 50 input frames:
+5 keyframe-filter encoder passes + one 6-view window inference + chaining/alignment + covisibility-graph update
+of the 5 new keyframes (hislam2/hi2.py:101-133 without the GS mapper).  Frames are resident in HBM before the
+timed region.  value = frames processed by all ranks / max-over-ranks time.
+
+N > 1 (one process per GPU, torch.distributed/RCCL): windows are sharded across ranks (every window re-initialises
+the recurrent state, src/dust3r/model.py:819-822, so windows are independent network evaluations); each step every
+rank infers ONE window, the three consumed outputs are all-gathered over xGMI and the cheap sequential chaining +
+graph update of all N windows runs replicated.  Per-GPU work is fixed => "scaling": "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def synth_frames(n, H, W, device, seed=0):
+    """seeded low-pass noise panned smoothly: u8 [n,3,H,W] on the GPU (data: synthetic)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    base = torch.rand(3, H // 8 + 64, W // 8 + 64, generator=g)
+    base = torch.nn.functional.interpolate(base[None], scale_factor=8, mode="bilinear", align_corners=False)[0]
+    base = (base * 255).to(device)
+    frames = torch.empty(n, 3, H, W, dtype=torch.uint8, device=device)
+    for t in range(n):
+        dx, dy = int(2 * t) % 400, int(1 * t) % 300
+        frames[t] = base[:, dy:dy + H, dx:dx + W].round().clamp(0, 255).to(torch.uint8)
+    return frames
+
+
+class GemmProbe:
+    """HIP-event timing of every launch of the dominant kernel (tile-128 GEMM) on the launch stream."""
+
+    def __init__(self):
+        self.ev, self.flops = [], 0.0
+
+    def install(self):
+        from cut3r_slam_amd import ops, _lib
+        import ctypes as C
+        lib = _lib.load()
+        raw = lib.cut3r_gemm_f16
+        probe = self
+
+        def wrapped(dref, stream):
+            d = dref._obj
+            big = ((d.M + 127) // 128) * ((d.N + 127) // 128) * max(d.batch, 1)
+            if (d.tile == 128) or (d.tile == 0 and big >= 192):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = raw(dref, stream)
+                e.record()
+                probe.ev.append((s, e))
+                probe.flops += 2.0 * d.M * d.N * d.K * max(d.batch, 1)
+                return rc
+            return raw(dref, stream)
+
+        self._lib, self._raw = lib, raw
+        lib.cut3r_gemm_f16 = wrapped
+
+    def remove(self):
+        self._lib.cut3r_gemm_f16 = self._raw
+
+    def result(self):
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e in self.ev)
+        n = len(self.ev)
+        return n, ms, self.flops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--small", action="store_true", help="debug: tiny network (NOT a valid benchmark line)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from cut3r_slam_amd.config import production_config, tiny_config
+    from cut3r_slam_amd.model import Cut3rModel
+    from cut3r_slam_amd.slam import Cut3rSlam
+    from cut3r_slam_amd.weights import synth_state_dict
+    from cut3r_slam_amd import dist as cdist
+
+    H, W, KF_EVERY, WIN = 384, 512, 10, 5
+    cfg = tiny_config("dpt") if args.small else production_config()
+    t0 = time.time()
+    sd = synth_state_dict(cfg, seed=0)
+    model = Cut3rModel(cfg, sd, dev, minimal=True)
+    t_build = time.time() - t0
+
+    frames_per_step = KF_EVERY * WIN
+    total_steps = args.warmup + args.steps
+    # rank r tracks its own windows: window w of step s is global window s*world + r
+    n_kf = 6 + WIN * (total_steps * world) + 1
+    n_frames = n_kf * KF_EVERY
+    config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": KF_EVERY},
+                           "frontend": {"iteration": 0}}}
+    slam = Cut3rSlam(model, config, (H, W), buffer=n_kf + 8, device=dev)
+    intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])  # calib/replica.txt scaled
+    runner = cdist.ShardedTracker(slam, world, rank) if dist_on else None
+    frames = synth_frames(n_frames if not dist_on else runner.frames_needed(total_steps, KF_EVERY, WIN), H, W, dev, seed=0)
+
+    # prologue (untimed): the 6-keyframe initialisation window
+    t = 0
+    while not slam.keyframes.is_initialized:
+        slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+        t += 1
+
+    def one_step(t):
+        if dist_on:
+            return runner.step(frames, t, KF_EVERY, WIN, intr)
+        for _ in range(frames_per_step):
+            slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+            t += 1
+        return t
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        t = one_step(t)
+    barrier()
+    tic = time.perf_counter()
+    for _ in range(args.steps):
+        t = one_step(t)
+    barrier()
+    elapsed = time.perf_counter() - tic
+    if dist_on:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    frames_total = frames_per_step * args.steps * world
+    value = frames_total / elapsed
+
+    roofline, cpu_base = None, None
+    if rank == 0 and not args.no_roofline and not dist_on:
+        # second, instrumented pass over the same number of steps: HIP events around every launch of the dominant
+        # kernel (tile-128 MFMA GEMM: encoder linears + DPT convolutions) on the launch stream
+        need = frames_per_step * args.steps
+        if t + need <= frames.shape[0]:
+            probe = GemmProbe()
+            probe.install()
+            for _ in range(args.steps):
+                t = one_step(t)
+            n, ms, fl = probe.result()
+            probe.remove()
+            if n:
+                ach = fl / (ms * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "kernel": "gemm_kernel<128,128> (v_mfma_f32_16x16x32_f16)", "achieved": round(ach, 2),
+                            "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
+                            "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n}
+    if rank == 0 and not args.no_cpu_baseline and not args.small:
+        cpu_base = cpu_baseline(cfg, sd, frames[:2].cpu(), frames_per_step)
+
+    if rank == 0:
+        out = {
+            "metric": "frames/sec (ViT pointmap + covisibility-graph tracking step) on 640x480", "value": round(value, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "Replica-shaped 640x480 stream -> 384x512 tracking res; kf_every=10; step = 1 window "
+                                   "(50 frames: 5 KF encodes + 6-view CUT3R inference + alignment + graph update); "
+                                   "ViT-L/24 enc, 768/12 dual decoder, DPT head, random init; GS backend off"
+                                   + (" [DEBUG --small]" if args.small else ""),
+                       "frames_per_step": frames_per_step, "window_views": 6, "parallelism": f"window-sharded x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu_base, "build_s": round(t_build, 1),
+        }
+        print(json.dumps(out))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, sd, imgs_u8, frames_per_step):
+    """Oracle (kind 'port') timed on the host cores on a BOUNDED sample: one keyframe-filter encode + one 2-view window
+    at 384x512, extrapolated to a step (5 encodes + 6 views; the model cost is linear in views)."""
+    from oracle import cut3r_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = O.normalize(imgs_u8)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.encode_image(cfg, sd, x[:1])
+        t_enc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.forward_views(cfg, sd, x[:2], minimal=True)
+        t_win2 = time.perf_counter() - t0
+    step_s = 5 * t_enc + 3.0 * t_win2
+    return {"value": round(frames_per_step / step_s, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/cut3r_oracle.py fp32: 1 encode_image ({t_enc:.2f} s) + one 2-view window ({t_win2:.2f} s) at "
+                      f"384x512, extrapolated to a 50-frame step = 5 encodes + 6 views"}
+
+
+if __name__ == "__main__":
+    main()

