@@ -79,6 +79,19 @@ class GemmProbe:
         return n, ms, self.flops
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """threads we may actually use: the affinity mask, capped at the GPU box's per-GPU CPU share"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,9 +121,13 @@ def main():
     H, W, KF_EVERY, WIN = 384, 512, 10, 5
     cfg = tiny_config("dpt") if args.small else production_config()
     t0 = time.time()
+    torch.set_num_threads(host_cores())
     sd = synth_state_dict(cfg, seed=0)
+    log(f"weights synthesised in {time.time() - t0:.1f}s")
     model = Cut3rModel(cfg, sd, dev, minimal=True)
+    torch.cuda.synchronize()
     t_build = time.time() - t0
+    log(f"model resident in HBM after {t_build:.1f}s")
 
     frames_per_step = KF_EVERY * WIN
     total_steps = args.warmup + args.steps
@@ -125,10 +142,13 @@ def main():
     frames = synth_frames(n_frames if not dist_on else runner.frames_needed(total_steps, KF_EVERY, WIN), H, W, dev, seed=0)
 
     # prologue (untimed): the 6-keyframe initialisation window
+    log(f"{frames.shape[0]} synthetic frames resident; running the initialisation window")
     t = 0
     while not slam.keyframes.is_initialized:
         slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
         t += 1
+    torch.cuda.synchronize()
+    log("initialised; warmup")
 
     def one_step(t):
         if dist_on:
@@ -147,6 +167,7 @@ def main():
     for _ in range(args.warmup):
         t = one_step(t)
     barrier()
+    log("timed region")
     tic = time.perf_counter()
     for _ in range(args.steps):
         t = one_step(t)
@@ -158,6 +179,7 @@ def main():
         elapsed = float(tt.item())
     frames_total = frames_per_step * args.steps * world
     value = frames_total / elapsed
+    log(f"timed region done: {elapsed:.3f}s for {frames_total} frames -> {value:.1f} frames/s")
 
     roofline, cpu_base = None, None
     if rank == 0 and not args.no_roofline and not dist_on:
@@ -177,7 +199,9 @@ def main():
                             "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
                             "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n}
     if rank == 0 and not args.no_cpu_baseline and not args.small:
+        log("cpu baseline (oracle on host cores)")
         cpu_base = cpu_baseline(cfg, sd, frames[:2].cpu(), frames_per_step)
+        log("cpu baseline done")
 
     if rank == 0:
         out = {
@@ -201,7 +225,7 @@ def cpu_baseline(cfg, sd, imgs_u8, frames_per_step):
     """Oracle (kind 'port') timed on the host cores on a BOUNDED sample: one keyframe-filter encode + one 2-view window
     at 384x512, extrapolated to a step (5 encodes + 6 views; the model cost is linear in views)."""
     from oracle import cut3r_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     x = O.normalize(imgs_u8)
     with torch.no_grad():

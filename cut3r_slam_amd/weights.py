@@ -32,6 +32,12 @@ def synth_tensor(key: str, shape, seed: int) -> np.ndarray:
             ("pose_retriever.masked_token", "pose_retriever.mem")):
         return (0.2 * z).astype(np.float32)
     if len(shape) == 1:
+        if key.endswith((".dpt_self.head.4.bias", ".dpt_cross.head.4.bias")):
+            # positive z offset: synthetic pointmaps must have depth > 0 like real ones (the tracker takes log(depth),
+            # hislam2/track_frontend.py:216)
+            out = (0.05 * z).astype(np.float32)
+            out[2] += 1.0
+            return out
         if last == "weight" and is_norm:
             return (1.0 + 0.1 * z).astype(np.float32)
         return (0.05 * z).astype(np.float32)
