@@ -132,7 +132,8 @@ def main():
     frames_per_step = KF_EVERY * WIN
     total_steps = args.warmup + args.steps
     # rank r tracks its own windows: window w of step s is global window s*world + r
-    n_kf = 6 + WIN * (total_steps * world) + 1
+    probe_steps = 0 if (args.no_roofline or dist_on) else args.steps      # second, instrumented pass
+    n_kf = 6 + WIN * ((total_steps + probe_steps) * world) + 2
     n_frames = n_kf * KF_EVERY
     config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": KF_EVERY},
                            "frontend": {"iteration": 0}}}

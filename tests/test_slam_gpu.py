@@ -105,6 +105,8 @@ def test_keyframe_filter_overlap_mode_decisions_match_oracle():
     cfgd = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 2, "kf_every": -1}, "frontend": {"iteration": 0}}}
     slam = Cut3rSlam(model, cfgd, (H, W), buffer=64, device=DEV)
     frames = _frames(40, seed=1)
+    g = torch.Generator().manual_seed(7)
+    frames[20:] = torch.randint(0, 256, frames[20:].shape, generator=g, dtype=torch.uint8)   # scene cut: unrelated images
     f = slam.filterx
     decisions, ref_dec = [], []
     for t in range(40):
@@ -121,4 +123,5 @@ def test_keyframe_filter_overlap_mode_decisions_match_oracle():
         else:
             ref_dec.append(False)
     assert decisions == ref_dec
-    assert 2 <= sum(decisions) < 40
+    assert 1 <= sum(decisions) < 40
+    print("keyframes taken at", [t for t, d in enumerate(decisions) if d])
