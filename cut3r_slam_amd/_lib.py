@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
         ("conv_k", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("conv_stride", c_int), ("Ho", c_int),
         ("Wo", c_int), ("relu_in", c_int),
         ("shuf", c_int), ("shuf_cout", c_int), ("shuf_Hin", c_int), ("shuf_Win", c_int),
-        ("tile", c_int),
+        ("tile", c_int), ("stages", c_int),
     ]
 
 

@@ -9,10 +9,10 @@
 //       /root/reference/src/croco/models/dpt_block.py:84-232, 281-513 (optional ReLU-on-load = ResidualConvUnit pre-activation)
 //   * ConvTranspose2d with kernel == stride as GEMM + pixel-shuffle scatter epilogue (dpt_block.py:416-446)
 //
-// Design (MI355X): v_mfma_f32_16x16x32_f16, 256-thread workgroups (4 waves, 2x2), BK = 64, register-staged
-// global->LDS double buffering (loads for tile t+1 issued before the MFMAs of tile t, written after them: one
-// barrier per K-tile), XOR-swizzled 16-B LDS chunks (conflict-free ds_read_b128), epilogue staged through LDS so
-// bias / residual / output traffic is 16-B coalesced.  Tile 128x128 for large grids, 64x64 when the grid would
+// Design (MI355X): v_mfma_f32_16x16x32_f16, 256-thread workgroups (4 waves, 2x2), BK = 64, LDS-DMA staging
+// (global_load_lds_dwordx4) into an N-stage LDS ring with counted s_waitcnt vmcnt and one raw s_barrier per K-tile,
+// XOR-swizzled 16-B LDS chunks (swizzle on the DMA source address + on the ds_read_b128 side), epilogue staged through
+// LDS so bias / residual / output traffic is 16-B coalesced.  Tile 128x128 for large grids, 64x64 when the grid would
 // not fill 256 CUs (batch-1 decoder GEMMs).  blockIdx.z batches independent problems with element strides.
 #include "common.h"
 #include "../../include/cut3r_hip.h"
@@ -40,16 +40,28 @@ DEVINL half8_t relu8(half8_t v) {
     return v;
 }
 
-template <int BM, int BN>
+// 16 bytes of zeros in HBM: the source of every out-of-range / padding chunk of the LDS-DMA loader
+__device__ __attribute__((aligned(16))) unsigned char g_zero16[16];
+
+template <int N>
+DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Loader: global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write).  One wave-instruction
+// writes 1 KiB = 8 tile rows x 128 B linearly; the XOR swizzle that makes the ds_read_b128 fragment reads
+// conflict-free is applied to the per-lane SOURCE chunk (lane l sits at row l>>3, chunk l&7 of its 8-row group and
+// fetches chunk (l&7)^(l>>3)), and again on the read side.  NSTAGE-deep ring, counted vmcnt, ONE raw s_barrier per
+// K-tile: NSTAGE-2 tiles stay in flight across the barrier.
+template <int BM, int BN, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2;       // wave tile
     constexpr int MT = WM / 16, NT = WN / 16;     // 16x16 MFMA tiles per wave
-    constexpr int A_CH = BM * KCH / 256;          // 16-B chunks per thread per stage
-    constexpr int B_CH = BN * KCH / 256;
+    constexpr int A_CH = BM / 32;                 // LDS-DMA instructions per wave per stage (A)
+    constexpr int B_CH = BN / 32;
+    constexpr int NL = A_CH + B_CH;
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     constexpr int CPAD = BN + 4;
     constexpr int EPI_BYTES = BM * CPAD * 4;
-    constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    constexpr int LDS_BYTES = (NSTAGE * STAGE_BYTES > EPI_BYTES) ? NSTAGE * STAGE_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -59,23 +71,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     const h16* __restrict__ Bm = g.B + (size_t)z * g.sB;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int M = g.M, N = g.N, K = g.K;
+    const h16* zero = reinterpret_cast<const h16*>(g_zero16);
 
     // ---- per-thread loader coordinates (tile-invariant part)
-    const int ck = tid & (KCH - 1);            // chunk column within the K tile
-    int a_row[A_CH]; bool a_ok[A_CH];
+    const int lrow = lane >> 3;                    // row inside the 8-row group
+    const int csrc = (lane & 7) ^ lrow;            // swizzled source chunk
+    bool a_ok[A_CH];
     const h16* a_base[A_CH];
     int a_oy[A_CH], a_ox[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; i++) {
-        int r = (tid >> 3) + i * 32;
-        a_row[i] = r;
-        int gm = m0 + r;
+        const int r = (wave + 4 * i) * 8 + lrow;
+        const int gm = m0 + r;
         a_ok[i] = gm < M;
         if (g.conv_k == 3) {
-            int gmc = a_ok[i] ? gm : 0;
-            int hw = g.Ho * g.Wo;
-            int b = gmc / hw, rem = gmc - b * hw;
-            int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            const int gmc = a_ok[i] ? gm : 0;
+            const int hw = g.Ho * g.Wo;
+            const int b = gmc / hw, rem = gmc - b * hw;
+            const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
             a_oy[i] = oy * g.cstride - 1;
             a_ox[i] = ox * g.cstride - 1;
             a_base[i] = A + (size_t)b * g.H * g.W * g.Cin;
@@ -87,54 +100,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     const h16* b_base[B_CH]; bool b_ok[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; i++) {
-        int r = (tid >> 3) + i * 32;
-        int gn = n0 + r;
+        const int gn = n0 + (wave + 4 * i) * 8 + lrow;
         b_ok[i] = gn < N;
         b_base[i] = Bm + (size_t)(b_ok[i] ? gn : 0) * g.ldb;
     }
 
-    half8_t ra[A_CH], rb[B_CH];
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + ck * 8;
+    auto issue_tile = [&](int kt, int stage) {
+        const int k = kt * BK + csrc * 8;
         const bool kok = k < K;
-        if (g.conv_k == 3) {
-            int tap = k / g.Cin, ci = k - tap * g.Cin;
-            int dy = tap / 3, dx = tap - dy * 3;
-#pragma unroll
-            for (int i = 0; i < A_CH; i++) {
-                int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
-                bool ok = kok && a_ok[i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-                half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok) v = *reinterpret_cast<const half8_t*>(a_base[i] + ((size_t)iy * g.W + ix) * g.Cin + ci);
-                ra[i] = g.relu_in ? relu8(v) : v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < A_CH; i++) {
-                half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (kok && a_ok[i]) v = *reinterpret_cast<const half8_t*>(a_base[i] + k);
-                ra[i] = g.relu_in ? relu8(v) : v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; i++) {
-            half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kok && b_ok[i]) v = *reinterpret_cast<const half8_t*>(b_base[i] + k);
-            rb[i] = v;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* sa = smem + buf * STAGE_BYTES;
+        unsigned char* sa = smem + stage * STAGE_BYTES;
         unsigned char* sb = sa + BM * BK * 2;
+        int tap = 0, ci = 0, dy = 0, dx = 0;
+        if (g.conv_k == 3) {
+            tap = k / g.Cin; ci = k - tap * g.Cin;
+            dy = tap / 3; dx = tap - dy * 3;
+        }
 #pragma unroll
         for (int i = 0; i < A_CH; i++) {
-            int r = a_row[i];
-            *reinterpret_cast<half8_t*>(sa + r * (BK * 2) + ((ck ^ (r & 7)) << 4)) = ra[i];
+            const h16* src = zero;
+            if (g.conv_k == 3) {
+                const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
+                if (kok && a_ok[i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                    src = a_base[i] + ((size_t)iy * g.W + ix) * g.Cin + ci;
+            } else if (kok && a_ok[i]) {
+                src = a_base[i] + k;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_CH; i++) {
-            int r = (tid >> 3) + i * 32;
-            *reinterpret_cast<half8_t*>(sb + r * (BK * 2) + ((ck ^ (r & 7)) << 4)) = rb[i];
+            const h16* src = (kok && b_ok[i]) ? b_base[i] + k : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + (wave + 4 * i) * 1024), 16, 0, 0);
         }
     };
 
@@ -145,15 +143,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
         for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nt = (K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; s++)
+        if (s < nt) issue_tile(s, s);
 
     const int fr = lane & 15, fq = lane >> 4;   // fragment row, k-chunk
+    int stage = 0;
     for (int t = 0; t < nt; t++) {
-        const int cur = t & 1;
-        if (t + 1 < nt) load_tile(t + 1);
-        const unsigned char* sa = smem + cur * STAGE_BYTES;
+        // tiles that may stay in flight behind tile t: min(NSTAGE-2, nt-1-t)
+        const int ahead = nt - 1 - t;
+        if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<2 * NL>();
+        else if (NSTAGE >= 3 && ahead >= 1) wait_vmcnt<NL>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + NSTAGE - 1 < nt) {
+            int st2 = stage + NSTAGE - 1;
+            if (st2 >= NSTAGE) st2 -= NSTAGE;
+            issue_tile(t + NSTAGE - 1, st2);
+        }
+        const unsigned char* sa = smem + stage * STAGE_BYTES;
         const unsigned char* sb = sa + BM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; kk++) {
@@ -163,6 +171,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
             for (int i = 0; i < MT; i++) {
                 int r = wm * WM + i * 16 + fr;
                 fa[i] = *reinterpret_cast<const half8_t*>(sa + r * (BK * 2) + ((ch ^ (r & 7)) << 4));
+                if (g.relu_in) fa[i] = relu8(fa[i]);
             }
 #pragma unroll
             for (int j = 0; j < NT; j++) {
@@ -175,9 +184,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
                 for (int j = 0; j < NT; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < nt) store_tile(cur ^ 1);
-        __syncthreads();
+        if (++stage == NSTAGE) stage = 0;
     }
+    __syncthreads();
 
     // ---- epilogue: accumulators -> LDS (fp32) -> coalesced fused store
     float* cs = reinterpret_cast<float*>(smem);
@@ -315,10 +324,13 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     if (tile == 0) tile = (big_blocks >= 192) ? 128 : 64;
     if (tile == 128) {
         dim3 grid((d->N + 127) / 128, (d->M + 127) / 128, batch);
-        hipLaunchKernelGGL((gemm_kernel<128, 128>), grid, dim3(256), 0, s, g);
+        if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<128, 128, 3>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_kernel<128, 128, 2>), grid, dim3(256), 0, s, g);
     } else if (tile == 64) {
         dim3 grid((d->N + 63) / 64, (d->M + 63) / 64, batch);
-        hipLaunchKernelGGL((gemm_kernel<64, 64>), grid, dim3(256), 0, s, g);
+        if (d->stages == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 2>), grid, dim3(256), 0, s, g);
+        else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<64, 64, 4>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_kernel<64, 64, 3>), grid, dim3(256), 0, s, g);
     } else {
         return CUT3R_ERR_ARG;
     }

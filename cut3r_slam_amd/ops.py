@@ -91,6 +91,9 @@ def layernorm(x, gamma, beta, eps=1e-6, out16=None, out32=None, mod_scale=None, 
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+GEMM_STAGES = 0     # tuning override (0 = kernel default)
+
+
 def _fill_common(d, A, Bw, out, bias, res1, res2, act, tile):
     d.A, d.B, d.C = A.data_ptr(), Bw.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -98,6 +101,7 @@ def _fill_common(d, A, Bw, out, bias, res1, res2, act, tile):
     d.out_f16 = 1 if out.dtype == F16 else 0
     d.batch = 1
     d.tile = tile
+    d.stages = GEMM_STAGES
     for i, r in ((1, res1), (2, res2)):
         if r is not None:
             _req(r.dtype in (F16, F32) and r.stride(-1) == 1, "residual must be fp16/fp32 with unit inner stride")
@@ -125,6 +129,30 @@ def linear(A, W, out, bias=None, act=0, res1=None, res2=None, tile=0):
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, A.stride(0), W.stride(0), out.stride(0)
     lib = _lib.load()
     check(lib.cut3r_gemm_f16(C.byref(d), _stream()), f"cut3r_gemm_f16 M={M} N={N} K={K}")
+    return out
+
+
+def linear_batched(A, W, out, bias=None, act=0, res1=None, tile=0):
+    """Z independent problems in ONE launch (blockIdx.z): A [Z,M,K], W [Z,N,K] fp16; out [Z,M,N] fp16|fp32;
+    bias [Z,N] fp32; res1 [Z,M,N].  Used to run the state-side and image-side decoder GEMMs of a layer together."""
+    _cuda(A, W, out, bias, res1)
+    _req(A.dtype == F16 and W.dtype == F16 and A.dim() == 3 and W.dim() == 3 and out.dim() == 3, "3-D fp16 operands")
+    Z, M, K = A.shape
+    N = W.shape[1]
+    _req(W.shape == (Z, N, K) and out.shape == (Z, M, N), "batched shapes")
+    _req(A.stride(2) == 1 and W.stride(2) == 1 and out.stride(2) == 1, "unit inner strides")
+    d = GemmDesc()
+    _fill_common(d, A, W, out, bias, None, None, act, tile)
+    if bias is not None:
+        _req(bias.dtype == F32 and bias.shape == (Z, N) and bias.stride(1) == 1, "bias [Z,N]")
+        d.strideBias = bias.stride(0)
+    if res1 is not None:
+        _req(res1.shape == (Z, M, N) and res1.stride(2) == 1 and res1.dtype in (F16, F32), "res1 [Z,M,N]")
+        d.res1, d.ldr1, d.res1_f16, d.strideR1 = res1.data_ptr(), res1.stride(1), int(res1.dtype == F16), res1.stride(0)
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, A.stride(1), W.stride(1), out.stride(1)
+    d.batch, d.strideA, d.strideB, d.strideC = Z, A.stride(0), W.stride(0), out.stride(0)
+    lib = _lib.load()
+    check(lib.cut3r_gemm_f16(C.byref(d), _stream()), f"cut3r_gemm_f16 batched Z={Z} M={M} N={N} K={K}")
     return out
 
 

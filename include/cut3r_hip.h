@@ -55,6 +55,7 @@ typedef struct cut3r_gemm_desc {
     int shuf;             /* > 0: ConvTranspose(k == stride == shuf) scatter; N = shuf*shuf*shuf_cout, ldc = Cout */
     int shuf_cout, shuf_Hin, shuf_Win;
     int tile;             /* 0 = auto, 64 or 128 */
+    int stages;           /* 0 = default; LDS ring depth override (tuning): 2|3 for tile 128, 2|3|4 for tile 64 */
 } cut3r_gemm_desc;
 int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream);
 
