@@ -68,6 +68,9 @@ class Cut3rModel:
             if tuple(state_dict[k].shape) != tuple(shp):
                 raise ValueError(f"{k}: shape {tuple(state_dict[k].shape)} != schema {tuple(shp)}")
         self._buf: Dict[tuple, torch.Tensor] = {}
+        self._graphs: Dict[tuple, tuple] = {}
+        import os as _os
+        self.use_graphs = _os.environ.get("CUT3R_GRAPHS", "1") != "0"
         self._prep(state_dict)
 
     # ------------------------------------------------------------------ reference-compatible constructors
@@ -271,6 +274,33 @@ class Cut3rModel:
         self._ln(x, "enc_norm", out16=feat16.view(M, E), out32=feat.view(M, E))
         return feat, feat16, pos
 
+    # ------------------------------------------------------------------ hipGraph capture
+    def _graphed(self, kind, fn, inp):
+        """Capture `fn(static_input)` once per input signature into a hipGraph and replay it: a window is ~4000 kernel
+        launches, which the Python/ctypes host path cannot issue as fast as the GPU retires them.  Inputs are copied
+        into a static buffer; outputs are static tensors that the caller must consume before the next replay."""
+        key = (kind, tuple(inp.shape), inp.dtype)
+        ent = self._graphs.get(key)
+        if ent is None:
+            static_in = inp.clone()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):          # warm-up: creates every persistent workspace outside the capture
+                    fn(static_in)
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = fn(static_in)
+            ent = (graph, static_in, out)
+            self._graphs[key] = ent
+        graph, static_in, out = ent
+        static_in.copy_(inp, non_blocking=True)
+        graph.replay()
+        return out
+
     def normalize(self, img_tensor):
         return (img_tensor / 255.0 - 0.5) / 0.5
 
@@ -280,7 +310,12 @@ class Cut3rModel:
             img = img.to(self.device)
         B = img.shape[0]
         im_shape = view.get("true_shape", torch.tensor(img.shape[-2:])[None].repeat(B, 1))
-        feat, _, pos = self._encode(img.to(F32) if img.dtype != torch.uint8 else img)
+        img = img.to(F32) if img.dtype != torch.uint8 else img
+        if self.use_graphs:
+            feat, _, pos = self._graphed("enc", self._encode, img.contiguous())
+            feat = feat.clone()            # callers keep encoder features (keyframe store)
+        else:
+            feat, _, pos = self._encode(img)
         return feat, pos, im_shape
 
     # ------------------------------------------------------------------ decoder block
@@ -402,7 +437,13 @@ class Cut3rModel:
     # ------------------------------------------------------------------ window forward
     @torch.no_grad()
     def forward_window(self, imgs: torch.Tensor, return_taps: bool = False):
-        """imgs [V,3,H,W] on the GPU (fp32 normalised or uint8).  Returns (list of V pred dicts, taps)."""
+        """imgs [V,3,H,W] on the GPU (fp32 normalised or uint8).  Returns (list of V pred dicts, taps).
+        With graphs enabled the prediction tensors are static buffers, valid until the next call."""
+        if self.use_graphs and not return_taps:
+            return self._graphed("win", lambda x: self._forward_window(x, False), imgs.contiguous())
+        return self._forward_window(imgs, return_taps)
+
+    def _forward_window(self, imgs: torch.Tensor, return_taps: bool = False):
         cfg = self.cfg
         V, _, H, W = imgs.shape
         P, E, D, Ld = cfg.patch_size, cfg.enc_embed_dim, cfg.dec_embed_dim, cfg.dec_depth
