@@ -190,10 +190,12 @@ def main():
         if t + need <= frames.shape[0]:
             probe = GemmProbe()
             probe.install()
+            model.use_graphs = False      # events must bracket live launches, not a graph replay
             for _ in range(args.steps):
                 t = one_step(t)
             n, ms, fl = probe.result()
             probe.remove()
+            model.use_graphs = True
             if n:
                 ach = fl / (ms * 1e-3) / 1e12
                 roofline = {"bound": "mfma", "kernel": "gemm_kernel<128,128> (v_mfma_f32_16x16x32_f16)", "achieved": round(ach, 2),

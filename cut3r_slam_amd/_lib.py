@@ -56,6 +56,13 @@ SIGNATURES = {
     "cut3r_align_view": [c_void_p, c_void_p, c_int, c_int, C.POINTER(c_float), c_float, c_int, c_void_p, c_void_p,
                          c_void_p, c_void_p],
     "cut3r_logdepth_sum": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "cut3r_lie_unary": [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "cut3r_lie_unary_bwd": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "cut3r_lie_mul": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "cut3r_lie_mul_bwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "cut3r_lie_act": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "cut3r_lie_act_bwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "cut3r_lie_adj": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
 }
 
 _lib = None

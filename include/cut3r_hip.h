@@ -126,6 +126,24 @@ int cut3r_align_view(const float* pts, const float* conf, int H, int W, const fl
 /* sum_i log(prev_depth[i]) - log(pts[i].z) -> out[0] (fp64 accumulate, device double[1], zeroed by the call) */
 int cut3r_logdepth_sum(const float* prev_depth, const float* pts, int n, double* out, void* stream);
 
+/* ---- Lie groups (slot of the un-vendored princeton-vl/lietorch 0.2, "lietorch_backends") -------------------------------
+ * call sites: hislam2/track_backend.py:269-270,298-299,418-425,458-459 (SE3.exp / .matrix / .data),
+ * hislam2/gs_backend_per_frame.py:721-731, hislam2/geom/projective_ops.py:17,51,67,69, hislam2/geom/ba.py:29,37.
+ * group: 0 = SO3 (tangent 3, data 4 = q_xyzw), 1 = SE3 (6 = [tau,phi], 7 = [t,q_xyzw]), 2 = Sim3 (7, 8 = [t,q,s]).
+ * All tensors fp32, contiguous, n elements.  op: 0 exp (tangent->data), 1 log (data->tangent), 2 inv (data->data),
+ * 3 matrix (data -> 16 floats, row-major 4x4).  *_bwd are vector-Jacobian products w.r.t. the Euclidean components. */
+int cut3r_lie_unary(int group, int op, const float* in, float* out, int n, void* stream);
+int cut3r_lie_unary_bwd(int group, int op, const float* in, const float* grad_out, float* grad_in, int n, void* stream);
+int cut3r_lie_mul(int group, const float* x, const float* y, float* out, int n, void* stream);
+int cut3r_lie_mul_bwd(int group, const float* x, const float* y, const float* grad_out, float* grad_x, float* grad_y, int n,
+                      void* stream);
+/* element e acts on its P points p[e,:,pd] (pd = 3, or 4 = homogeneous [X,Y,Z,W] -> [R*XYZ*s + t*W, W]) */
+int cut3r_lie_act(int group, const float* x, const float* p, float* out, int n, int P, int pd, void* stream);
+int cut3r_lie_act_bwd(int group, const float* x, const float* p, const float* grad_out, float* grad_x, float* grad_p, int n, int P,
+                      int pd, void* stream);
+/* adjoint (transpose = 0) or transposed adjoint (1) of element e applied to tangent vector a[e] */
+int cut3r_lie_adj(int group, const float* x, const float* a, float* out, int n, int transpose, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
