@@ -50,7 +50,7 @@ SIGNATURES = {
     "cut3r_postprocess_pose": [c_void_p, c_int, c_void_p, c_void_p],
     "cut3r_patch_overlap": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "cut3r_overlap_fwd": [c_void_p, c_int, C.POINTER(c_float), c_float, c_void_p, c_int, c_float, c_float, c_float, c_float,
-                          c_int, c_int, c_void_p, c_void_p],
+                          c_int, c_int, c_int, c_void_p, c_void_p],
     "cut3r_overlap_bwd": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_int, c_int,
                           c_void_p, c_void_p],
     "cut3r_align_view": [c_void_p, c_void_p, c_int, c_int, C.POINTER(c_float), c_float, c_int, c_void_p, c_void_p,
@@ -63,6 +63,10 @@ SIGNATURES = {
     "cut3r_lie_act": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "cut3r_lie_act_bwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "cut3r_lie_adj": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "cut3r_lc_workspace_floats": [c_int, c_int],
+    "cut3r_lc_optimize": [c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_float,
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "cut3r_transform_submaps": [c_void_p, c_void_p, c_int, c_ll, c_void_p],
 }
 
 _lib = None

@@ -28,7 +28,7 @@ constexpr int OVL_MAXB = 2048;
 struct AlignArgs { float P[12]; float s; };
 
 __global__ __launch_bounds__(256) void overlap_fwd_kernel(const float* __restrict__ pm, int N, const float* __restrict__ w2c, int B,
-                                                          Cam cam, int32_t* __restrict__ counts, int has_align, AlignArgs al) {
+                                                          Cam cam, int32_t* __restrict__ counts, int has_align, AlignArgs al, int clamp_z) {
     __shared__ int32_t cnt[OVL_MAXB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int p = blockIdx.x * 256 + tid;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void overlap_fwd_kernel(const float* __restric
         for (int i = tid; i < nb; i += 256) cnt[i] = 0;
         __syncthreads();
         for (int b = 0; b < nb; b++) {
-            const int v = ok ? proj_valid(w2c + 12 * (size_t)(b0 + b), x, y, z, cam, true) : 0;
+            const int v = ok ? proj_valid(w2c + 12 * (size_t)(b0 + b), x, y, z, cam, clamp_z != 0) : 0;
             const unsigned long long bal = __ballot(v);
             if (lane == 0) atomicAdd(&cnt[b], (int)__popcll(bal));
         }
@@ -192,7 +192,7 @@ inline int grid_for(size_t total, int block = 256) {
 }  // namespace
 
 extern "C" int cut3r_overlap_fwd(const float* pm, int N, const float* P_host, float s_align, const float* w2c, int B, float fx,
-                                 float fy, float cx, float cy, int W, int H, int32_t* counts, void* stream) {
+                                 float fy, float cx, float cy, int W, int H, int clamp_z, int32_t* counts, void* stream) {
     if (!pm || !w2c || !counts || N <= 0 || B <= 0) return CUT3R_ERR_ARG;
     AlignArgs al;
     for (int i = 0; i < 12; i++) al.P[i] = P_host ? P_host[i] : 0.f;
@@ -200,7 +200,7 @@ extern "C" int cut3r_overlap_fwd(const float* pm, int N, const float* P_host, fl
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(counts, 0, sizeof(int32_t) * B, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
     Cam cam{fx, fy, cx, cy, W, H};
-    hipLaunchKernelGGL(overlap_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, pm, N, w2c, B, cam, counts, P_host ? 1 : 0, al);
+    hipLaunchKernelGGL(overlap_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, pm, N, w2c, B, cam, counts, P_host ? 1 : 0, al, clamp_z);
     return cut3r_check_launch();
 }
 

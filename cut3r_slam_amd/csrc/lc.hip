@@ -1,0 +1,183 @@
+// Fused loop-closure optimiser on gfx950: Adam over per-submap se(3) corrections minimising the L1 disagreement of
+// overlapping pointmaps (reference: /root/reference/hislam2/track_backend.py:256-299 `loop_closure_init`, :400-461).
+//
+// The reference runs ~60 tiny autograd kernels per iteration for 1000-2000 iterations (launch-bound).  Here one
+// iteration is TWO launches:
+//   lc_accum : one streaming pass over the first/last pointmaps of every submap (2*B*N*12 bytes, HBM/L2 bound); each
+//              thread folds sign(residual) x [p;1] into the 3x4 gradient of both matrices of its pair in registers,
+//              wave-shuffle + LDS reduce, one partial row per block (deterministic: no float atomics).
+//   lc_adam  : one thread per submap: sums its partial rows in fixed order, pulls the 3x4 gradient back through
+//              matrix(exp(xi)) with forward-mode duals (lie_math.h), Adam step, writes the new 3x4 matrix.
+// Loss (identical to the reference):  mean_{masked (b,n), xyz} |T_b last_b - T_{b+1} first_{b+1}|
+//                                    + mean_{n, xyz} |T_{B-1} cur - cur_lc|,  T_0 = I fixed.
+#include "common.h"
+#include "lie_math.h"
+#include "../../include/cut3r_hip.h"
+
+namespace {
+using namespace liemath;
+
+constexpr int LC_PPT = 8;               // points per thread
+constexpr int LC_BLOCK = 256;
+constexpr int LC_ROW = 28;              // 12 (grad of the 'a' matrix) + 12 (grad of the 'c' matrix) + loss + pad
+
+DEVINL void apply34(const float* __restrict__ T, float x, float y, float z, float& ox, float& oy, float& oz) {
+    ox = fmaf(T[2], z, fmaf(T[1], y, fmaf(T[0], x, T[3])));
+    oy = fmaf(T[6], z, fmaf(T[5], y, fmaf(T[4], x, T[7])));
+    oz = fmaf(T[10], z, fmaf(T[9], y, fmaf(T[8], x, T[11])));
+}
+DEVINL float sgn(float r) { return r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f); }
+
+// pair p in [0, B-2]: a = T_p * last_p, c = T_{p+1} * first_{p+1} (masked);  pair B-1: a = T_{B-1} * cur, c = cur_lc (fixed)
+__global__ __launch_bounds__(LC_BLOCK) void lc_accum_kernel(const float* __restrict__ first, const float* __restrict__ last,
+                                                            long long sub_stride, const unsigned char* __restrict__ mask,
+                                                            const float* __restrict__ cur, const float* __restrict__ cur_lc,
+                                                            const float* __restrict__ T, int B, int N, float w_fl, float w_cur,
+                                                            float* __restrict__ partial, int nblk) {
+    __shared__ float red[4][LC_ROW];
+    const int p = blockIdx.y;
+    const bool is_cur = (p == B - 1);
+    const float* pa = is_cur ? cur : last + (size_t)p * sub_stride;
+    const float* pc = is_cur ? cur_lc : first + (size_t)(p + 1) * sub_stride;
+    const float* Ta = T + 12 * (is_cur ? (B - 1) : p);
+    const float* Tc = T + 12 * (is_cur ? 0 : (p + 1));
+    const float w = is_cur ? w_cur : w_fl;
+    float acc[LC_ROW];
+#pragma unroll
+    for (int k = 0; k < LC_ROW; k++) acc[k] = 0.f;
+    const int base = blockIdx.x * (LC_BLOCK * LC_PPT) + threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < LC_PPT; it++) {
+        const int n = base + it * LC_BLOCK;
+        if (n >= N) break;
+        if (!is_cur && mask && !mask[(size_t)p * N + n]) continue;
+        const float ax = pa[3 * (size_t)n], ay = pa[3 * (size_t)n + 1], az = pa[3 * (size_t)n + 2];
+        const float cx = pc[3 * (size_t)n], cy = pc[3 * (size_t)n + 1], cz = pc[3 * (size_t)n + 2];
+        float a0, a1, a2, c0, c1, c2;
+        apply34(Ta, ax, ay, az, a0, a1, a2);
+        if (is_cur) { c0 = cx; c1 = cy; c2 = cz; }
+        else apply34(Tc, cx, cy, cz, c0, c1, c2);
+        const float r0 = a0 - c0, r1 = a1 - c1, r2 = a2 - c2;
+        const float s0 = sgn(r0), s1 = sgn(r1), s2 = sgn(r2);
+        acc[24] += fabsf(r0) + fabsf(r1) + fabsf(r2);
+        acc[0] += s0 * ax; acc[1] += s0 * ay; acc[2] += s0 * az; acc[3] += s0;
+        acc[4] += s1 * ax; acc[5] += s1 * ay; acc[6] += s1 * az; acc[7] += s1;
+        acc[8] += s2 * ax; acc[9] += s2 * ay; acc[10] += s2 * az; acc[11] += s2;
+        if (!is_cur) {
+            acc[12] -= s0 * cx; acc[13] -= s0 * cy; acc[14] -= s0 * cz; acc[15] -= s0;
+            acc[16] -= s1 * cx; acc[17] -= s1 * cy; acc[18] -= s1 * cz; acc[19] -= s1;
+            acc[20] -= s2 * cx; acc[21] -= s2 * cy; acc[22] -= s2 * cz; acc[23] -= s2;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 25; k++) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 25) {
+        const int k = threadIdx.x;
+        partial[((size_t)p * nblk + blockIdx.x) * LC_ROW + k] = (red[0][k] + red[1][k] + red[2][k] + red[3][k]) * w;
+    }
+}
+
+struct AdamHyper { float lr, b1, b2, eps; };
+
+// one thread per optimised submap b = 1..B-1  (b = 0 is the fixed identity)
+__global__ void lc_adam_kernel(const float* __restrict__ partial, int nblk, int B, float* __restrict__ xi, float* __restrict__ m,
+                               float* __restrict__ v, float* __restrict__ T, float* __restrict__ loss_out, int step, AdamHyper h) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) {
+        // total loss of this iteration (deterministic order) -- for logging / convergence tests
+        float L = 0.f;
+        for (int p = 0; p < B; p++)
+            for (int k = 0; k < nblk; k++) L += partial[((size_t)p * nblk + k) * LC_ROW + 24];
+        if (loss_out) loss_out[step] = L;
+        return;
+    }
+    if (b >= B) return;
+    float G[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) G[k] = 0.f;
+    // 'a' role: pair b (b <= B-2: last_b; b == B-1: the current term); 'c' role: pair b-1
+    for (int k = 0; k < nblk; k++) {
+        const float* ra = partial + ((size_t)b * nblk + k) * LC_ROW;
+        const float* rc = partial + ((size_t)(b - 1) * nblk + k) * LC_ROW + 12;
+#pragma unroll
+        for (int e = 0; e < 12; e++) G[e] += ra[e] + rc[e];
+    }
+    typedef Dual<6> D;
+    D a[6], X[7], M[16];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { a[k] = D(xi[(size_t)b * 6 + k]); a[k].d[k] = 1.f; }
+    f_exp<1, D>(a, X);
+    f_matrix<1, D>(X, M);
+    const float bc1 = 1.f - powf(h.b1, (float)(step + 1)), bc2 = 1.f - powf(h.b2, (float)(step + 1));
+    float nx[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        float g = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) g += G[r * 4 + c] * M[r * 4 + c].d[j];
+        const float mj = h.b1 * m[(size_t)b * 6 + j] + (1.f - h.b1) * g;
+        const float vj = h.b2 * v[(size_t)b * 6 + j] + (1.f - h.b2) * g * g;
+        m[(size_t)b * 6 + j] = mj;
+        v[(size_t)b * 6 + j] = vj;
+        // torch.optim.Adam: step_size = lr / bc1 ; denom = sqrt(v)/sqrt(bc2) + eps
+        nx[j] = xi[(size_t)b * 6 + j] - (h.lr / bc1) * mj / (sqrtf(vj) / sqrtf(bc2) + h.eps);
+        xi[(size_t)b * 6 + j] = nx[j];
+    }
+    float Xf[7], Mf[16];
+    f_exp<1, float>(nx, Xf);
+    f_matrix<1, float>(Xf, Mf);
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[(size_t)b * 12 + k] = Mf[k];
+}
+
+// in-place p <- T_b p over every pointmap of submap b (the rewrite at track_backend.py:306-310)
+__global__ __launch_bounds__(256) void transform_submaps_kernel(float* __restrict__ pts, const float* __restrict__ T, long long per_sub) {
+    const int b = blockIdx.y;
+    const float* Tb = T + 12 * b;
+    float* p = pts + (size_t)b * per_sub * 3;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)per_sub; i += (size_t)gridDim.x * blockDim.x) {
+        float ox, oy, oz;
+        apply34(Tb, p[3 * i], p[3 * i + 1], p[3 * i + 2], ox, oy, oz);
+        p[3 * i] = ox; p[3 * i + 1] = oy; p[3 * i + 2] = oz;
+    }
+}
+
+}  // namespace
+
+extern "C" int cut3r_lc_workspace_floats(int B, int N) {
+    const int nblk = (N + LC_BLOCK * LC_PPT - 1) / (LC_BLOCK * LC_PPT);
+    return B * nblk * LC_ROW;
+}
+
+extern "C" int cut3r_lc_optimize(const float* first, const float* last, long long sub_stride, const unsigned char* mask,
+                                 const float* cur, const float* cur_lc, int B, int N, long long n_masked, int iters, float lr,
+                                 float* xi, float* adam_m, float* adam_v, float* T, float* workspace, float* loss_out, void* stream) {
+    if (!first || !last || !cur || !cur_lc || !xi || !adam_m || !adam_v || !T || !workspace) return CUT3R_ERR_ARG;
+    if (B < 2 || N <= 0 || iters < 0 || n_masked < 0) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (N + LC_BLOCK * LC_PPT - 1) / (LC_BLOCK * LC_PPT);
+    const float w_fl = n_masked > 0 ? 1.0f / (3.0f * (float)n_masked) : 0.f;
+    const float w_cur = 1.0f / (3.0f * (float)N);
+    AdamHyper h{lr, 0.9f, 0.999f, 1e-8f};
+    for (int it = 0; it < iters; it++) {
+        hipLaunchKernelGGL(lc_accum_kernel, dim3(nblk, B), dim3(LC_BLOCK), 0, s, first, last, sub_stride, mask, cur, cur_lc, T, B, N,
+                           w_fl, w_cur, workspace, nblk);
+        hipLaunchKernelGGL(lc_adam_kernel, dim3((B + 63) / 64), dim3(64), 0, s, workspace, nblk, B, xi, adam_m, adam_v, T, loss_out, it, h);
+    }
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_transform_submaps(float* pts, const float* T, int B, long long points_per_submap, void* stream) {
+    if (!pts || !T || B <= 0 || points_per_submap <= 0) return CUT3R_ERR_ARG;
+    int gx = (int)((points_per_submap + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(transform_submaps_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, pts, T, points_per_submap);
+    return cut3r_check_launch();
+}

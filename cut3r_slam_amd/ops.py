@@ -307,7 +307,7 @@ def patch_overlap_count(feat0, feat1, thr, ws, count):
     check(lib.cut3r_patch_overlap(_p(feat0), _p(feat1), N, Cc, float(thr), _p(ws), _p(count), _stream()), "cut3r_patch_overlap")
 
 
-def overlap_fwd(pm, w2c, K4, W, H, counts, P12=None, s_align=1.0):
+def overlap_fwd(pm, w2c, K4, W, H, counts, P12=None, s_align=1.0, clamp_z=True):
     """counts[b] = #points of pm (optionally mapped p <- P*(s*p) first) that land inside camera b's W x H image."""
     _cuda(pm, w2c, counts)
     N = pm.numel() // 3
@@ -317,7 +317,7 @@ def overlap_fwd(pm, w2c, K4, W, H, counts, P12=None, s_align=1.0):
     arr = (C.c_float * 12)(*[float(v) for v in P12]) if P12 is not None else None
     lib = _lib.load()
     check(lib.cut3r_overlap_fwd(_p(pm), N, arr, float(s_align), _p(w2c), B, *[float(v) for v in K4], int(W), int(H),
-                                _p(counts), _stream()), "cut3r_overlap_fwd")
+                                int(clamp_z), _p(counts), _stream()), "cut3r_overlap_fwd")
 
 
 def overlap_bwd(pms, w2c, K4, W, H, counts, B=None, N=None, grp=0, grp_stride=0):
@@ -356,3 +356,47 @@ def logdepth_sum(prev_depth, pts, out):
     _req(out.dtype == torch.float64 and out.numel() == 1, "out fp64[1]")
     lib = _lib.load()
     check(lib.cut3r_logdepth_sum(_p(prev_depth), _p(pts), n, _p(out), _stream()), "cut3r_logdepth_sum")
+
+
+# ------------------------------------------------------------------------------------------------ loop closure
+def lc_optimize(submaps, mask, cur, cur_lc, iters, lr=5e-4, return_loss=False):
+    """Fused Adam over per-submap se(3) corrections (track_backend.py:256-299).  submaps: [B,6,h,w,3] fp32 contiguous
+    (slot 0 = first, slot 5 = last pointmap of each submap); mask: bool/uint8 [B-1,h*w] or None; cur, cur_lc: [h*w,3].
+    Returns (xi [B,6], T [B,3,4]) (+ per-iteration loss)."""
+    _cuda(submaps, mask, cur, cur_lc)
+    _req(submaps.dtype == F32 and submaps.dim() == 5 and submaps.is_contiguous() and submaps.shape[1] == 6 and submaps.shape[4] == 3, "submaps [B,6,h,w,3]")
+    B = submaps.shape[0]
+    N = submaps.shape[2] * submaps.shape[3]
+    _req(B >= 2, "need at least two submaps")
+    cur = cur.reshape(-1, 3).contiguous()
+    cur_lc = cur_lc.reshape(-1, 3).contiguous()
+    _req(cur.shape == (N, 3) and cur_lc.shape == (N, 3) and cur.dtype == F32 and cur_lc.dtype == F32, "cur / cur_lc [N,3] fp32")
+    dev = submaps.device
+    if mask is not None:
+        mask = mask.reshape(B - 1, N).to(torch.uint8).contiguous()
+        n_masked = int(mask.sum().item())
+    else:
+        n_masked = (B - 1) * N
+    lib = _lib.load()
+    xi = torch.zeros(B, 6, device=dev)
+    m, v = torch.zeros_like(xi), torch.zeros_like(xi)
+    T = torch.eye(4, device=dev)[:3].reshape(1, 12).repeat(B, 1).contiguous()
+    ws = torch.empty(lib.cut3r_lc_workspace_floats(B, N), device=dev)
+    loss = torch.zeros(max(iters, 1), device=dev) if return_loss else None
+    first = submaps
+    last_ptr = C.c_void_p(submaps.data_ptr() + 5 * N * 3 * 4)
+    check(lib.cut3r_lc_optimize(_p(first), last_ptr, 6 * N * 3, _p(mask), _p(cur), _p(cur_lc), B, N, n_masked, int(iters), float(lr),
+                                _p(xi), _p(m), _p(v), _p(T), _p(ws), _p(loss), _stream()), "cut3r_lc_optimize")
+    T = T.view(B, 3, 4)
+    return (xi, T, loss) if return_loss else (xi, T)
+
+
+def transform_submaps(submaps, T):
+    """in place: every point of submap b <- T[b] (3x4) applied (track_backend.py:301-310)."""
+    _cuda(submaps, T)
+    B = submaps.shape[0]
+    _req(submaps.dtype == F32 and submaps.is_contiguous() and T.dtype == F32 and T.is_contiguous() and T.numel() == 12 * B, "transform_submaps")
+    per = submaps[0].numel() // 3
+    lib = _lib.load()
+    check(lib.cut3r_transform_submaps(_p(submaps), _p(T), B, per, _stream()), "cut3r_transform_submaps")
+    return submaps

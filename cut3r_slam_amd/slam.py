@@ -14,6 +14,7 @@ from .factor_graph import FactorGraph
 from .keyframe import KeyFrame
 from .motion_filter import MotionFilter
 from .track_frontend import TrackFrontend
+from .track_backend import TrackBackend
 
 DEFAULT_CONFIG = {
     "Tracking": {
@@ -38,7 +39,7 @@ class Cut3rSlam:
         self.graph = FactorGraph(self.keyframes, device=device, max_factors=48)
         self.filterx = MotionFilter(model, self.keyframes, self.config["Tracking"]["motion_filter"], device)
         self.tracker = TrackFrontend(self, self.keyframes, self.config["Tracking"]["frontend"], device)
-        self.backend = None
+        self.backend = TrackBackend(self, self.keyframes, self.config["Tracking"]["frontend"], device)
         self.do_lc = self.config["Tracking"]["frontend"].get("iteration", 0) > 0
         self.freeze_counter = 0
 

@@ -1,0 +1,217 @@
+"""Loop closure backend with the reference's control flow (/root/reference/hislam2/track_backend.py:527-586 `run`,
+:137-217 `track`, :220-358 `loop_closure_init`, :361-524 `loop_closure`) on HBM-resident submaps.
+
+  detection : covisible keyframes farther than 8 frames apart (FactorGraph.detect_loop)
+  NMS       : 0.8 * mean(bidirectional reprojection overlap) + 0.2 * patch-feature overlap, accept if > 0.4
+  re-track  : 6-view inference over [5 keyframes of the matched submap, current keyframe], chained to the anchor
+  optimise  : first loop  -> fused HIP Adam over per-submap se(3) (ops.lc_optimize: 2 launches / iteration)
+              later loops -> same objective plus the matched-submap terms, through cut3r_slam_amd.lietorch autograd
+  rewrite   : every pointmap of every corrected submap in place (ops.transform_submaps) + the 7-float poses
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import geom_host as gh
+from . import ops
+from .lietorch import SE3
+
+
+class TrackBackend:
+    def __init__(self, slam, keyframes, config, device="cuda:0"):
+        self.device = device
+        self.keyframes = keyframes
+        self.model = slam.model
+        self.graph = slam.graph
+        self.loop_iters = int(config.get("iteration", 0))
+        self.downsample_ratio = slam.downsample_ratio
+        self.conf_th = 0.05
+        self.lc_initialized = False
+        self.closed_loop = {"idx_current": [], "idx_matched": [], "pointmaps_lc": []}
+        self._lsum = torch.zeros(1, dtype=torch.float64, device=device)
+        self._count = torch.zeros(1, dtype=torch.int32, device=device)
+        self._ws = None
+
+    # ------------------------------------------------------------------ NMS (factor_graph.py:561-582)
+    def _feat_overlap(self, f0, f1s, thr=0.7):
+        N, C = f0.shape
+        need = 2 * (N - 1) * C + N
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=self.device)
+        counts = torch.zeros(len(f1s), dtype=torch.int32, device=self.device)
+        for i, f1 in enumerate(f1s):
+            ops.patch_overlap_count(f0.contiguous(), f1.contiguous(), thr, self._ws, counts[i:i + 1])
+        return counts.float() / float(N - 1)
+
+    def nms(self, ids_matched, idx_current, K4, th=0.4):
+        kf = self.keyframes
+        h, w = kf.submap_ds.shape[2], kf.submap_ds.shape[3]
+        ids = torch.as_tensor(np.asarray(ids_matched), dtype=torch.long)
+        pm_matched = kf.submap_ds[ids // 5, ids % 5].contiguous()                       # [B,h,w,3]
+        pm_cur = kf.submap_ds[idx_current // 5, idx_current % 5].contiguous()
+        B = len(ids)
+        a2c = torch.empty(B, dtype=torch.int32, device=self.device)
+        c2a = torch.empty(B, dtype=torch.int32, device=self.device)
+        ops.overlap_bwd(pm_matched, kf.w2c[idx_current].contiguous(), K4, w, h, a2c)
+        ops.overlap_fwd(pm_cur, kf.w2c[ids.to(kf.w2c.device)].contiguous(), K4, w, h, c2a, clamp_z=False)
+        feat = self._feat_overlap(kf.featI[idx_current], [kf.featI[int(i)] for i in ids])
+        overlap = (a2c.float() / (h * w) + c2a.float() / (h * w)) / 2
+        scores = (0.8 * overlap + 0.2 * feat).cpu()
+        if float(scores.max()) > th:
+            return int(torch.argmax(scores))
+        return None
+
+    # ------------------------------------------------------------------ re-tracking against the anchor submap
+    def track(self, selected_idx, anchor_sub_num):
+        kf, ds = self.keyframes, self.downsample_ratio
+        sel = torch.as_tensor(np.asarray(selected_idx), dtype=torch.long)
+        imgs = kf.image[sel.to(kf.image.device)]
+        preds, _ = self.model.forward_window(imgs)
+        pts = torch.cat([p["pts3d_in_self_view"] for p in preds], 0).contiguous()
+        conf = torch.cat([p["conf_self"] for p in preds], 0).contiguous()
+        enc = torch.cat([p["camera_pose"] for p in preds], 0)
+        V, H, W, _ = pts.shape
+        a = anchor_sub_num * 5
+        ops.logdepth_sum(kf.depth[a], pts[0], self._lsum)
+        host = enc.detach().cpu().numpy()
+        align_s = np.float32(math.exp(np.float32(float(self._lsum.item()) / (H * W))))
+        poses = gh.pose_encoding_to_camera(host)
+        first_w2c = gh.inv4(poses[0])
+        prev = gh.pose_vec_to_matrix(kf.pose[a].numpy()[None])[0]
+        pm = torch.empty(V, H // ds, W // ds, 3, device=self.device)
+        cf = torch.empty(V, H // ds, W // ds, device=self.device)
+        dp = torch.empty(H, W, device=self.device)
+        out_poses = []
+        for i in range(V):
+            pose = gh.chain_pose(first_w2c, poses[i], prev[:3, :3], prev[:3, 3], align_s)
+            ops.align_view(pts[i], conf[i], pose[:3, :4].reshape(-1), float(align_s), ds, pm[i], cf[i], dp)
+            out_poses.append(gh.matrix_to_pose_vec(pose))
+        return pm, cf, np.stack(out_poses)
+
+    # ------------------------------------------------------------------ optimisation + rewrite
+    def _rewrite(self, sub0, sub1, T34, include_last=True):
+        """submaps sub0..sub1 <- T_b applied; poses of their keyframes likewise (track_backend.py:301-346)."""
+        kf = self.keyframes
+        B = sub1 - sub0 + 1
+        block = kf.submap_ds[sub0:sub1 + 1]
+        ops.transform_submaps(block, T34.reshape(B, 12).contiguous())
+        Th = T34.detach().cpu().numpy()
+        new = []
+        for b in range(B):
+            Ts = np.eye(4, dtype=np.float32)
+            Ts[:3, :4] = Th[b]
+            for n in range(5):
+                i = (sub0 + b) * 5 + n
+                c2w = gh.pose_vec_to_matrix(kf.pose[i].numpy()[None])[0]
+                p7 = gh.matrix_to_pose_vec(Ts @ c2w)
+                kf.set_pose(i, p7)
+                new.append(p7)
+        if include_last:
+            i = (sub1 + 1) * 5
+            Ts = np.eye(4, dtype=np.float32)
+            Ts[:3, :4] = Th[-1]
+            p7 = gh.matrix_to_pose_vec(Ts @ gh.pose_vec_to_matrix(kf.pose[i].numpy()[None])[0])
+            kf.set_pose(i, p7)
+            new.append(p7)
+        return np.stack(new)
+
+    def loop_closure_init(self, pointmap_current_lc, idx_matched, idx_current, return_loss=False):
+        kf = self.keyframes
+        sub0, sub1 = 0, idx_current // 5
+        block = kf.submap_ds[sub0:sub1 + 1]                                               # [B,6,h,w,3] view, resident
+        B = block.shape[0]
+        mask = (kf.conf_ds[sub0:sub1, 5] > 0).reshape(B - 1, -1) if B > 1 else None         # conf of each submap's last map
+        cur = kf.submap_ds[sub1, idx_current % 5]
+        res = ops.lc_optimize(block.contiguous(), mask, cur, pointmap_current_lc, self.loop_iters, 5e-4, return_loss)
+        xi, T = res[0], res[1]
+        se3 = SE3.exp(xi)
+        new_pose = self._rewrite(sub0, sub1, T)
+        updates = {"pose_updates": se3.data, "submap_idx": range(sub0, sub1 + 1),
+                   "camera_idx": range(sub0 * 5, (sub1 + 1) * 5 + 1), "camera_pose": torch.from_numpy(new_pose)}
+        if return_loss:
+            updates["loss"] = res[2]
+        return updates
+
+    def loop_closure(self, pointmaps_lc, idx_matched, idx_current):
+        """later loops (track_backend.py:361-524): adds the matched-submap terms; torch expressions over the HIP Lie
+        ops (cut3r_slam_amd.lietorch) with autograd -- not fused yet."""
+        kf, dev = self.keyframes, self.device
+        sub1 = idx_current // 5
+        block = kf.submap_ds[0:sub1 + 1]
+        B, N6, h, w, _ = block.shape
+        fl = torch.stack([block[:, 0], block[:, -1]], dim=1).reshape(B, 2, -1, 3)
+        prev_cur = np.array(self.closed_loop["idx_current"])
+        sub_cur_all = np.append(prev_cur // 5, sub1)
+        pm_cur = torch.cat([kf.submap_ds[prev_cur // 5, prev_cur % 5], kf.submap_ds[sub1, idx_current % 5][None]], 0)
+        lc_all = torch.cat([torch.stack(self.closed_loop["pointmaps_lc"], 0), pointmaps_lc[None]], 0).float()
+        lc_fl = torch.stack([lc_all[:, 0], lc_all[:, -1]], dim=1)
+        Bc = lc_all.shape[0]
+        sub_matched_all = np.append(np.array(self.closed_loop["idx_matched"]) // 5, idx_matched // 5)
+        with torch.enable_grad():
+            a_lie = torch.nn.Parameter(torch.zeros(B - 1, 6, device=dev))
+            m_lie = torch.nn.Parameter(torch.zeros(Bc, 6, device=dev))
+            opt = torch.optim.Adam([{"params": a_lie, "lr": 5e-4}, {"params": m_lie, "lr": 5e-4}])
+            lie0 = torch.zeros(1, 6, device=dev)
+            sc = torch.as_tensor(sub_cur_all, device=dev)
+            sm = torch.as_tensor(sub_matched_all, device=dev)
+            for _ in range(self.loop_iters):
+                opt.zero_grad()
+                T = SE3.exp(torch.cat([lie0, a_lie], 0)).matrix()
+                R, t = T[:, :3, :3], T[:, :3, 3].unsqueeze(1)
+                Tm = SE3.exp(m_lie).matrix()
+                Rm, tm = Tm[:, :3, :3], Tm[:, :3, 3].unsqueeze(1)
+                fla = torch.matmul(fl, R.transpose(1, 2).unsqueeze(1)) + t.unsqueeze(1)
+                lca = torch.matmul(lc_fl.reshape(Bc, 2, -1, 3), Rm.transpose(1, 2).unsqueeze(1)) + tm.unsqueeze(1)
+                cura = torch.matmul(pm_cur.reshape(Bc, -1, 3), R[sc].transpose(1, 2)) + t[sc]
+                loss = (fla[:-1, -1] - fla[1:, 0]).abs().mean() + (lca[:, 0] - fla[sm, 0]).abs().mean() + \
+                    (cura - lca[:, -1]).abs().mean()
+                loss.backward()
+                opt.step()
+        with torch.no_grad():
+            se3 = SE3.exp(torch.cat([lie0, a_lie.detach()], 0))
+            T = se3.matrix()[:, :3, :4].contiguous()
+            Tm = SE3.exp(m_lie.detach()).matrix()
+            new_pose = self._rewrite(0, sub1, T)
+            lc_al = torch.matmul(lc_all.reshape(Bc, N6, -1, 3), Tm[:, :3, :3].transpose(1, 2).unsqueeze(1)) + Tm[:, :3, 3].reshape(Bc, 1, 1, 3)
+            lc_al = lc_al.reshape(Bc, N6, h, w, 3)
+            for i in range(Bc - 1):
+                self.closed_loop["pointmaps_lc"][i] = lc_al[i]
+        updates = {"pose_updates": se3.data, "submap_idx": range(0, sub1 + 1), "camera_idx": range(0, (sub1 + 1) * 5 + 1),
+                   "camera_pose": torch.from_numpy(new_pose)}
+        return lc_al[-1], updates
+
+    # ------------------------------------------------------------------ entry point (track_backend.py:527-586)
+    def run(self):
+        kf = self.keyframes
+        intr = kf.intrinsic[0].numpy() / self.downsample_ratio
+        K4 = [float(intr[0]), float(intr[1]), float(intr[2]), float(intr[3])]
+        t1 = kf.counter.value - 1
+        t0 = t1 - 6
+        ids_matched, idx_current = None, None
+        for idx_current in range(t0, t1 - 1):
+            ids_matched = self.graph.detect_loop(idx_current, small_loop_candidates=False)
+            if ids_matched is not None:
+                break
+        if ids_matched is None:
+            return False, None
+        k_th = self.nms(ids_matched, idx_current, K4)
+        if k_th is None:
+            return False, None
+        idx_matched = int(ids_matched[k_th])
+        anchor = idx_matched // 5
+        selected = list(range(anchor * 5, (anchor + 1) * 5)) + [idx_current]
+        pm_lc, conf_lc, poses_lc = self.track(selected, anchor)
+        if not self.lc_initialized:
+            updates = self.loop_closure_init(pm_lc[-1], idx_matched, idx_current)
+            self.lc_initialized = True
+            stored = pm_lc
+        else:
+            stored, updates = self.loop_closure(pm_lc, idx_matched, idx_current)
+            stored = pm_lc if stored.dim() == 3 else stored
+        self.closed_loop["idx_current"].append(idx_current)
+        self.closed_loop["idx_matched"].append(idx_matched)
+        self.closed_loop["pointmaps_lc"].append(pm_lc)
+        return True, updates

@@ -113,7 +113,8 @@ int cut3r_patch_overlap(const float* feat0, const float* feat1, int N, int C, fl
  *      pms + slot(b)*N*3 with slot(b) = b when grp == 0, else (b/grp)*grp_stride + b%grp -- the keyframe order of the
  *      [submap][6 slots] store (hislam2/keyframe.py:28, track_frontend.py:251-255) without gathering a copy. */
 int cut3r_overlap_fwd(const float* pm, int N, const float* P_host, float s_align, const float* w2c, int B, float fx, float fy,
-                      float cx, float cy, int W, int H, int32_t* counts, void* stream);
+                      float cx, float cy, int W, int H, int clamp_z /* 1: cal_overlap_batch, 0: cal_overlap_bi with B1 == 1 */,
+                      int32_t* counts, void* stream);
 int cut3r_overlap_bwd(const float* pms, int B, int N, int grp, int grp_stride, const float* w2c, float fx, float fy, float cx,
                       float cy, int W, int H, int32_t* counts, void* stream);
 
@@ -143,6 +144,21 @@ int cut3r_lie_act_bwd(int group, const float* x, const float* p, const float* gr
                       int pd, void* stream);
 /* adjoint (transpose = 0) or transposed adjoint (1) of element e applied to tangent vector a[e] */
 int cut3r_lie_adj(int group, const float* x, const float* a, float* out, int n, int transpose, void* stream);
+
+/* ---- loop closure: fused submap-alignment optimiser -----------------------------------------------------------------
+ * replaces the Adam loop over SE3.exp(xi).matrix() of TrackBackend.loop_closure_init
+ * (hislam2/track_backend.py:256-299; lr 5e-4, `iteration` steps) and the pointmap rewrite (:301-310).
+ * first/last: device pointers to slot 0 / slot 5 of the [B][6][N][3] submap store (sub_stride = floats between
+ * consecutive submaps); mask: uint8 [B-1,N] (conf of `last` > 0) or NULL; cur/cur_lc: [N,3] current pointmap in the
+ * global frame / in the matched submap's frame.  xi,adam_m,adam_v: [B,6] (row 0 unused, zero-initialised by the caller),
+ * T: [B,12] row-major 3x4 (identity-initialised); workspace: cut3r_lc_workspace_floats(B,N) floats; loss_out: NULL or
+ * float[iters].  Two launches per iteration, deterministic (no float atomics). */
+int cut3r_lc_workspace_floats(int B, int N);
+int cut3r_lc_optimize(const float* first, const float* last, long long sub_stride, const unsigned char* mask, const float* cur,
+                      const float* cur_lc, int B, int N, long long n_masked, int iters, float lr, float* xi, float* adam_m,
+                      float* adam_v, float* T, float* workspace, float* loss_out, void* stream);
+/* in place p <- T_b p for the points_per_submap points of each of the B submaps (pts: [B, points_per_submap, 3]) */
+int cut3r_transform_submaps(float* pts, const float* T, int B, long long points_per_submap, void* stream);
 
 #ifdef __cplusplus
 }

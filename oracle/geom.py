@@ -51,12 +51,12 @@ def w2c_rows(c2w):
     return np.ascontiguousarray(inv[:, :3, :].reshape(-1, 12), dtype=np.float32)
 
 
-def overlap_fwd(pm, w2c12, K4, W, H):
+def overlap_fwd(pm, w2c12, K4, W, H, clamp_z=True):
     pm = _f(pm).reshape(-1, 3)
     w = _f(w2c12).reshape(-1, 12)
     k = _f(K4)
     out = np.zeros(w.shape[0], np.int32)
-    lib().oracle_overlap_fwd(_ptr(pm), pm.shape[0], _ptr(w), w.shape[0], _ptr(k), int(W), int(H), _ptr(out, C.c_int32))
+    lib().oracle_overlap_fwd_ex(_ptr(pm), pm.shape[0], _ptr(w), w.shape[0], _ptr(k), int(W), int(H), int(clamp_z), _ptr(out, C.c_int32))
     return out
 
 

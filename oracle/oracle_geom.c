@@ -47,13 +47,23 @@ static inline int proj_valid(const float *w2c, float x, float y, float z, float 
     return (u >= 0.0f) && (u < (float)W) && (v >= 0.0f) && (v < (float)H) && (zc > 0.0f);
 }
 
+void oracle_overlap_fwd_ex(const float *pm, int N, const float *w2c, int B, const float *K4, int W, int H, int clamp_z,
+                           int32_t *counts);
+
 /* cal_overlap_batch (factor_graph.py:255-282): project ONE pointmap [N,3] into B cameras; counts[b] = #valid. */
 void oracle_overlap_fwd(const float *pm, int N, const float *w2c, int B, const float *K4, int W, int H,
                         int32_t *counts) {
+    oracle_overlap_fwd_ex(pm, N, w2c, B, K4, W, H, 1, counts);
+}
+
+/* same, with the divide convention selectable: clamp_z = 0 is cal_overlap_bi called with ONE pointmap and B cameras
+ * (factor_graph.py:567 in NMS) */
+void oracle_overlap_fwd_ex(const float *pm, int N, const float *w2c, int B, const float *K4, int W, int H, int clamp_z,
+                           int32_t *counts) {
     for (int b = 0; b < B; b++) {
         int c = 0;
         for (int n = 0; n < N; n++)
-            c += proj_valid(w2c + 12 * b, pm[3 * n], pm[3 * n + 1], pm[3 * n + 2], K4[0], K4[1], K4[2], K4[3], W, H, 1);
+            c += proj_valid(w2c + 12 * b, pm[3 * n], pm[3 * n + 1], pm[3 * n + 2], K4[0], K4[1], K4[2], K4[3], W, H, clamp_z);
         counts[b] = c;
     }
 }

@@ -22,6 +22,7 @@ def test_library_loads_and_exports_every_symbol():
     for name in _declared():
         assert hasattr(lib, name), name
     assert lib.cut3r_abi_version() >= 1
+    assert lib.cut3r_lc_workspace_floats(3, 5000) == 3 * 3 * 28
 
 
 def test_bad_arguments_are_rejected_without_launching():
