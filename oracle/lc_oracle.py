@@ -36,6 +36,6 @@ def loop_closure_init(submaps, mask, cur, cur_lc, iters, lr=5e-4, dtype=torch.fl
         loss = l_fl + l_cur
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     xi = torch.cat([lie0, p.detach()], 0)
     return xi, torch.matrix_exp(twist(xi)), losses

