@@ -67,7 +67,12 @@ SIGNATURES = {
     "cut3r_lc_optimize": [c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_float,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "cut3r_transform_submaps": [c_void_p, c_void_p, c_int, c_ll, c_void_p],
+    "cut3r_corr_index_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "cut3r_corr_index_backward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "cut3r_ba_workspace_floats": [c_int, c_int, c_int, c_int, c_int, c_int],
+    "cut3r_ba_step": [c_void_p] * 12 + [c_int] * 6 + [c_float, c_float] + [c_void_p] * 5,
 }
+RESTYPES = {"cut3r_ba_workspace_floats": c_ll}
 
 _lib = None
 
@@ -88,7 +93,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the export is missing
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = RESTYPES.get(name, c_int)
     _lib = lib
     return lib
 

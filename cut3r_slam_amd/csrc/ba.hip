@@ -1,0 +1,430 @@
+// Dense bundle adjustment operators (row A13 of SURVEY.md section 8) on gfx950 -- the DROID-style stack that the
+// reference keeps only as dead Python (/root/reference/hislam2/geom/{projective_ops,pinhole,ba,chol}.py,
+// /root/reference/hislam2/modules/corr.py) on top of the absent `droid_backends` CUDA sources.
+//
+//   corr_index fwd/bwd   bilinear lookup of a (2r+1)^2 window in an all-pairs correlation volume  (corr.py:6-21)
+//   ba_edge              per source frame: reprojection residuals, 2x6 pose Jacobians (via the transposed adjoint of
+//                        G_ij), depth Jacobian; emits the 6x6 Hessian blocks / gradient as per-block partials and the
+//                        E rows, C, w per pixel  (projective_ops.py:44-74, ba.py:43-74)
+//   ba_reduce_H          fixed-order sum of the partials into H [P,P,6,6], v [P,6]
+//   ba_schur             S = H + damping - E Q E^T,  v' = v - E Q w          (chol.py:47-65)
+//   ba_chol_solve        in-LDS Cholesky + two triangular solves (n = 6P <= 192), failure => dx = 0 (chol.py:9-18)
+//   ba_dz                dz = Q (w - E^T dx)                                 (chol.py:71)
+// All reductions are deterministic (no float atomics): every (source frame, pixel) is owned by one thread that walks
+// that frame's edges in order, block partials are summed in fixed order.
+#include "common.h"
+#include "lie_math.h"
+#include "../../include/cut3r_hip.h"
+
+namespace {
+using namespace liemath;
+
+// ------------------------------------------------------------------------------------------------ correlation lookup
+// volume [BN,h1,w1,h2,w2], coords [BN,2,h1,w1] (x,y), out [BN,rd,rd,h1,w1] with out[n,i,j,y,x] = bilinear(volume[n,y,x],
+// x0 - r + i, y0 - r + j), zero outside (upstream DROID-SLAM correlation_kernels.cu semantics; i = x offset, j = y offset).
+__global__ __launch_bounds__(256) void corr_index_fwd_kernel(const float* __restrict__ vol, const float* __restrict__ coords,
+                                                             float* __restrict__ out, int BN, int h1, int w1, int h2, int w2, int r) {
+    const int rd = 2 * r + 1;
+    const size_t total = (size_t)BN * h1 * w1;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(p % w1);
+        const int y = (int)((p / w1) % h1);
+        const int n = (int)(p / ((size_t)w1 * h1));
+        const float x0 = coords[(((size_t)n * 2 + 0) * h1 + y) * w1 + x];
+        const float y0 = coords[(((size_t)n * 2 + 1) * h1 + y) * w1 + x];
+        const float fx = floorf(x0), fy = floorf(y0);
+        const float dx = x0 - fx, dy = y0 - fy;
+        const float* v = vol + p * (size_t)h2 * w2;
+        for (int i = 0; i < rd; i++)
+            for (int j = 0; j < rd; j++) {
+                const int xa = (int)fx - r + i, ya = (int)fy - r + j;
+                float s = 0.f;
+#pragma unroll
+                for (int oy = 0; oy < 2; oy++)
+#pragma unroll
+                    for (int ox = 0; ox < 2; ox++) {
+                        const int xx = xa + ox, yy = ya + oy;
+                        if (xx >= 0 && xx < w2 && yy >= 0 && yy < h2)
+                            s += v[(size_t)yy * w2 + xx] * (ox ? dx : 1.f - dx) * (oy ? dy : 1.f - dy);
+                    }
+                out[((((size_t)n * rd + i) * rd + j) * h1 + y) * w1 + x] = s;
+            }
+    }
+}
+
+// each (n,y,x) owns its own h2 x w2 slice of grad_volume -> no races, plain read-modify-write
+__global__ __launch_bounds__(256) void corr_index_bwd_kernel(const float* __restrict__ coords, const float* __restrict__ gout,
+                                                             float* __restrict__ gvol, int BN, int h1, int w1, int h2, int w2, int r) {
+    const int rd = 2 * r + 1;
+    const size_t total = (size_t)BN * h1 * w1;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(p % w1);
+        const int y = (int)((p / w1) % h1);
+        const int n = (int)(p / ((size_t)w1 * h1));
+        const float x0 = coords[(((size_t)n * 2 + 0) * h1 + y) * w1 + x];
+        const float y0 = coords[(((size_t)n * 2 + 1) * h1 + y) * w1 + x];
+        const float fx = floorf(x0), fy = floorf(y0);
+        const float dx = x0 - fx, dy = y0 - fy;
+        float* v = gvol + p * (size_t)h2 * w2;
+        for (int i = 0; i < rd; i++)
+            for (int j = 0; j < rd; j++) {
+                const float g = gout[((((size_t)n * rd + i) * rd + j) * h1 + y) * w1 + x];
+                const int xa = (int)fx - r + i, ya = (int)fy - r + j;
+#pragma unroll
+                for (int oy = 0; oy < 2; oy++)
+#pragma unroll
+                    for (int ox = 0; ox < 2; ox++) {
+                        const int xx = xa + ox, yy = ya + oy;
+                        if (xx >= 0 && xx < w2 && yy >= 0 && yy < h2)
+                            v[(size_t)yy * w2 + xx] += g * (ox ? dx : 1.f - dx) * (oy ? dy : 1.f - dy);
+                    }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BA: per-edge assembly
+constexpr int BA_BLOCK = 256;
+constexpr int BA_HROW = 120;        // Hii(36) Hij(36) Hjj(36) vi(6) vj(6)   (Hji = Hij^T)
+
+struct BaGeom {
+    int P, ht, wd, N, M, fixedp;
+};
+
+// poses [P,7] (world->camera, t q_xyzw), Gij [N,7] = G_j * G_i^-1, disps [P,HW], intr [P,4], target/weight [N,HW,2]
+// CSR over source frames: src_ptr [M+1], src_edges [*] (edge ids), kx [M] (frame id of source m)
+__global__ __launch_bounds__(BA_BLOCK) void ba_edge_kernel(const float* __restrict__ Gij, const float* __restrict__ disps,
+                                                           const float* __restrict__ intr, const float* __restrict__ target,
+                                                           const float* __restrict__ weight, const int* __restrict__ ii,
+                                                           const int* __restrict__ jj, const int* __restrict__ src_ptr,
+                                                           const int* __restrict__ src_edges, const int* __restrict__ kx, BaGeom g,
+                                                           float* __restrict__ Hpart, float* __restrict__ E, float* __restrict__ Cm,
+                                                           float* __restrict__ wm, const float* __restrict__ eta) {
+    __shared__ float red[4][BA_HROW];
+    const int m = blockIdx.y;
+    const int HW = g.ht * g.wd;
+    const int k = blockIdx.x * BA_BLOCK + threadIdx.x;
+    const bool ok = k < HW;
+    const int i = kx[m];
+    const int Pf = g.P - g.fixedp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = ok ? k % g.wd : 0, py = ok ? k / g.wd : 0;
+    const float fxi = intr[i * 4 + 0], fyi = intr[i * 4 + 1], cxi = intr[i * 4 + 2], cyi = intr[i * 4 + 3];
+    const float d0 = ok ? disps[(size_t)i * HW + k] : 1.f;
+    const float X0x = ((float)px - cxi) / fxi, X0y = ((float)py - cyi) / fyi;
+    float Ei_sum[6] = {0, 0, 0, 0, 0, 0};
+    float Csum = 0.f, wsum = 0.f;
+    const int ip = i - g.fixedp;
+    for (int s = src_ptr[m]; s < src_ptr[m + 1]; s++) {
+        const int e = src_edges[s];
+        const int j = jj[e];
+        const int jp = j - g.fixedp;
+        const float* G = Gij + (size_t)e * 7;
+        const V3<float> t = {G[0], G[1], G[2]};
+        const Q4<float> q = {G[3], G[4], G[5], G[6]};
+        const Q4<float> qi = qconj(q);
+        const float fxj = intr[j * 4 + 0], fyj = intr[j * 4 + 1], cxj = intr[j * 4 + 2], cyj = intr[j * 4 + 3];
+        // X1 = G_ij * [X0, 1, d]
+        const V3<float> RX = qrot(q, V3<float>{X0x, X0y, 1.f});
+        const float X = RX.x + t.x * d0, Y = RX.y + t.y * d0, Z = RX.z + t.z * d0;
+        const float Zc = (Z < 0.1f) ? 1.f : Z;
+        const float dz = 1.0f / Zc;
+        const float u = fxj * (X * dz) + cxj, v = fyj * (Y * dz) + cyj;
+        const float valid = (ok && Z > 0.2f) ? 1.f : 0.f;          // X0.z == 1 > MIN_DEPTH always
+        float r[2], w[2];
+        if (ok) {
+            r[0] = target[((size_t)e * HW + k) * 2 + 0] - u;
+            r[1] = target[((size_t)e * HW + k) * 2 + 1] - v;
+            w[0] = 0.001f * valid * weight[((size_t)e * HW + k) * 2 + 0];
+            w[1] = 0.001f * valid * weight[((size_t)e * HW + k) * 2 + 1];
+        } else { r[0] = r[1] = w[0] = w[1] = 0.f; }
+        // Jp rows (2x3 part), Ja = [d I, -[X1]x]  (actp for SE3)
+        const float jp0[3] = {fxj * dz, 0.f, -fxj * X * dz * dz};
+        const float jp1[3] = {0.f, fyj * dz, -fyj * Y * dz * dz};
+        float Jj[2][6], Ji[2][6], Jz[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float* a = c ? jp1 : jp0;
+            Jj[c][0] = a[0] * d0; Jj[c][1] = a[1] * d0; Jj[c][2] = a[2] * d0;
+            // a^T * (-[X1]x) : columns 3..5 of Ja are (0,Z,-Y),(-Z,0,X),(Y,-X,0) as column vectors of rows
+            Jj[c][3] = -a[1] * Z + a[2] * Y;
+            Jj[c][4] = a[0] * Z - a[2] * X;
+            Jj[c][5] = -a[0] * Y + a[1] * X;
+            // Ji = -adjT_{Gij}(Jj):  [R^T tau ; R^T phi - R^T (t x tau)]
+            const V3<float> tau = {Jj[c][0], Jj[c][1], Jj[c][2]}, phi = {Jj[c][3], Jj[c][4], Jj[c][5]};
+            const V3<float> a_tau = qrot(qi, tau);
+            const V3<float> a_phi = add(qrot(qi, phi), scale(-1.f, qrot(qi, cross(t, tau))));
+            Ji[c][0] = -a_tau.x; Ji[c][1] = -a_tau.y; Ji[c][2] = -a_tau.z;
+            Ji[c][3] = -a_phi.x; Ji[c][4] = -a_phi.y; Ji[c][5] = -a_phi.z;
+            Jz[c] = a[0] * t.x + a[1] * t.y + a[2] * t.z;
+        }
+        // per-pixel depth terms
+        float Ej[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            Ei_sum[a] += w[0] * Ji[0][a] * Jz[0] + w[1] * Ji[1][a] * Jz[1];
+            Ej[a] = w[0] * Jj[0][a] * Jz[0] + w[1] * Jj[1][a] * Jz[1];
+        }
+        Csum += w[0] * Jz[0] * Jz[0] + w[1] * Jz[1] * Jz[1];
+        wsum += w[0] * r[0] * Jz[0] + w[1] * r[1] * Jz[1];
+        if (ok && jp >= 0) {
+            float* Eb = E + (((size_t)jp * g.M + m) * 6) * HW + k;
+#pragma unroll
+            for (int a = 0; a < 6; a++) Eb[(size_t)a * HW] += Ej[a];        // same thread owns (m,k): ordered, race-free
+        }
+        // 6x6 blocks + gradients, reduced over the block's pixels
+        float loc[BA_HROW];
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                loc[a * 6 + b] = w[0] * Ji[0][a] * Ji[0][b] + w[1] * Ji[1][a] * Ji[1][b];
+                loc[36 + a * 6 + b] = w[0] * Ji[0][a] * Jj[0][b] + w[1] * Ji[1][a] * Jj[1][b];
+                loc[72 + a * 6 + b] = w[0] * Jj[0][a] * Jj[0][b] + w[1] * Jj[1][a] * Jj[1][b];
+            }
+            loc[108 + a] = w[0] * Ji[0][a] * r[0] + w[1] * Ji[1][a] * r[1];
+            loc[114 + a] = w[0] * Jj[0][a] * r[0] + w[1] * Jj[1][a] * r[1];
+        }
+#pragma unroll
+        for (int c = 0; c < BA_HROW; c++) {
+            const float sv = wave_sum(loc[c]);
+            if (lane == 0) red[wave][c] = sv;
+        }
+        __syncthreads();
+        if (threadIdx.x < BA_HROW)
+            Hpart[((size_t)e * gridDim.x + blockIdx.x) * BA_HROW + threadIdx.x] =
+                red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        __syncthreads();
+    }
+    if (ok) {
+        if (ip >= 0) {
+            float* Eb = E + (((size_t)ip * g.M + m) * 6) * HW + k;
+#pragma unroll
+            for (int a = 0; a < 6; a++) Eb[(size_t)a * HW] += Ei_sum[a];
+        }
+        Cm[(size_t)m * HW + k] = Csum + eta[(size_t)m * HW + k] + 1e-7f;
+        wm[(size_t)m * HW + k] = wsum;
+    }
+    (void)Pf;
+}
+
+// H [Pf,Pf,6,6], v [Pf,6] (zeroed by the launcher): one thread per (edge-independent) output element, edges in order
+__global__ void ba_reduce_H_kernel(const float* __restrict__ Hpart, int nblk, const int* __restrict__ ii, const int* __restrict__ jj,
+                                   int N, int Pf, int fixedp, float* __restrict__ H, float* __restrict__ v) {
+    // block = one (p,q) pair [or the gradient row when q == Pf]; thread = one of the 36 (or 6) entries
+    const int p = blockIdx.x, q = blockIdx.y, tix = threadIdx.x;
+    if (q < Pf) {
+        if (tix >= 36) return;
+        const int a = tix / 6, b = tix % 6;
+        float s = 0.f;
+        for (int e = 0; e < N; e++) {
+            const int i = ii[e] - fixedp, j = jj[e] - fixedp;
+            const float* row = Hpart + (size_t)e * nblk * BA_HROW;
+            float c = 0.f;
+            bool hit = false;
+            if (i == p && i == q && i >= 0) { for (int k = 0; k < nblk; k++) c += row[k * BA_HROW + a * 6 + b]; hit = true; }
+            if (i == p && j == q && i >= 0 && j >= 0) { for (int k = 0; k < nblk; k++) c += row[k * BA_HROW + 36 + a * 6 + b]; hit = true; }
+            if (j == p && i == q && i >= 0 && j >= 0) { for (int k = 0; k < nblk; k++) c += row[k * BA_HROW + 36 + b * 6 + a]; hit = true; }
+            if (j == p && j == q && j >= 0) { for (int k = 0; k < nblk; k++) c += row[k * BA_HROW + 72 + a * 6 + b]; hit = true; }
+            if (hit) s += c;
+        }
+        H[(((size_t)p * Pf + q) * 6 + a) * 6 + b] = s;
+    } else {
+        if (tix >= 6) return;
+        float s = 0.f;
+        for (int e = 0; e < N; e++) {
+            const int i = ii[e] - fixedp, j = jj[e] - fixedp;
+            const float* row = Hpart + (size_t)e * nblk * BA_HROW;
+            if (i == p) for (int k = 0; k < nblk; k++) s += row[k * BA_HROW + 108 + tix];
+            if (j == p) for (int k = 0; k < nblk; k++) s += row[k * BA_HROW + 114 + tix];
+        }
+        v[(size_t)p * 6 + tix] = s;
+    }
+}
+
+// S[(p,a),(q,b)] = Hd[(p,a),(q,b)] - sum_m sum_k E[p,m,a,k] E[q,m,b,k] / C[m,k];  vS[(p,a)] = v - sum E w / C
+// one block per (p,q); 36 (+6 when q == p) reductions over M*HW pixels.
+__global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__ H, const float* __restrict__ v,
+                                                       const float* __restrict__ E, const float* __restrict__ Cm,
+                                                       const float* __restrict__ wm, const unsigned char* __restrict__ present,
+                                                       int Pf, int M, int HW, float ep, float lm, float* __restrict__ S,
+                                                       float* __restrict__ vS) {
+    __shared__ float red[4][42];
+    const int p = blockIdx.x, q = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[42];
+#pragma unroll
+    for (int c = 0; c < 42; c++) acc[c] = 0.f;
+    for (int m = 0; m < M; m++) {
+        if (!present[p * M + m] || !present[q * M + m]) continue;
+        const float* Ep = E + (((size_t)p * M + m) * 6) * HW;
+        const float* Eq = E + (((size_t)q * M + m) * 6) * HW;
+        for (int k = threadIdx.x; k < HW; k += 256) {
+            const float Q = 1.0f / Cm[(size_t)m * HW + k];
+            float ea[6], eb[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) { ea[a] = Ep[(size_t)a * HW + k]; eb[a] = Eq[(size_t)a * HW + k] * Q; }
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = 0; b < 6; b++) acc[a * 6 + b] += ea[a] * eb[b];
+            if (p == q) {
+                const float wq = wm[(size_t)m * HW + k] * Q;
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[36 + a] += ea[a] * wq;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 42; c++) {
+        const float sv = wave_sum(acc[c]);
+        if (lane == 0) red[wave][c] = sv;
+    }
+    __syncthreads();
+    const int n = Pf * 6;
+    if (threadIdx.x < 36) {
+        const int a = threadIdx.x / 6, b = threadIdx.x % 6;
+        float h = H[(((size_t)p * Pf + q) * 6 + a) * 6 + b];
+        if (p == q && a == b) h = h + (ep + lm * h);                       // H + (ep + lm*H) * I   (chol.py:56-57)
+        S[(size_t)(p * 6 + a) * n + (q * 6 + b)] = h - (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    } else if (threadIdx.x < 42 && p == q) {
+        const int a = threadIdx.x - 36;
+        vS[p * 6 + a] = v[p * 6 + a] - (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+}
+
+// in-LDS Cholesky (lower) of S [n,n] (n <= 192) and solve S x = b.  flag[0] = 1 on a non-positive pivot (x = 0).
+constexpr int CHOL_MAXN = 192;
+__global__ __launch_bounds__(256) void ba_chol_solve_kernel(const float* __restrict__ S, const float* __restrict__ b, int n,
+                                                            float* __restrict__ x, float* __restrict__ Lout, int* __restrict__ flag) {
+    extern __shared__ float sm[];
+    float* A = sm;                 // n*n
+    float* y = sm + n * n;         // n
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int i = tid; i < n * n; i += 256) A[i] = S[i];
+    for (int i = tid; i < n; i += 256) y[i] = b[i];
+    __syncthreads();
+    for (int k = 0; k < n; k++) {
+        if (tid == 0) {
+            const float d = A[k * n + k];
+            if (!(d > 0.f)) bad = 1;
+            A[k * n + k] = sqrtf(d > 0.f ? d : 1.f);
+        }
+        __syncthreads();
+        const float dk = A[k * n + k];
+        for (int i = k + 1 + tid; i < n; i += 256) A[i * n + k] /= dk;
+        __syncthreads();
+        const int rem = n - k - 1;
+        for (int idx = tid; idx < rem * rem; idx += 256) {
+            const int i = k + 1 + idx / rem, j = k + 1 + idx % rem;
+            if (j <= i) A[i * n + j] -= A[i * n + k] * A[j * n + k];
+        }
+        __syncthreads();
+    }
+    // forward: L y = b
+    for (int k = 0; k < n; k++) {
+        if (tid == 0) y[k] /= A[k * n + k];
+        __syncthreads();
+        const float yk = y[k];
+        for (int i = k + 1 + tid; i < n; i += 256) y[i] -= A[i * n + k] * yk;
+        __syncthreads();
+    }
+    // backward: L^T x = y
+    for (int k = n - 1; k >= 0; k--) {
+        if (tid == 0) y[k] /= A[k * n + k];
+        __syncthreads();
+        const float xk = y[k];
+        for (int i = tid; i < k; i += 256) y[i] -= A[k * n + i] * xk;
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) x[i] = bad ? 0.f : y[i];
+    if (Lout)
+        for (int i = tid; i < n * n; i += 256) { const int r = i / n, c = i % n; Lout[i] = (c <= r) ? A[i] : 0.f; }
+    if (tid == 0) flag[0] = bad;
+}
+
+// dz[m,k] = (w - sum_p E[p,m,:,k] . dx[p]) / C
+__global__ __launch_bounds__(256) void ba_dz_kernel(const float* __restrict__ E, const float* __restrict__ Cm, const float* __restrict__ wm,
+                                                    const float* __restrict__ dx, const unsigned char* __restrict__ present, int Pf,
+                                                    int M, int HW, float* __restrict__ dz) {
+    const int m = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= HW) return;
+    float s = wm[(size_t)m * HW + k];
+    for (int p = 0; p < Pf; p++) {
+        if (!present[p * M + m]) continue;
+        const float* Ep = E + (((size_t)p * M + m) * 6) * HW + k;
+#pragma unroll
+        for (int a = 0; a < 6; a++) s -= Ep[(size_t)a * HW] * dx[p * 6 + a];
+    }
+    dz[(size_t)m * HW + k] = s / Cm[(size_t)m * HW + k];
+}
+
+inline int grid_for(size_t total, int block = 256) {
+    size_t gsz = (total + block - 1) / block;
+    if (gsz > 8192) gsz = 8192;
+    if (gsz < 1) gsz = 1;
+    return (int)gsz;
+}
+
+}  // namespace
+
+extern "C" int cut3r_corr_index_forward(const float* volume, const float* coords, float* out, int BN, int h1, int w1, int h2, int w2,
+                                        int radius, void* stream) {
+    if (!volume || !coords || !out || BN <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || radius < 0) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(corr_index_fwd_kernel, dim3(grid_for((size_t)BN * h1 * w1)), dim3(256), 0, (hipStream_t)stream, volume, coords, out,
+                       BN, h1, w1, h2, w2, radius);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_corr_index_backward(const float* coords, const float* grad_out, float* grad_volume, int BN, int h1, int w1, int h2,
+                                         int w2, int radius, void* stream) {
+    if (!coords || !grad_out || !grad_volume || BN <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || radius < 0) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(grad_volume, 0, sizeof(float) * (size_t)BN * h1 * w1 * h2 * w2, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    hipLaunchKernelGGL(corr_index_bwd_kernel, dim3(grid_for((size_t)BN * h1 * w1)), dim3(256), 0, s, coords, grad_out, grad_volume, BN,
+                       h1, w1, h2, w2, radius);
+    return cut3r_check_launch();
+}
+
+extern "C" long long cut3r_ba_workspace_floats(int P, int ht, int wd, int N, int M, int fixedp) {
+    const long long HW = (long long)ht * wd, Pf = P - fixedp, nblk = (HW + BA_BLOCK - 1) / BA_BLOCK, n = Pf * 6;
+    //      Hpart                      E                 C, w, dz     H            v    S      vS  L
+    return (long long)N * nblk * BA_HROW + Pf * M * 6 * HW + 3 * M * HW + Pf * Pf * 36 + Pf * 6 + n * n + n + n * n + 64;
+}
+
+extern "C" int cut3r_ba_step(const float* Gij, const float* disps, const float* intr, const float* target, const float* weight,
+                             const float* eta, const int* ii, const int* jj, const int* src_ptr, const int* src_edges, const int* kx,
+                             const unsigned char* present, int P, int ht, int wd, int N, int M, int fixedp, float ep, float lm,
+                             float* workspace, float* dx, float* dz, int* flag, void* stream) {
+    if (!Gij || !disps || !intr || !target || !weight || !eta || !ii || !jj || !src_ptr || !src_edges || !kx || !present || !workspace ||
+        !dx || !dz || !flag)
+        return CUT3R_ERR_ARG;
+    const int Pf = P - fixedp;
+    if (P <= 0 || Pf <= 0 || ht <= 0 || wd <= 0 || N <= 0 || M <= 0 || fixedp < 0 || Pf * 6 > CHOL_MAXN) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long long HW = (long long)ht * wd;
+    const int nblk = (int)((HW + BA_BLOCK - 1) / BA_BLOCK), n = Pf * 6;
+    float* Hpart = workspace;
+    float* E = Hpart + (size_t)N * nblk * BA_HROW;
+    float* Cm = E + (size_t)Pf * M * 6 * HW;
+    float* wm = Cm + (size_t)M * HW;
+    float* H = wm + (size_t)M * HW + (size_t)M * HW;     // (third M*HW slot reserved)
+    float* v = H + (size_t)Pf * Pf * 36;
+    float* S = v + (size_t)Pf * 6;
+    float* vS = S + (size_t)n * n;
+    float* L = vS + n;
+    if (hipMemsetAsync(E, 0, sizeof(float) * (size_t)Pf * M * 6 * HW, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    BaGeom g{P, ht, wd, N, M, fixedp};
+    hipLaunchKernelGGL(ba_edge_kernel, dim3(nblk, M), dim3(BA_BLOCK), 0, s, Gij, disps, intr, target, weight, ii, jj, src_ptr, src_edges,
+                       kx, g, Hpart, E, Cm, wm, eta);
+    hipLaunchKernelGGL(ba_reduce_H_kernel, dim3(Pf, Pf + 1), dim3(64), 0, s, Hpart, nblk, ii, jj, N, Pf, fixedp, H, v);
+    hipLaunchKernelGGL(ba_schur_kernel, dim3(Pf, Pf), dim3(256), 0, s, H, v, E, Cm, wm, present, Pf, M, (int)HW, ep, lm, S, vS);
+    const size_t chol_lds = sizeof(float) * ((size_t)n * n + n);
+    if (hipFuncSetAttribute((const void*)ba_chol_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds) != hipSuccess)
+        return CUT3R_ERR_LAUNCH;
+    hipLaunchKernelGGL(ba_chol_solve_kernel, dim3(1), dim3(256), chol_lds, s, S, vS, n, dx, L, flag);
+    hipLaunchKernelGGL(ba_dz_kernel, dim3(nblk, M), dim3(256), 0, s, E, Cm, wm, dx, present, Pf, M, (int)HW, dz);
+    return cut3r_check_launch();
+}

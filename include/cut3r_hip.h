@@ -160,6 +160,25 @@ int cut3r_lc_optimize(const float* first, const float* last, long long sub_strid
 /* in place p <- T_b p for the points_per_submap points of each of the B submaps (pts: [B, points_per_submap, 3]) */
 int cut3r_transform_submaps(float* pts, const float* T, int B, long long points_per_submap, void* stream);
 
+/* ---- legacy dense-BA operators (`droid_backends` sources are absent from the reference) --------------
+ * corr_index: replaces droid_backends.corr_index_forward/backward (call sites hislam2/modules/corr.py:12,19).
+ * volume [BN,h1,w1,h2,w2], coords [BN,2,h1,w1] (x,y), out [BN,2r+1,2r+1,h1,w1]: bilinear lookup with zero padding,
+ * out[n,i,j,y,x] = volume[n,y,x] sampled at (x0 - r + i, y0 - r + j). */
+int cut3r_corr_index_forward(const float* volume, const float* coords, float* out, int BN, int h1, int w1, int h2, int w2,
+                             int radius, void* stream);
+int cut3r_corr_index_backward(const float* coords, const float* grad_out, float* grad_volume, int BN, int h1, int w1, int h2, int w2,
+                              int radius, void* stream);
+/* one Gauss-Newton step of geom.ba.BA (hislam2/geom/ba.py:32-107, geom/chol.py:47-78, geom/projective_ops.py:44-74):
+ * Gij [N,7] = G_j*G_i^-1 (SE3 data), disps [P,ht*wd], intr [P,4], target/weight [N,ht*wd,2], eta [M,ht*wd];
+ * ii,jj int32 [N]; CSR of edges by source frame (src_ptr [M+1], src_edges [N], kx [M] = sorted unique(ii));
+ * present uint8 [P-fixedp, M] marks the non-zero E blocks.  Outputs dx [P-fixedp,6], dz [M,ht*wd], flag[0] = 1 if
+ * the Cholesky failed (dx = 0, as geom/chol.py:13-18).  Requires 6*(P-fixedp) <= 192. */
+long long cut3r_ba_workspace_floats(int P, int ht, int wd, int N, int M, int fixedp);
+int cut3r_ba_step(const float* Gij, const float* disps, const float* intr, const float* target, const float* weight, const float* eta,
+                  const int* ii, const int* jj, const int* src_ptr, const int* src_edges, const int* kx, const unsigned char* present,
+                  int P, int ht, int wd, int N, int M, int fixedp, float ep, float lm, float* workspace, float* dx, float* dz, int* flag,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

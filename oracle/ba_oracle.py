@@ -1,0 +1,108 @@
+"""TEST INFRASTRUCTURE ONLY -- float64 torch-CPU restatement of the legacy dense-BA math
+(/root/reference/hislam2/geom/projective_ops.py:15-74, pinhole.py:6-53, ba.py:32-107, chol.py:47-78,
+modules/corr.py:23-39).  PARITY UNPINNED vs the reference: `droid_backends` sources and lietorch are absent and
+`geom/ba.py` cannot execute (undefined scatter_sum).  This oracle is pinned by its own finite-difference checks
+(tests/test_ba_gpu.py) and solves the UN-REDUCED normal equations densely, so it also checks the Schur path."""
+import numpy as np
+import torch
+
+from . import lie_oracle as LO
+
+DT = torch.float64
+
+
+def se3_matrix(data):
+    """[n,7] (t, q_xyzw) -> [n,4,4]"""
+    return torch.from_numpy(np.stack([LO.data_to_matrix(1, d) for d in np.asarray(data, np.float64)]))
+
+
+def project(Gij_M, disp, intr_i, intr_j, ht, wd):
+    """coords [HW,2], valid [HW], X1 for one edge; Gij_M [4,4] fp64"""
+    y, x = torch.meshgrid(torch.arange(ht, dtype=DT), torch.arange(wd, dtype=DT), indexing="ij")
+    fx, fy, cx, cy = [float(v) for v in intr_i]
+    X0 = torch.stack([(x - cx) / fx, (y - cy) / fy, torch.ones_like(x), disp.reshape(ht, wd).to(DT)], -1).reshape(-1, 4)
+    X1 = X0 @ Gij_M.T
+    Z = torch.where(X1[:, 2] < 0.1, torch.ones_like(X1[:, 2]), X1[:, 2])
+    d = 1.0 / Z
+    fxj, fyj, cxj, cyj = [float(v) for v in intr_j]
+    coords = torch.stack([fxj * X1[:, 0] * d + cxj, fyj * X1[:, 1] * d + cyj], -1)
+    valid = (X1[:, 2] > 0.2).to(DT)
+    return coords, valid
+
+
+def ba_dense(target, weight, eta, poses7, disps, intr, ii, jj, fixedp, ep=0.1, lm=1e-4, eps=1e-6):
+    """Numerical-Jacobian Gauss-Newton step on the same normal equations, solved WITHOUT the Schur reduction.
+    Left perturbation of world->camera poses: G <- exp(a) G (retr, ba.py:29).  Returns dx [P-fixedp,6], dz [M,HW]."""
+    P, ht, wd = disps.shape
+    HW = ht * wd
+    N = len(ii)
+    G = se3_matrix(poses7)
+    kx = np.unique(ii)
+    M = len(kx)
+    kk = {int(k): m for m, k in enumerate(kx)}
+    Pf = P - fixedp
+    nx = Pf * 6 + M * HW
+    H = torch.zeros(nx, nx, dtype=DT)
+    g = torch.zeros(nx, dtype=DT)
+
+    def resid(e, Gi, Gj, d_i):
+        Gij = Gj @ torch.linalg.inv(Gi)
+        c, valid = project(Gij, d_i, intr[ii[e]], intr[jj[e]], ht, wd)
+        return c, valid
+
+    for e in range(N):
+        i, j = int(ii[e]), int(jj[e])
+        c0, valid = resid(e, G[i], G[j], disps[i])
+        r = (target[e].reshape(HW, 2).to(DT) - c0)
+        w = 0.001 * valid[:, None] * weight[e].reshape(HW, 2).to(DT)
+        # numerical Jacobians of coords wrt left perturbations of G_i, G_j and wrt the disparity of each pixel
+        Ji = torch.zeros(HW, 2, 6, dtype=DT)
+        Jj = torch.zeros(HW, 2, 6, dtype=DT)
+        for a in range(6):
+            da = np.zeros(6); da[a] = eps
+            Ep, Em = torch.from_numpy(LO.exp_matrix(1, da)), torch.from_numpy(LO.exp_matrix(1, -da))
+            Ji[:, :, a] = (resid(e, Ep @ G[i], G[j], disps[i])[0] - resid(e, Em @ G[i], G[j], disps[i])[0]) / (2 * eps)
+            Jj[:, :, a] = (resid(e, G[i], Ep @ G[j], disps[i])[0] - resid(e, G[i], Em @ G[j], disps[i])[0]) / (2 * eps)
+        Jz = (resid(e, G[i], G[j], disps[i] + eps)[0] - resid(e, G[i], G[j], disps[i] - eps)[0]) / (2 * eps)   # [HW,2]
+        m = kk[i]
+        zi = Pf * 6 + m * HW + torch.arange(HW)
+        ip, jp = i - fixedp, j - fixedp
+        blocks = []
+        if ip >= 0:
+            blocks.append((ip * 6, Ji))
+        if jp >= 0:
+            blocks.append((jp * 6, Jj))
+        for (o1, J1) in blocks:
+            g[o1:o1 + 6] += torch.einsum("kc,kca,kc->a", w, J1, r)
+            for (o2, J2) in blocks:
+                H[o1:o1 + 6, o2:o2 + 6] += torch.einsum("kc,kca,kcb->ab", w, J1, J2)
+            Ez = torch.einsum("kc,kca,kc->ka", w, J1, Jz)            # [HW,6]
+            H[o1:o1 + 6][:, zi] += Ez.T
+            H[zi[:, None], torch.arange(o1, o1 + 6)[None]] += Ez
+        H[zi, zi] += (w * Jz * Jz).sum(-1)
+        g[zi] += (w * r * Jz).sum(-1)
+    # damping exactly as chol.py:56-57 on the pose block, eta + 1e-7 on the depth diagonal (ba.py:92)
+    idx = torch.arange(Pf * 6)
+    H[idx, idx] = H[idx, idx] + (ep + lm * H[idx, idx])
+    zi = torch.arange(Pf * 6, nx)
+    H[zi, zi] += eta.reshape(-1).to(DT) + 1e-7
+    sol = torch.linalg.solve(H, g)
+    return sol[:Pf * 6].reshape(Pf, 6), sol[Pf * 6:].reshape(M, HW), kx
+
+
+def corr_lookup(volume, coords, r):
+    """grid_sample statement of the (2r+1)^2 window lookup on an all-pairs volume (corr.py:23-39 + DROID kernel)."""
+    import torch.nn.functional as F
+    BN, h1, w1, h2, w2 = volume.shape
+    rd = 2 * r + 1
+    out = torch.zeros(BN, rd, rd, h1, w1, dtype=volume.dtype)
+    v = volume.reshape(BN * h1 * w1, 1, h2, w2)
+    x0 = coords[:, 0].reshape(-1)
+    y0 = coords[:, 1].reshape(-1)
+    for i in range(rd):
+        for j in range(rd):
+            xs, ys = x0 - r + i, y0 - r + j
+            grid = torch.stack([2 * xs / (w2 - 1) - 1, 2 * ys / (h2 - 1) - 1], -1).reshape(-1, 1, 1, 2)
+            s = F.grid_sample(v, grid.to(v.dtype), mode="bilinear", padding_mode="zeros", align_corners=True)
+            out[:, i, j] = s.reshape(BN, h1, w1)
+    return out

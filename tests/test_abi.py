@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "cut3r_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(cut3r_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|long long)\s+(cut3r_\w+)\s*\(", src)))
 
 
 def test_header_and_ctypes_table_agree():
