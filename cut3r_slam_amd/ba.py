@@ -75,8 +75,10 @@ def BA(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp=1, ep=0.1, 
     dz = torch.empty(M, HW, device=dev)
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    # keep the index tensors alive until the launches are enqueued (a temporary would be recycled by the allocator)
+    src_ptr_d, order_d, kx_d, present_d = t(src_ptr, torch.int32), t(order, torch.int32), t(kx, torch.int32), t(present, torch.uint8)
     check(lib.cut3r_ba_step(_p(Gij), _p(dsp), _p(intr), _p(tgt), _p(wgt), _p(eta_d), _p(ii_d), _p(jj_d),
-                            _p(t(src_ptr, torch.int32)), _p(t(order, torch.int32)), _p(t(kx, torch.int32)), _p(t(present, torch.uint8)),
+                            _p(src_ptr_d), _p(order_d), _p(kx_d), _p(present_d),
                             P, ht, wd, N, M, fixedp, float(ep), float(lm), _p(ws), _p(dx), _p(dz), _p(flag), _stream()), "cut3r_ba_step")
     # retraction (ba.py:100-105)
     full_dx = torch.zeros(P, 6, device=dev)
