@@ -71,6 +71,10 @@ class Cut3rModel:
         self._graphs: Dict[tuple, tuple] = {}
         import os as _os
         self.use_graphs = _os.environ.get("CUT3R_GRAPHS", "1") != "0"
+        # the state-side and image-side decoder blocks of a layer are independent (both read the previous layer's
+        # pair, model.py:669-692): issue them on two streams so the captured graph has two parallel branches
+        self.dual_stream = _os.environ.get("CUT3R_DUAL_STREAM", "1") != "0"
+        self._side = None
         self._prep(state_dict)
 
     # ------------------------------------------------------------------ reference-compatible constructors
@@ -484,9 +488,20 @@ class Cut3rModel:
                 a[0:1] = self._mem_inquire(g16, mem[cm])
             self._linear(feat16[i], "decoder_embed", a[1:])
             s_a, s_b = st[cs], st[cs ^ 1]
+            fork = self.dual_stream and self.use_graphs and torch.cuda.is_current_stream_capturing()
+            if fork and self._side is None:
+                self._side = torch.cuda.Stream()
             for l in range(Ld):
-                self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, self.state_pos, pos_img, cfg.state_dec_num_heads, s_b)
-                self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, self.state_pos, cfg.dec_num_heads, b)
+                if fork:
+                    cur = torch.cuda.current_stream()
+                    self._side.wait_stream(cur)
+                    with torch.cuda.stream(self._side):
+                        self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, self.state_pos, pos_img, cfg.state_dec_num_heads, s_b)
+                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, self.state_pos, cfg.dec_num_heads, b)
+                    cur.wait_stream(self._side)
+                else:
+                    self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, self.state_pos, pos_img, cfg.state_dec_num_heads, s_b)
+                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, self.state_pos, cfg.dec_num_heads, b)
                 s_a, s_b = s_b, s_a
                 a, b = b, a
                 if l + 1 == h1:
