@@ -45,7 +45,7 @@ class ShardedTracker:
     def __init__(self, slam, world: int, rank: int, infer_fn: Callable = None, track_fn: Callable = None,
                  append_fn: Callable = None):
         self.slam, self.world, self.rank = slam, world, rank
-        self.infer_fn = infer_fn or (lambda t0, t1: slam.tracker.infer(slam.keyframes.image[t0:t1]))
+        self.infer_fn = infer_fn or (lambda t0, t1: slam.tracker.infer(t0=t0, t1=t1))
         self.track_fn = track_fn or (lambda t0, t1, outs: slam.tracker.track(t0, t1, outputs=outs))
         self.append_fn = append_fn or self._append
 
@@ -55,11 +55,8 @@ class ShardedTracker:
 
     def _append(self, kf_index: int, frame, tstamp, intr, mine: bool):
         slam = self.slam
-        if mine:
-            feat, pos = slam.filterx.encode(frame)
-            slam.keyframes.append(tstamp, frame[0], None, None, None, None, intr, feat, pos)
-        else:
-            slam.keyframes.append(tstamp, frame[0], None, None, None, None, intr, None, None)
+        # fixed cadence: the encoder pass of a keyframe is deferred to the window that owns it (TrackFrontend.window_features)
+        slam.keyframes.append(tstamp, frame[0], None, None, None, None, intr, None, None)
 
     def step(self, frames, t, kf_every, win, intr):
         """Advance `world` windows (= world*win*kf_every frames).  Returns the new frame counter."""

@@ -37,6 +37,7 @@ class KeyFrame:
         n = (ht // patch) * (wd // patch)
         self.featI = torch.zeros(buffer, n, feat_dim, dtype=torch.float, device=dev)
         self.pos = torch.zeros(buffer, n, 2, dtype=torch.int64, device=dev)
+        self.feat_valid = [False] * buffer            # host flags: featI[i] holds the encoder features of keyframe i
 
     # the reference exposes an mp.Value; single-process here, same `.counter.value` spelling
     class _Counter:
@@ -87,5 +88,6 @@ class KeyFrame:
             self.intrinsic[i] = self.intrinsic[0].clone()
         if feat is not None:
             self.featI[i].copy_(feat)
+            self.feat_valid[i] = True
         if pos is not None:
             self.pos[i].copy_(pos.reshape(self.pos[i].shape))

@@ -283,7 +283,7 @@ class Cut3rModel:
         """Capture `fn(static_input)` once per input signature into a hipGraph and replay it: a window is ~4000 kernel
         launches, which the Python/ctypes host path cannot issue as fast as the GPU retires them.  Inputs are copied
         into a static buffer; outputs are static tensors that the caller must consume before the next replay."""
-        key = (kind, tuple(inp.shape), inp.dtype)
+        key = (kind, tuple(inp.shape), inp.dtype)      # `kind` may itself be a tuple (e.g. image size)
         ent = self._graphs.get(key)
         if ent is None:
             static_in = inp.clone()
@@ -447,13 +447,40 @@ class Cut3rModel:
             return self._graphed("win", lambda x: self._forward_window(x, False), imgs.contiguous())
         return self._forward_window(imgs, return_taps)
 
-    def _forward_window(self, imgs: torch.Tensor, return_taps: bool = False):
+    @torch.no_grad()
+    def encode_batch(self, imgs: torch.Tensor) -> torch.Tensor:
+        """encoder features fp32 [B,N,E] of B images (one batched pass; a fresh tensor the caller may keep)."""
+        if self.use_graphs:
+            feat, _, _ = self._graphed("enc", self._encode, imgs.contiguous())
+            return feat.clone()
+        return self._encode(imgs)[0]
+
+    @torch.no_grad()
+    def decode_window(self, feats: torch.Tensor, H: int, W: int):
+        """Window inference from cached encoder features [V,N,E] (fp32): recurrent decoder + heads only.  The trackers
+        keep every keyframe's features (keyframe.featI, hislam2/keyframe.py:36), so a keyframe is encoded ONCE instead
+        of once in the filter and again in every window it belongs to ('double encoding')."""
+        if self.use_graphs:
+            return self._graphed(("dec", H, W), lambda f: self._forward_window(None, False, feats=f, hw=(H, W)), feats.contiguous())
+        return self._forward_window(None, False, feats=feats, hw=(H, W))
+
+    def _forward_window(self, imgs, return_taps: bool = False, feats=None, hw=None):
         cfg = self.cfg
-        V, _, H, W = imgs.shape
         P, E, D, Ld = cfg.patch_size, cfg.enc_embed_dim, cfg.dec_embed_dim, cfg.dec_depth
-        nh, nw = H // P, W // P
+        if feats is None:
+            V, _, H, W = imgs.shape
+            nh, nw = H // P, W // P
+            feat, feat16, pos = self._encode(imgs)
+        else:
+            H, W = hw
+            V = feats.shape[0]
+            nh, nw = H // P, W // P
+            feat = feats
+            feat16 = self.buf("win.feat16", (V, nh * nw, E), F16)
+            ops.cast_f16(feat.view(V * nh * nw, E), feat16.view(V * nh * nw, E))
+            y, xx = torch.meshgrid(torch.arange(nh, device=self.device), torch.arange(nw, device=self.device), indexing="ij")
+            pos = torch.stack([y.reshape(-1), xx.reshape(-1)], -1)[None].expand(V, -1, -1).contiguous()
         N, S = nh * nw, cfg.state_size
-        feat, feat16, pos = self._encode(imgs)
         taps = {"enc_feat": feat} if return_taps else None
 
         # state init (model.py:538-568, 705-711)

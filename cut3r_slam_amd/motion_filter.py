@@ -45,7 +45,7 @@ class MotionFilter:
         kf = self.keyframes
         compute_overlap = not (self.kf_every > 0)
         if kf.counter.value == 0 or last_frame or second_last_frame:
-            feat1, pos1 = self.encode(image[:1])
+            feat1, pos1 = (self.encode(image[:1]) if compute_overlap else (None, None))
             kf.append(tstamp, image[0], pose, 1.0, depth, None, intrinsics, feat1, pos1)
             return True
         overlap_ratio, feat1, pos1 = 1.0, None, None
@@ -54,7 +54,9 @@ class MotionFilter:
             feat1, pos1 = self.encode(image[:1])
             overlap_ratio = self.overlap_ratio(feat0, feat1)
         elif not compute_overlap and tstamp % self.kf_every == 0:
-            feat1, pos1 = self.encode(image[:1])
+            # fixed cadence: the decision does not depend on the features, so the encoder pass is deferred to the
+            # tracking window, which encodes its new keyframes as ONE batch and stores them in keyframes.featI
+            feat1, pos1 = None, None
         if (compute_overlap and overlap_ratio < self.thresh) or (not compute_overlap and tstamp % self.kf_every == 0):
             kf.append(tstamp, image[0], pose, None, depth, None, intrinsics, feat1, pos1)
             return True

@@ -68,8 +68,14 @@ class TrackBackend:
     def track(self, selected_idx, anchor_sub_num):
         kf, ds = self.keyframes, self.downsample_ratio
         sel = torch.as_tensor(np.asarray(selected_idx), dtype=torch.long)
-        imgs = kf.image[sel.to(kf.image.device)]
-        preds, _ = self.model.forward_window(imgs)
+        sel_d = sel.to(kf.image.device)
+        miss = [int(i) for i in sel if not kf.feat_valid[int(i)]]
+        if miss:
+            mi = torch.as_tensor(miss, device=kf.image.device)
+            kf.featI[mi] = self.model.encode_batch(kf.image[mi])
+            for i in miss:
+                kf.feat_valid[i] = True
+        preds, _ = self.model.decode_window(kf.featI[sel_d].contiguous(), kf.ht, kf.wd)
         pts = torch.cat([p["pts3d_in_self_view"] for p in preds], 0).contiguous()
         conf = torch.cat([p["conf_self"] for p in preds], 0).contiguous()
         enc = torch.cat([p["camera_pose"] for p in preds], 0)

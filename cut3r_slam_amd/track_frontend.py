@@ -54,9 +54,26 @@ class TrackFrontend:
         return make_views(self.model, images)
 
     # ------------------------------------------------------------------ one window
-    def infer(self, imgs_u8):
+    def window_features(self, t0, t1):
+        """encoder features of keyframes t0..t1-1: cached ones are reused, missing ones are encoded in one batch and
+        written back to keyframes.featI (so each keyframe goes through the ViT-L encoder exactly once)."""
+        kf = self.keyframes
+        missing = [i for i in range(t0, t1) if not kf.feat_valid[i]]
+        if missing:
+            idx = torch.as_tensor(missing, device=kf.image.device)
+            feats = self.model.encode_batch(kf.image[idx])
+            kf.featI[idx] = feats
+            for i in missing:
+                kf.feat_valid[i] = True
+        return kf.featI[t0:t1]
+
+    def infer(self, imgs_u8=None, t0=None, t1=None):
         """model outputs consumed by SLAM (track_frontend.py:81-100 keeps only these three)."""
-        preds, _ = self.model.forward_window(imgs_u8)
+        if t0 is not None:
+            H, W = self.keyframes.ht, self.keyframes.wd
+            preds, _ = self.model.decode_window(self.window_features(t0, t1), H, W)
+        else:
+            preds, _ = self.model.forward_window(imgs_u8)
         pts = torch.cat([p["pts3d_in_self_view"] for p in preds], 0)       # [V,H,W,3]
         conf = torch.cat([p["conf_self"] for p in preds], 0)               # [V,H,W]
         pose_enc = torch.cat([p["camera_pose"] for p in preds], 0)         # [V,7] (t, q wxyz)
@@ -68,7 +85,7 @@ class TrackFrontend:
         kf, graph, ds = self.keyframes, self.graph, self.downsample_ratio
         if init:
             graph.add_neighborhood_factors(0, 3, r=3)
-        pts, conf, pose_enc = outputs if outputs is not None else self.infer(kf.image[t0:t1])
+        pts, conf, pose_enc = outputs if outputs is not None else self.infer(t0=t0, t1=t1)
         V, H, W, _ = pts.shape
         lsum = None
         if not init:

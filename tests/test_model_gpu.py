@@ -107,3 +107,19 @@ def test_medium_config_head_dims_48_64_vs_oracle():
         _check(f"pts{i}", preds[i]["pts3d_in_self_view"], ref[i]["pts3d_in_self_view"], 2e-2, log)
         _check(f"conf{i}", preds[i]["conf_self"], ref[i]["conf_self"], 2e-2, log)
     print("\n".join(log))
+
+
+def test_decode_from_cached_features_equals_full_window():
+    """encode once + decode_window(features) must give the window result (features are batch-invariant bit for bit)."""
+    f = np.load(os.path.join(GOLD, "model_tiny_dpt.npz"))
+    cfg = Cut3rConfig.from_dict(json.loads(bytes(f["config_json"]).decode()))
+    model = Cut3rModel(cfg, synth_state_dict(cfg, int(f["seed"])), DEV, minimal=True)
+    imgs = torch.from_numpy(f["imgs"]).to(DEV)
+    full, _ = model.forward_window(imgs)
+    full = [{k: v.clone() for k, v in p.items()} for p in full]
+    feats = torch.cat([model.encode_batch(imgs[i:i + 1]) for i in range(3)], 0)          # per-frame encodes (B=1)
+    assert torch.equal(feats, model.encode_batch(imgs))                                   # == batched encode (B=3)
+    dec, _ = model.decode_window(feats, imgs.shape[2], imgs.shape[3])
+    for a, b in zip(full, dec):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k

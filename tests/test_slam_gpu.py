@@ -41,8 +41,8 @@ def test_tracking_loop_matches_oracle_on_same_network_outputs():
     captured = []
     real_infer = slam.tracker.infer
 
-    def spy(imgs):
-        out = real_infer(imgs)
+    def spy(*a, **k):
+        out = real_infer(*a, **k)
         captured.append(tuple(o.detach().cpu().clone() for o in out))
         return out
 
