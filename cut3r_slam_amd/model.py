@@ -75,6 +75,8 @@ class Cut3rModel:
         # pair, model.py:669-692): issue them on two streams so the captured graph has two parallel branches
         self.dual_stream = _os.environ.get("CUT3R_DUAL_STREAM", "1") != "0"
         self._side = None
+        self._kv_side = {}
+        self._head_side = None
         self._prep(state_dict)
 
     # ------------------------------------------------------------------ reference-compatible constructors
@@ -329,21 +331,37 @@ class Cut3rModel:
         Ny = y.shape[0]
         D = Cc // heads
         ln16 = self.buf(tag + ".ln16", (Nx, Cc), F16)
+        y16 = self.buf(tag + ".y16", (Ny, Cc), F16)
+        kv = self.buf(tag + ".kv", (Ny, 2 * Cc), F16)
+        kv4 = kv.view(1, Ny, 2, heads, D)
+        k, v = kv4[:, :, 0], kv4[:, :, 1]
+
+        def kv_branch():          # depends only on y (the other stream's previous layer): norm_y -> projk|projv -> RoPE(k)
+            self._ln(y, p + ".norm_y", out16=y16)
+            self._linear(y16, p + ".cross_attn.projkv", kv)
+            if ypos is not None:
+                self._rope(k, ypos)
+
+        fork = self.dual_stream and self.use_graphs and torch.cuda.is_current_stream_capturing()
+        if fork:
+            cur = torch.cuda.current_stream()
+            side = self._kv_side.get(tag)
+            if side is None:
+                side = self._kv_side[tag] = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                kv_branch()
         self._ln(x, p + ".norm1", out16=ln16)
         self._self_attn(tag, ln16, 1, Nx, heads, xpos, p + ".attn", out, x)
-        y16 = self.buf(tag + ".y16", (Ny, Cc), F16)
-        self._ln(y, p + ".norm_y", out16=y16)
         self._ln(out, p + ".norm2", out16=ln16)
         q = self.buf(tag + ".q", (1, Nx, heads, D), F16)
         self._linear(ln16, p + ".cross_attn.projq", q.view(Nx, Cc))
-        kv = self.buf(tag + ".kv", (Ny, 2 * Cc), F16)
-        self._linear(y16, p + ".cross_attn.projkv", kv)
-        kv4 = kv.view(1, Ny, 2, heads, D)
-        k, v = kv4[:, :, 0], kv4[:, :, 1]
         if xpos is not None:
             self._rope(q, xpos)
-        if ypos is not None:
-            self._rope(k, ypos)
+        if fork:
+            cur.wait_stream(side)
+        else:
+            kv_branch()
         a = self.buf(tag + ".cattn", (1, Nx, heads, D), F16)
         ops.attention(q, k, v, a, D ** -0.5)
         self._linear(a.view(Nx, Cc), p + ".cross_attn.proj", out, res1=out)
@@ -431,12 +449,16 @@ class Cut3rModel:
         o = self._conv3(o, p + ".head.2", act=2)
         return o
 
-    def _dpt_pts(self, p, toks16, B, nh, nw, H, W, key_pts, key_conf, res):
+    def _dpt_pts(self, p, toks16, B, nh, nw, H, W, key_pts, key_conf, res, out=None):
         o = self._dpt(p, toks16, B, nh, nw)
-        pts = torch.empty((B, H, W, 3), dtype=F32, device=self.device)
-        conf = torch.empty((B, H, W), dtype=F32, device=self.device)
+        if out is None:
+            pts = torch.empty((B, H, W, 3), dtype=F32, device=self.device)
+            conf = torch.empty((B, H, W), dtype=F32, device=self.device)
+        else:
+            pts, conf = out
         ops.dpt_final(o.view(B * H * W, -1), self.w[p + ".head.4.w"], self.w[p + ".head.4.b"], 0, pts, conf)
-        res[key_pts], res[key_conf] = pts, conf
+        if res is not None:
+            res[key_pts], res[key_conf] = pts, conf
 
     # ------------------------------------------------------------------ window forward
     @torch.no_grad()
@@ -503,6 +525,14 @@ class Cut3rModel:
         dn16 = self.buf("dec.dn16", (N + 1, D), F16)
         states = []
         cs, cm = 0, 0             # current state / mem buffer index
+        # DPT head of view i overlaps the (latency-bound, low-occupancy) decoder of view i+1 on a third capture stream
+        overlap_head = (self.dual_stream and self.use_graphs and torch.cuda.is_current_stream_capturing()
+                        and cfg.head_type == "dpt")
+        if overlap_head:
+            if self._head_side is None:
+                self._head_side = torch.cuda.Stream()
+            pts_all = torch.empty((V, H, W, 3), dtype=F32, device=self.device)
+            conf_all = torch.empty((V, H, W), dtype=F32, device=self.device)
         for i in range(V):
             pos_i = pos[i:i + 1]
             pos_img = torch.cat([pose_pos, pos_i], dim=1).contiguous()
@@ -544,6 +574,12 @@ class Cut3rModel:
                 tok3_32[i].copy_(dn32[1:])
             pose_tok[i].copy_(dn32[0])
             pose_tok16[i].copy_(dn16[0])
+            if overlap_head:
+                cur = torch.cuda.current_stream()
+                self._head_side.wait_stream(cur)
+                with torch.cuda.stream(self._head_side):
+                    self._dpt_pts("downstream_head.dpt_self", [feat16[i], tok1[i], tok2[i], tok3[i]], 1, nh, nw, H, W,
+                                  None, None, None, out=(pts_all[i:i + 1], conf_all[i:i + 1]))
             self._mem_update(mem[cm], g16, dn32[0:1], mem[cm ^ 1])
             cm ^= 1
             # the state ping-pong: make st[cs] hold the new state for the next view
@@ -564,7 +600,10 @@ class Cut3rModel:
         ops.postprocess_pose(praw[:, :7].contiguous(), pose)
         res: Dict[str, torch.Tensor] = {"camera_pose": pose}
         toks = [feat16.view(V * N, E), tok1.view(V * N, D), tok2.view(V * N, D), tok3.view(V * N, D)]
-        if cfg.head_type == "dpt":
+        if overlap_head:
+            torch.cuda.current_stream().wait_stream(self._head_side)
+            res["pts3d_in_self_view"], res["conf_self"] = pts_all, conf_all
+        elif cfg.head_type == "dpt":
             self._dpt_pts(h + ".dpt_self", toks, V, nh, nw, H, W, "pts3d_in_self_view", "conf_self", res)
         else:
             self._linear_head(h + ".proj", tok3.view(V * N, D), V, nh, nw, True, "pts3d_in_self_view", "conf_self", res)
