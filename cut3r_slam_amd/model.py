@@ -74,6 +74,8 @@ class Cut3rModel:
         # the state-side and image-side decoder blocks of a layer are independent (both read the previous layer's
         # pair, model.py:669-692): issue them on two streams so the captured graph has two parallel branches
         self.dual_stream = _os.environ.get("CUT3R_DUAL_STREAM", "1") != "0"
+        self.kv_branch = _os.environ.get("CUT3R_KV_BRANCH", "1") != "0"
+        self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "1") != "0"
         self._side = None
         self._kv_side = {}
         self._head_side = None
@@ -342,7 +344,7 @@ class Cut3rModel:
             if ypos is not None:
                 self._rope(k, ypos)
 
-        fork = self.dual_stream and self.use_graphs and torch.cuda.is_current_stream_capturing()
+        fork = self.dual_stream and self.kv_branch and self.use_graphs and torch.cuda.is_current_stream_capturing()
         if fork:
             cur = torch.cuda.current_stream()
             side = self._kv_side.get(tag)
@@ -526,7 +528,7 @@ class Cut3rModel:
         states = []
         cs, cm = 0, 0             # current state / mem buffer index
         # DPT head of view i overlaps the (latency-bound, low-occupancy) decoder of view i+1 on a third capture stream
-        overlap_head = (self.dual_stream and self.use_graphs and torch.cuda.is_current_stream_capturing()
+        overlap_head = (self.dual_stream and self.head_overlap and self.use_graphs and torch.cuda.is_current_stream_capturing()
                         and cfg.head_type == "dpt")
         if overlap_head:
             if self._head_side is None:
