@@ -198,7 +198,7 @@ def main():
             model.use_graphs = True
             if n:
                 ach = fl / (ms * 1e-3) / 1e12
-                roofline = {"bound": "mfma", "kernel": "gemm_kernel<128,128> (v_mfma_f32_16x16x32_f16)", "achieved": round(ach, 2),
+                roofline = {"bound": "mfma", "kernel": "gemm_kernel<128,128,2,4,2> (v_mfma_f32_16x16x32_f16, 8 waves)", "achieved": round(ach, 2),
                             "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
                             "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n}
     if rank == 0 and not args.no_cpu_baseline and not args.small:

@@ -12,8 +12,9 @@
 // Design (MI355X): v_mfma_f32_16x16x32_f16, 256-thread workgroups (4 waves, 2x2), BK = 64, LDS-DMA staging
 // (global_load_lds_dwordx4) into an N-stage LDS ring with counted s_waitcnt vmcnt and one raw s_barrier per K-tile,
 // XOR-swizzled 16-B LDS chunks (swizzle on the DMA source address + on the ds_read_b128 side), epilogue staged through
-// LDS so bias / residual / output traffic is 16-B coalesced.  Tile 128x128 for large grids, 64x64 when the grid would
-// not fill 256 CUs (batch-1 decoder GEMMs).  blockIdx.z batches independent problems with element strides.
+// LDS so bias / residual / output traffic is 16-B coalesced.  Tile 128x128 with 8 waves (4x2; two waves per SIMD hide
+// each other's LDS-DMA issue: +25-30 % over 4 waves) for large grids, 64x64 when the grid would not fill 256 CUs
+// (batch-1 decoder GEMMs; 8 waves when K >= 2048).  blockIdx.z batches independent problems with element strides.
 #include "common.h"
 #include "../../include/cut3r_hip.h"
 
@@ -51,12 +52,15 @@ DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory
 // conflict-free is applied to the per-lane SOURCE chunk (lane l sits at row l>>3, chunk l&7 of its 8-row group and
 // fetches chunk (l&7)^(l>>3)), and again on the read side.  NSTAGE-deep ring, counted vmcnt, ONE raw s_barrier per
 // K-tile: NSTAGE-2 tiles stay in flight across the barrier.
-template <int BM, int BN, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
-    constexpr int WM = BM / 2, WN = BN / 2;       // wave tile
+template <int BM, int BN, int NSTAGE, int WAVES_M = 2, int WAVES_N = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const GemmArgs g) {
+    constexpr int NWAVE = WAVES_M * WAVES_N;
+    constexpr int NTHR = 64 * NWAVE;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
     constexpr int MT = WM / 16, NT = WN / 16;     // 16x16 MFMA tiles per wave
-    constexpr int A_CH = BM / 32;                 // LDS-DMA instructions per wave per stage (A)
-    constexpr int B_CH = BN / 32;
+    constexpr int A_CH = BM / (8 * NWAVE);        // LDS-DMA instructions per wave per stage (A)
+    constexpr int B_CH = BN / (8 * NWAVE);
+    static_assert(A_CH >= 1 && B_CH >= 1 && A_CH * 8 * NWAVE == BM && B_CH * 8 * NWAVE == BN, "tile / wave mismatch");
     constexpr int NL = A_CH + B_CH;
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     constexpr int CPAD = BN + 4;
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int z = blockIdx.z;
     const h16* __restrict__ A = g.A + (size_t)z * g.sA;
     const h16* __restrict__ Bm = g.B + (size_t)z * g.sB;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     int a_oy[A_CH], a_ox[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; i++) {
-        const int r = (wave + 4 * i) * 8 + lrow;
+        const int r = (wave + NWAVE * i) * 8 + lrow;
         const int gm = m0 + r;
         a_ok[i] = gm < M;
         if (g.conv_k == 3) {
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     const h16* b_base[B_CH]; bool b_ok[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; i++) {
-        const int gn = n0 + (wave + 4 * i) * 8 + lrow;
+        const int gn = n0 + (wave + NWAVE * i) * 8 + lrow;
         b_ok[i] = gn < N;
         b_base[i] = Bm + (size_t)(b_ok[i] ? gn : 0) * g.ldb;
     }
@@ -126,13 +130,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
                 src = a_base[i] + k;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sa + (wave + NWAVE * i) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_CH; i++) {
             const h16* src = (kok && b_ok[i]) ? b_base[i] + k : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sb + (wave + 4 * i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sb + (wave + NWAVE * i) * 1024), 16, 0, 0);
         }
     };
 
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 
     const float* bias = g.bias ? g.bias + (size_t)z * g.sBias : nullptr;
     constexpr int TPR = BN / 4;               // threads per output row (4 columns each)
-    constexpr int RPP = 256 / TPR;            // rows per pass
+    constexpr int RPP = NTHR / TPR;           // rows per pass
     const int c4 = (tid % TPR) * 4;
     const int gn = n0 + c4;
     if (gn >= N) return;
@@ -325,10 +329,22 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     if (tile == 128) {
         dim3 grid((d->N + 127) / 128, (d->M + 127) / 128, batch);
         if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<128, 128, 3>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((gemm_kernel<128, 128, 2>), grid, dim3(256), 0, s, g);
+        else if (d->stages == 8) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 4>), grid, dim3(512), 0, s, g);   // 8 waves
+        else if (d->stages == 9) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);   // 8 waves
+        else if (d->stages == 10) hipLaunchKernelGGL((gemm_kernel<128, 128, 3, 4, 2>), grid, dim3(512), 0, s, g);
+        else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<128, 128, 2>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
+    } else if (tile == 256128) {
+        dim3 grid((d->N + 127) / 128, (d->M + 255) / 256, batch);
+        hipLaunchKernelGGL((gemm_kernel<256, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
+    } else if (tile == 12864) {
+        dim3 grid((d->N + 63) / 64, (d->M + 127) / 128, batch);
+        if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<128, 64, 3>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_kernel<128, 64, 2>), grid, dim3(256), 0, s, g);
     } else if (tile == 64) {
         dim3 grid((d->N + 63) / 64, (d->M + 63) / 64, batch);
         if (d->stages == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 2>), grid, dim3(256), 0, s, g);
+        else if (d->stages == 8 || (d->stages == 0 && d->K >= 2048)) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4>), grid, dim3(512), 0, s, g);   // long K: 8 waves
         else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<64, 64, 4>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((gemm_kernel<64, 64, 3>), grid, dim3(256), 0, s, g);
     } else {

@@ -75,7 +75,7 @@ class Cut3rModel:
         # pair, model.py:669-692): issue them on two streams so the captured graph has two parallel branches
         self.dual_stream = _os.environ.get("CUT3R_DUAL_STREAM", "1") != "0"
         self.kv_branch = _os.environ.get("CUT3R_KV_BRANCH", "0") != "0"   # nested capture forks segfault in hipGraph capture_end (ROCm 7.2)
-        self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "1") != "0"
+        self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "0") != "0"     # measured: no gain over the batched head
         self._side = None
         self._kv_side = {}
         self._head_side = None

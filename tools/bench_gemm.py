@@ -8,7 +8,8 @@ from cut3r_slam_amd import ops
 DEV = "cuda:0"
 SHAPES = [  # (M, N, K, label)
     (4608, 3072, 1024, "enc qkv B6"), (4608, 1024, 1024, "enc proj B6"), (4608, 4096, 1024, "enc fc1 B6"),
-    (4608, 1024, 4096, "enc fc2 B6"), (768, 3072, 1024, "enc qkv B1"), (768, 1024, 4096, "enc fc2 B1"),
+    (4608, 1024, 4096, "enc fc2 B6"), (3840, 3072, 1024, "enc qkv B5"), (3840, 1024, 1024, "enc proj B5"), (3840, 1024, 4096, "enc fc2 B5"),
+    (768, 3072, 1024, "enc qkv B1"), (768, 1024, 4096, "enc fc2 B1"), (769, 768, 768, "dec proj"), (769, 2304, 768, "dec qkv"), (769, 768, 3072, "dec fc2 "),
     (769, 2304, 768, "dec qkv"), (769, 768, 768, "dec proj"), (769, 3072, 768, "dec fc1"), (769, 768, 3072, "dec fc2"),
     (768, 1536, 768, "dec kv"), (256, 4608, 1536, "mem qkv"), (1, 1536, 1536, "mem M=1"),
 ]
@@ -29,14 +30,15 @@ def timeit(fn, reps=50):
 
 def main():
     g = torch.Generator().manual_seed(0)
-    print(f"{'shape':34s} " + " ".join(f"t{t}s{s:>1d}".rjust(12) for t, s in [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3)]))
+    CFG = [(64, 3), (64, 8), (128, 4), (128, 9), (128, 10), (256128, 2)]
+    print(f"{'shape':34s} " + " ".join(f"t{t}s{s:>1d}".rjust(12) for t, s in CFG))
     for M, N, K, label in SHAPES:
         A = torch.randn(M, K, generator=g).half().to(DEV)
         W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(DEV)
         b = torch.randn(N, generator=g).to(DEV)
         out = torch.empty(M, N, dtype=torch.float16, device=DEV)
         row = []
-        for tile, st in [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3)]:
+        for tile, st in CFG:
             ops.GEMM_STAGES = st
             us = timeit(lambda: ops.linear(A, W, out, b, 0, tile=tile))
             row.append(f"{us:6.1f}us/{2.0*M*N*K/us/1e6:5.0f}T")
@@ -78,7 +80,7 @@ def main():
         wk = (torch.randn(Cout, 9 * Cin, generator=g) / (9 * Cin) ** 0.5).half().to(DEV)
         out = torch.empty(B, H, W_, Cout, dtype=torch.float16, device=DEV)
         row = []
-        for tile, st in [(64, 3), (128, 2), (128, 3)]:
+        for tile, st in [(128, 9), (128, 10), (256128, 2)]:
             ops.GEMM_STAGES = st
             us = timeit(lambda: ops.conv3x3_nhwc(x, wk, out, None, tile=tile), reps=10)
             row.append(f"t{tile}s{st} {us:8.1f}us/{2.0*B*H*W_*Cout*9*Cin/us/1e6:5.0f}T")
