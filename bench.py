@@ -100,9 +100,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: tiny network (NOT a valid benchmark line)")
+    ap.add_argument("--window-batch", type=int, default=4, help="tracking windows pushed through the decoder together "
+                    "(buffered-stream throughput mode; 1 = the reference's one-window-at-a-time schedule)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        args.window_batch = 1          # ranks already process their windows concurrently; one window per rank per step
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
@@ -119,6 +123,7 @@ def main():
     from cut3r_slam_amd import dist as cdist
 
     H, W, KF_EVERY, WIN = 384, 512, 10, 5
+    WB = max(1, args.window_batch)
     cfg = tiny_config("dpt") if args.small else production_config()
     t0 = time.time()
     torch.set_num_threads(host_cores())
@@ -129,14 +134,14 @@ def main():
     t_build = time.time() - t0
     log(f"model resident in HBM after {t_build:.1f}s")
 
-    frames_per_step = KF_EVERY * WIN
+    frames_per_step = KF_EVERY * WIN * WB          # one step = WB windows
     total_steps = args.warmup + args.steps
     # rank r tracks its own windows: window w of step s is global window s*world + r
     probe_steps = 0 if (args.no_roofline or dist_on) else args.steps      # second, instrumented pass
-    n_kf = 6 + WIN * ((total_steps + probe_steps) * world) + 2
+    n_kf = 6 + WIN * WB * ((total_steps + probe_steps) * world) + 2 + WIN * WB
     n_frames = n_kf * KF_EVERY
     config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": KF_EVERY},
-                           "frontend": {"iteration": 0}}}
+                           "frontend": {"iteration": 0, "window_batch": WB if not dist_on else 1}}}
     slam = Cut3rSlam(model, config, (H, W), buffer=n_kf + 8, device=dev)
     intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])  # calib/replica.txt scaled
     runner = cdist.ShardedTracker(slam, world, rank) if dist_on else None
@@ -212,11 +217,13 @@ def main():
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "Replica-shaped 640x480 stream -> 384x512 tracking res; kf_every=10; step = 1 window "
-                                   "(50 frames: 5 KF encodes + 6-view CUT3R inference + alignment + graph update); "
+            "config": {"workload": f"Replica-shaped 640x480 stream -> 384x512 tracking res; kf_every=10; step = {WB} window(s) "
+                                   f"= {frames_per_step} frames: each new keyframe through the ViT-L encoder once (batched), "
+                                   "6-view recurrent decoder + DPT head per window (windows batched through the decoder), "
+                                   "log-depth/pose chaining + covisibility-graph update per keyframe; "
                                    "ViT-L/24 enc, 768/12 dual decoder, DPT head, random init; GS backend off"
                                    + (" [DEBUG --small]" if args.small else ""),
-                       "frames_per_step": frames_per_step, "window_views": 6, "parallelism": f"window-sharded x{world}"},
+                       "frames_per_step": frames_per_step, "window_views": 6, "window_batch": WB, "parallelism": f"window-sharded x{world}"},
             "roofline": roofline, "cpu_baseline": cpu_base, "build_s": round(t_build, 1),
         }
         print(json.dumps(out))
@@ -238,10 +245,13 @@ def cpu_baseline(cfg, sd, imgs_u8, frames_per_step):
         t0 = time.perf_counter()
         O.forward_views(cfg, sd, x[:2], minimal=True)
         t_win2 = time.perf_counter() - t0
-    step_s = 5 * t_enc + 3.0 * t_win2
-    return {"value": round(frames_per_step / step_s, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+    # same algorithmic work as the GPU path per 50-frame window: 5 new keyframes encoded once + 6 views decoded
+    # (the 2-view sample contains 2 encodes + 2 decodes; the model cost is linear in views)
+    t_dec_view = max(t_win2 - 2 * t_enc, 0.0) / 2
+    window_s = 5 * t_enc + 6 * t_dec_view
+    return {"value": round(50.0 / window_s, 3), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle/cut3r_oracle.py fp32: 1 encode_image ({t_enc:.2f} s) + one 2-view window ({t_win2:.2f} s) at "
-                      f"384x512, extrapolated to a 50-frame step = 5 encodes + 6 views"}
+                      f"384x512, extrapolated to a 50-frame window = 5 encodes + 6 decoder/head views"}
 
 
 if __name__ == "__main__":

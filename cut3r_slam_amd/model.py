@@ -327,15 +327,16 @@ class Cut3rModel:
         return feat, pos, im_shape
 
     # ------------------------------------------------------------------ decoder block
-    def _dec_block(self, tag, p, x, y, xpos, ypos, heads, out):
-        """x fp32 [Nx,C], y fp32 [Ny,C] -> out fp32 [Nx,C]   (dust3r/blocks.py:292-297); batch = 1."""
-        Nx, Cc = x.shape
-        Ny = y.shape[0]
+    def _dec_block(self, tag, p, x, y, xpos, ypos, heads, out, B=1):
+        """x fp32 [B*Nx,C], y fp32 [B*Ny,C] -> out fp32 [B*Nx,C]   (dust3r/blocks.py:292-297).  B = independent
+        sequences (tracking windows batched through the decoder)."""
+        Cc = x.shape[1]
+        Nx, Ny = x.shape[0] // B, y.shape[0] // B
         D = Cc // heads
-        ln16 = self.buf(tag + ".ln16", (Nx, Cc), F16)
-        y16 = self.buf(tag + ".y16", (Ny, Cc), F16)
-        kv = self.buf(tag + ".kv", (Ny, 2 * Cc), F16)
-        kv4 = kv.view(1, Ny, 2, heads, D)
+        ln16 = self.buf(tag + ".ln16", (B * Nx, Cc), F16)
+        y16 = self.buf(tag + ".y16", (B * Ny, Cc), F16)
+        kv = self.buf(tag + ".kv", (B * Ny, 2 * Cc), F16)
+        kv4 = kv.view(B, Ny, 2, heads, D)
         k, v = kv4[:, :, 0], kv4[:, :, 1]
 
         def kv_branch():          # depends only on y (the other stream's previous layer): norm_y -> projk|projv -> RoPE(k)
@@ -354,45 +355,47 @@ class Cut3rModel:
             with torch.cuda.stream(side):
                 kv_branch()
         self._ln(x, p + ".norm1", out16=ln16)
-        self._self_attn(tag, ln16, 1, Nx, heads, xpos, p + ".attn", out, x)
+        self._self_attn(tag, ln16, B, Nx, heads, xpos, p + ".attn", out, x)
         self._ln(out, p + ".norm2", out16=ln16)
-        q = self.buf(tag + ".q", (1, Nx, heads, D), F16)
-        self._linear(ln16, p + ".cross_attn.projq", q.view(Nx, Cc))
+        q = self.buf(tag + ".q", (B, Nx, heads, D), F16)
+        self._linear(ln16, p + ".cross_attn.projq", q.view(B * Nx, Cc))
         if xpos is not None:
             self._rope(q, xpos)
         if fork:
             cur.wait_stream(side)
         else:
             kv_branch()
-        a = self.buf(tag + ".cattn", (1, Nx, heads, D), F16)
+        a = self.buf(tag + ".cattn", (B, Nx, heads, D), F16)
         ops.attention(q, k, v, a, D ** -0.5)
-        self._linear(a.view(Nx, Cc), p + ".cross_attn.proj", out, res1=out)
+        self._linear(a.view(B * Nx, Cc), p + ".cross_attn.proj", out, res1=out)
         self._ln(out, p + ".norm3", out16=ln16)
         self._mlp(tag, ln16, p + ".mlp", out, out)
         return out
 
     # ------------------------------------------------------------------ pose memory
-    def _mem_inquire(self, gfeat16, mem):
+    def _mem_inquire(self, gfeat16, mem, B=1):
+        """gfeat16 [B,E] fp16, mem [B*size, 2D] -> pose feature [B, D]  (model.py:217-222)"""
         cfg = self.cfg
         D = cfg.dec_embed_dim
-        x = self.buf("memr.x", (1, 2 * D), F32)
+        x = self.buf("memr.x", (B, 2 * D), F32)
         self._linear(gfeat16, "pose_retriever.proj_q", x[:, :D])
         x[:, D:] = self.masked_token
-        a, b = x, self.buf("memr.x2", (1, 2 * D), F32)
+        a, b = x, self.buf("memr.x2", (B, 2 * D), F32)
         for i in range(2):
-            self._dec_block("memr", f"pose_retriever.read_blocks.{i}", a, mem, None, None, cfg.dec_num_heads, b)
+            self._dec_block("memr", f"pose_retriever.read_blocks.{i}", a, mem, None, None, cfg.dec_num_heads, b, B)
             a, b = b, a
         return a[:, D:]
 
-    def _mem_update(self, mem, gfeat16, pose_out, out):
+    def _mem_update(self, mem, gfeat16, pose_out, out, B=1):
+        """mem [B*size, 2D], pose_out [B, D] -> out (new memory)  (model.py:204-215)"""
         cfg = self.cfg
         D = cfg.dec_embed_dim
-        f = self.buf("memw.f", (1, 2 * D), F32)
+        f = self.buf("memw.f", (B, 2 * D), F32)
         self._linear(gfeat16, "pose_retriever.proj_q", f[:, :D])
         f[:, D:] = pose_out
         tmp = self.buf("memw.tmp", tuple(mem.shape), F32)
-        self._dec_block("memw", "pose_retriever.write_blocks.0", mem, f, None, None, cfg.dec_num_heads, tmp)
-        self._dec_block("memw", "pose_retriever.write_blocks.1", tmp, f, None, None, cfg.dec_num_heads, out)
+        self._dec_block("memw", "pose_retriever.write_blocks.0", mem, f, None, None, cfg.dec_num_heads, tmp, B)
+        self._dec_block("memw", "pose_retriever.write_blocks.1", tmp, f, None, None, cfg.dec_num_heads, out, B)
         return out
 
     # ------------------------------------------------------------------ heads
@@ -489,132 +492,150 @@ class Cut3rModel:
         return self._forward_window(None, False, feats=feats, hw=(H, W))
 
     def _forward_window(self, imgs, return_taps: bool = False, feats=None, hw=None):
-        cfg = self.cfg
-        P, E, D, Ld = cfg.patch_size, cfg.enc_embed_dim, cfg.dec_embed_dim, cfg.dec_depth
+        """one window: images [V,3,H,W] (encoder + decoder + heads) or cached features [V,N,E] (decoder + heads)"""
+        P = self.cfg.patch_size
         if feats is None:
             V, _, H, W = imgs.shape
-            nh, nw = H // P, W // P
-            feat, feat16, pos = self._encode(imgs)
+            feat, feat16, _ = self._encode(imgs)
+            res, taps = self._decode(feat[None], feat16[None], H, W, return_taps)
         else:
             H, W = hw
+            res, taps = self._decode(feats[None], None, H, W, return_taps)
             V = feats.shape[0]
-            nh, nw = H // P, W // P
-            feat = feats
-            feat16 = self.buf("win.feat16", (V, nh * nw, E), F16)
-            ops.cast_f16(feat.view(V * nh * nw, E), feat16.view(V * nh * nw, E))
-            y, xx = torch.meshgrid(torch.arange(nh, device=self.device), torch.arange(nw, device=self.device), indexing="ij")
-            pos = torch.stack([y.reshape(-1), xx.reshape(-1)], -1)[None].expand(V, -1, -1).contiguous()
-        N, S = nh * nw, cfg.state_size
-        taps = {"enc_feat": feat} if return_taps else None
+        preds = [{k: v[i:i + 1] for k, v in res.items()} for i in range(V)]
+        return preds, taps
 
-        # state init (model.py:538-568, 705-711)
-        st = [self.buf("dec.state0", (S, D), F32), self.buf("dec.state1", (S, D), F32)]
-        self._linear(self.register_tokens16, "decoder_embed_state", st[0])
-        im = [self.buf("dec.img0", (N + 1, D), F32), self.buf("dec.img1", (N + 1, D), F32)]
-        mem = [self.buf("dec.mem0", tuple(self.mem0.shape), F32), self.buf("dec.mem1", tuple(self.mem0.shape), F32)]
-        mem[0].copy_(self.mem0)
-        pose_pos = -torch.ones(1, 1, 2, dtype=torch.int64, device=self.device)
+    @torch.no_grad()
+    def decode_windows(self, feats: torch.Tensor, H: int, W: int):
+        """Batched window inference: feats [Wn,V,N,E] fp32 (cached encoder features of Wn INDEPENDENT tracking windows:
+        every window re-initialises state and pose memory, model.py:819-822) -> dict of stacked predictions
+        (pts3d_in_self_view [Wn*V,H,W,3], conf_self [Wn*V,H,W], camera_pose [Wn*V,7], window-major).  The recurrent decoder
+        is sequential over the V views but its GEMMs/attention are batched over the Wn windows (M = Wn*768 rows),
+        which lifts them from the latency-bound tile-64 regime into the MFMA-bound tile-128 regime."""
+        if self.use_graphs:
+            return self._graphed(("decW", H, W), lambda f: self._decode(f, None, H, W, False)[0], feats.contiguous())
+        return self._decode(feats, None, H, W, False)[0]
+
+    def _decode(self, feat, feat16, H, W, return_taps=False):
+        """feat fp32 [Wn,V,N,E] (+ optional fp16 copy).  Returns (dict of [Wn*V,...] tensors, taps)."""
+        cfg = self.cfg
+        P, E, D, Ld = cfg.patch_size, cfg.enc_embed_dim, cfg.dec_embed_dim, cfg.dec_depth
+        Wn, V, N, _ = feat.shape
+        nh, nw = H // P, W // P
+        S = cfg.state_size
+        dev = self.device
+        if feat16 is None:
+            feat16 = self.buf("win.feat16", (Wn, V, N, E), F16)
+            ops.cast_f16(feat.reshape(Wn * V * N, E), feat16.view(Wn * V * N, E))
+        y, xx = torch.meshgrid(torch.arange(nh, device=dev), torch.arange(nw, device=dev), indexing="ij")
+        pos1 = torch.stack([y.reshape(-1), xx.reshape(-1)], -1)[None]                                  # [1,N,2]
+        pos_img = torch.cat([-torch.ones(1, 1, 2, dtype=torch.int64, device=dev), pos1], dim=1).expand(Wn, -1, -1).contiguous()
+        pos_state = self.state_pos.expand(Wn, -1, -1).contiguous()
+        taps = {"enc_feat": feat[0]} if return_taps else None
+
+        # state init (model.py:538-568, 705-711): identical for every window
+        st = [self.buf("dec.state0", (Wn * S, D), F32), self.buf("dec.state1", (Wn * S, D), F32)]
+        s0 = self.buf("dec.s0", (S, D), F32)
+        self._linear(self.register_tokens16, "decoder_embed_state", s0)
+        st[0].view(Wn, S, D).copy_(s0[None].expand(Wn, -1, -1))
+        im = [self.buf("dec.img0", (Wn * (N + 1), D), F32), self.buf("dec.img1", (Wn * (N + 1), D), F32)]
+        msz = self.mem0.shape[0]
+        mem = [self.buf("dec.mem0", (Wn * msz, 2 * D), F32), self.buf("dec.mem1", (Wn * msz, 2 * D), F32)]
+        mem[0].view(Wn, msz, 2 * D).copy_(self.mem0[None].expand(Wn, -1, -1))
         h1, h2 = Ld * 2 // 4, Ld * 3 // 4
-        tok1 = self.buf("head.tok1", (V, N, D), F16)
-        tok2 = self.buf("head.tok2", (V, N, D), F16)
-        tok3 = self.buf("head.tok3", (V, N, D), F16)
-        tok3_32 = self.buf("head.tok3_32", (V, N, D), F32) if not self.minimal else None
-        pose_tok = self.buf("head.pose_tok", (V, D), F32)
-        pose_tok16 = self.buf("head.pose_tok16", (V, D), F16)
-        g32 = self.buf("dec.g32", (1, E), F32)
-        g16 = self.buf("dec.g16", (1, E), F16)
-        dn32 = self.buf("dec.dn32", (N + 1, D), F32)
-        dn16 = self.buf("dec.dn16", (N + 1, D), F16)
+        tok1 = self.buf("head.tok1", (Wn, V, N, D), F16)
+        tok2 = self.buf("head.tok2", (Wn, V, N, D), F16)
+        tok3 = self.buf("head.tok3", (Wn, V, N, D), F16)
+        tok3_32 = self.buf("head.tok3_32", (Wn, V, N, D), F32) if not self.minimal else None
+        pose_tok = self.buf("head.pose_tok", (Wn, V, D), F32)
+        pose_tok16 = self.buf("head.pose_tok16", (Wn, V, D), F16)
+        g32 = self.buf("dec.g32", (Wn, E), F32)
+        g16 = self.buf("dec.g16", (Wn, E), F16)
+        dn32 = self.buf("dec.dn32", (Wn * (N + 1), D), F32)
+        dn16 = self.buf("dec.dn16", (Wn * (N + 1), D), F16)
+        Lde = self.w["decoder_embed"]
+        w_de = Lde.w.unsqueeze(0).expand(Wn, -1, -1)
+        b_de = Lde.b.unsqueeze(0).expand(Wn, -1)
         states = []
         cs, cm = 0, 0             # current state / mem buffer index
-        # DPT head of view i overlaps the (latency-bound, low-occupancy) decoder of view i+1 on a third capture stream
-        overlap_head = (self.dual_stream and self.head_overlap and self.use_graphs and torch.cuda.is_current_stream_capturing()
-                        and cfg.head_type == "dpt")
-        if overlap_head:
-            if self._head_side is None:
-                self._head_side = torch.cuda.Stream()
-            pts_all = torch.empty((V, H, W, 3), dtype=F32, device=self.device)
-            conf_all = torch.empty((V, H, W), dtype=F32, device=self.device)
+        fork = self.dual_stream and self.use_graphs and torch.cuda.is_current_stream_capturing()
+        if fork and self._side is None:
+            self._side = torch.cuda.Stream()
         for i in range(V):
-            pos_i = pos[i:i + 1]
-            pos_img = torch.cat([pose_pos, pos_i], dim=1).contiguous()
-            ops.colmean(feat[i], g32.view(-1))
+            for w in range(Wn):
+                ops.colmean(feat[w, i], g32[w])
             ops.cast_f16(g32, g16)
             a, b = im[0], im[1]
+            a3 = a.view(Wn, N + 1, D)
             if i == 0:
-                a[0:1] = self.pose_token
+                a3[:, 0] = self.pose_token
             else:
-                a[0:1] = self._mem_inquire(g16, mem[cm])
-            self._linear(feat16[i], "decoder_embed", a[1:])
+                a3[:, 0] = self._mem_inquire(g16, mem[cm], Wn)
+            ops.linear_batched(feat16[:, i], w_de, a3[:, 1:], b_de)                                   # decoder_embed
             s_a, s_b = st[cs], st[cs ^ 1]
-            fork = self.dual_stream and self.use_graphs and torch.cuda.is_current_stream_capturing()
-            if fork and self._side is None:
-                self._side = torch.cuda.Stream()
             for l in range(Ld):
                 if fork:
                     cur = torch.cuda.current_stream()
                     self._side.wait_stream(cur)
                     with torch.cuda.stream(self._side):
-                        self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, self.state_pos, pos_img, cfg.state_dec_num_heads, s_b)
-                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, self.state_pos, cfg.dec_num_heads, b)
+                        self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn)
+                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn)
                     cur.wait_stream(self._side)
                 else:
-                    self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, self.state_pos, pos_img, cfg.state_dec_num_heads, s_b)
-                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, self.state_pos, cfg.dec_num_heads, b)
+                    self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn)
+                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn)
                 s_a, s_b = s_b, s_a
                 a, b = b, a
-                if l + 1 == h1:
-                    ops.cast_f16(a[1:], tok1[i])
-                if l + 1 == h2:
-                    ops.cast_f16(a[1:], tok2[i])
+                if l + 1 == h1 or l + 1 == h2:
+                    tk = tok1 if l + 1 == h1 else tok2
+                    av = a.view(Wn, N + 1, D)
+                    for w in range(Wn):
+                        ops.cast_f16(av[w, 1:], tk[w, i])
             # final norms (model.py:694-697): new state = dec_norm_state(state), img = dec_norm(img)
             self._ln(s_a, "dec_norm_state", out32=s_b)
             new_state = s_b
             self._ln(a, "dec_norm", out16=dn16, out32=dn32)
-            tok3[i].copy_(dn16[1:])
+            dn16v, dn32v = dn16.view(Wn, N + 1, D), dn32.view(Wn, N + 1, D)
+            tok3[:, i].copy_(dn16v[:, 1:])
             if tok3_32 is not None:
-                tok3_32[i].copy_(dn32[1:])
-            pose_tok[i].copy_(dn32[0])
-            pose_tok16[i].copy_(dn16[0])
-            if overlap_head:
-                cur = torch.cuda.current_stream()
-                self._head_side.wait_stream(cur)
-                with torch.cuda.stream(self._head_side):
-                    self._dpt_pts("downstream_head.dpt_self", [feat16[i], tok1[i], tok2[i], tok3[i]], 1, nh, nw, H, W,
-                                  None, None, None, out=(pts_all[i:i + 1], conf_all[i:i + 1]))
-            self._mem_update(mem[cm], g16, dn32[0:1], mem[cm ^ 1])
+                tok3_32[:, i].copy_(dn32v[:, 1:])
+            pose_tok[:, i].copy_(dn32v[:, 0])
+            pose_tok16[:, i].copy_(dn16v[:, 0])
+            self._mem_update(mem[cm], g16, dn32v[:, 0], mem[cm ^ 1], Wn)
             cm ^= 1
             # the state ping-pong: make st[cs] hold the new state for the next view
             cs = 0 if new_state is st[0] else 1
             if return_taps:
-                states.append((new_state.clone(), mem[cm].clone()))
+                states.append((new_state.view(Wn, S, D)[0].clone(), mem[cm].view(Wn, msz, 2 * D)[0].clone()))
         if return_taps:
             taps["states"] = states
 
-        # ---- heads, batched over the V views of the window
-        preds = [dict() for _ in range(V)]
+        # ---- heads, batched over all Wn*V views
+        BV = Wn * V
         h = "downstream_head"
-        ph = self.buf("head.pose_h", (V, self.w[h + ".pose_head.mlp.fc1"].npad), F16)
-        self._linear(pose_tok16, h + ".pose_head.mlp.fc1", ph, act=1)
-        praw = self.buf("head.pose_raw", (V, 8), F32)
+        ph = self.buf("head.pose_h", (BV, self.w[h + ".pose_head.mlp.fc1"].npad), F16)
+        self._linear(pose_tok16.view(BV, D), h + ".pose_head.mlp.fc1", ph, act=1)
+        praw = self.buf("head.pose_raw", (BV, 8), F32)
         self._linear(ph, h + ".pose_head.mlp.fc2", praw)
-        pose = torch.empty((V, 7), dtype=F32, device=self.device)
+        pose = torch.empty((BV, 7), dtype=F32, device=dev)
         ops.postprocess_pose(praw[:, :7].contiguous(), pose)
         res: Dict[str, torch.Tensor] = {"camera_pose": pose}
-        toks = [feat16.view(V * N, E), tok1.view(V * N, D), tok2.view(V * N, D), tok3.view(V * N, D)]
-        if overlap_head:
-            torch.cuda.current_stream().wait_stream(self._head_side)
-            res["pts3d_in_self_view"], res["conf_self"] = pts_all, conf_all
-        elif cfg.head_type == "dpt":
-            self._dpt_pts(h + ".dpt_self", toks, V, nh, nw, H, W, "pts3d_in_self_view", "conf_self", res)
+        toks = [feat16.reshape(BV * N, E), tok1.view(BV * N, D), tok2.view(BV * N, D), tok3.view(BV * N, D)]
+        if cfg.head_type == "dpt":
+            # chunks of <= 8 views keep the implicit-GEMM grids (M/128 row tiles on grid.y) inside the 65535 limit
+            pts = torch.empty((BV, H, W, 3), dtype=F32, device=dev)
+            conf = torch.empty((BV, H, W), dtype=F32, device=dev)
+            for c0 in range(0, BV, 8):
+                c1 = min(BV, c0 + 8)
+                tk = [t.view(BV, N, -1)[c0:c1].reshape((c1 - c0) * N, -1) for t in toks]
+                self._dpt_pts(h + ".dpt_self", tk, c1 - c0, nh, nw, H, W, None, None, None, out=(pts[c0:c1], conf[c0:c1]))
+            res["pts3d_in_self_view"], res["conf_self"] = pts, conf
         else:
-            self._linear_head(h + ".proj", tok3.view(V * N, D), V, nh, nw, True, "pts3d_in_self_view", "conf_self", res)
+            self._linear_head(h + ".proj", tok3.view(BV * N, D), BV, nh, nw, True, "pts3d_in_self_view", "conf_self", res)
         if not self.minimal:
-            self._cross_heads(toks, tok3_32, pose_tok, pos, V, nh, nw, H, W, res)
-        for i in range(V):
-            for k, v in res.items():
-                preds[i][k] = v[i:i + 1]
-        return preds, taps
+            posBV = pos1.expand(BV, -1, -1).contiguous()
+            self._cross_heads(toks, tok3_32.view(BV, N, D), pose_tok.view(BV, D), posBV, BV, nh, nw, H, W, res)
+        return res, taps
 
     def _linear_head(self, p, tok16, V, nh, nw, pos_z, key_pts, key_conf, res, rgb=False):
         P = self.cfg.patch_size

@@ -48,6 +48,10 @@ class TrackFrontend:
         self.frontend_radius = config.get("frontend_radius", 2)
         self.keyframes.mono_depth_alpha = config.get("mono_depth_alpha", 0.01)
         self.downsample_ratio = slam.downsample_ratio
+        # throughput knob (not in the reference, default 1 = reference behaviour): wait for `window_batch` windows of new
+        # keyframes and push them through the decoder TOGETHER (windows are independent network evaluations; the chaining
+        # below stays sequential).  Trades latency (window_batch*5 keyframes) for MFMA-bound decoder GEMMs.
+        self.window_batch = int(config.get("window_batch", 1))
         self._lsum = torch.zeros(1, dtype=torch.float64, device=device)
 
     def prepare_input(self, images):
@@ -125,6 +129,18 @@ class TrackFrontend:
                 graph.add(i, all_c2w, SubmapStore(kf.submap_ds, i), cur_c2w, cur_pm, K,
                           all_w2c_rows=kf.w2c[:i], current_w2c_row=kf.w2c[i])
 
+    def track_batch(self, ranges):
+        """several consecutive 6-keyframe windows: ONE batched decoder/head inference, then the reference's sequential
+        chaining + graph update window by window (identical results to calling track() per window)."""
+        kf = self.keyframes
+        feats = torch.stack([self.window_features(a, b) for a, b in ranges], 0)          # [Wb,6,N,E]
+        res = self.model.decode_windows(feats, kf.ht, kf.wd)
+        V = ranges[0][1] - ranges[0][0]
+        for j, (a, b) in enumerate(ranges):
+            sl = slice(j * V, (j + 1) * V)
+            self.track(a, b, outputs=(res["pts3d_in_self_view"][sl], res["conf_self"][sl], res["camera_pose"][sl]))
+            self.t1 = b
+
     # ------------------------------------------------------------------ scheduling (track_frontend.py:285-330)
     def run(self, tstamp, last_frame=False):
         kf = self.keyframes
@@ -134,6 +150,21 @@ class TrackFrontend:
             kf.is_initialized = True
             self.t1 = t1
             return False, range(0, t1), 0
+        elif kf.is_initialized and self.window_batch > 1:
+            Wb = self.window_batch
+            if self.t1 < kf.counter.value - 5 * Wb:
+                first = self.t1 - 1
+                self.track_batch([(first + 5 * j, first + 5 * j + 6) for j in range(Wb)])
+                t1 = self.t1
+                return (t1 > 10), range(first, t1), (t1 - 6) // 5
+            if last_frame:
+                while self.t1 < kf.counter.value - 1:
+                    t0 = self.t1 - 1
+                    t1 = min(t0 + 6, kf.counter.value - 1)
+                    self.track(t0, t1)
+                    self.t1 = t1
+                return False, None, None
+            return False, None, None
         elif kf.is_initialized and self.t1 < kf.counter.value - 5:
             t0 = self.t1 - 1
             t1 = kf.counter.value - 1

@@ -123,3 +123,22 @@ def test_decode_from_cached_features_equals_full_window():
     for a, b in zip(full, dec):
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_batched_windows_equal_individual_windows():
+    """decode_windows over Wn independent windows == each window alone (GEMM rows / attention batches are independent)."""
+    cfg = Cut3rConfig(img_size=(64, 96), enc_embed_dim=256, enc_depth=2, enc_num_heads=4, dec_embed_dim=192, dec_depth=4,
+                      dec_num_heads=3, state_dec_num_heads=4, state_size=30, local_mem_size=16, ray_enc_depth=1, head_type="dpt")
+    model = Cut3rModel(cfg, synth_state_dict(cfg, 5), DEV, minimal=True)
+    g = torch.Generator().manual_seed(1)
+    imgs = torch.randint(0, 256, (9, 3, 64, 96), generator=g, dtype=torch.uint8).to(DEV)
+    feats = model.encode_batch(imgs)                                    # [9,N,E]
+    wins = torch.stack([feats[0:3], feats[3:6], feats[6:9]], 0)         # 3 windows of 3 views
+    res = model.decode_windows(wins, 64, 96)
+    res = {k: v.clone() for k, v in res.items()}
+    for w in range(3):
+        single, _ = model.decode_window(wins[w], 64, 96)
+        for v in range(3):
+            for k in ("pts3d_in_self_view", "conf_self", "camera_pose"):
+                a, b = res[k][w * 3 + v], single[v][k][0]
+                assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), (w, v, k, float((a - b).abs().max()))

@@ -125,3 +125,23 @@ def test_keyframe_filter_overlap_mode_decisions_match_oracle():
     assert decisions == ref_dec
     assert 1 <= sum(decisions) < 40
     print("keyframes taken at", [t for t, d in enumerate(decisions) if d])
+
+
+def test_window_batch_gives_the_same_trajectory_and_graph():
+    """window_batch=3 (batched decoder inference of 3 windows) vs the reference schedule (one window at a time)."""
+    frames = _frames(80, seed=2)
+    intr = torch.tensor([40.0, 40.0, 23.5, 15.5])
+    out = []
+    for wb in (1, 3):
+        model = _model()
+        cfgd = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 1, "kf_every": 2}, "frontend": {"iteration": 0, "window_batch": wb}}}
+        slam = Cut3rSlam(model, cfgd, (H, W), buffer=48, device=DEV)
+        for t in range(80):
+            slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr, last_frame=(t == 79))
+        n = slam.tracker.t1
+        out.append((n, slam.keyframes.pose[:n].numpy().copy(), slam.graph.edges_numpy(), slam.keyframes.depth[:n].cpu().numpy()))
+    assert out[0][0] == out[1][0] and out[0][0] > 20
+    np.testing.assert_allclose(out[0][1], out[1][1], atol=1e-5)
+    np.testing.assert_allclose(out[0][3], out[1][3], rtol=1e-4, atol=1e-5)
+    for a, b in zip(out[0][2], out[1][2]):
+        np.testing.assert_array_equal(a, b)
