@@ -133,7 +133,8 @@ class TrackFrontend:
         """several consecutive 6-keyframe windows: ONE batched decoder/head inference, then the reference's sequential
         chaining + graph update window by window (identical results to calling track() per window)."""
         kf = self.keyframes
-        feats = torch.stack([self.window_features(a, b) for a, b in ranges], 0)          # [Wb,6,N,E]
+        self.window_features(ranges[0][0], ranges[-1][1])                                 # ONE batched encode of every new keyframe
+        feats = torch.stack([self.window_features(a, b) for a, b in ranges], 0)          # [Wb,6,N,E] (all cached now)
         res = self.model.decode_windows(feats, kf.ht, kf.wd)
         V = ranges[0][1] - ranges[0][0]
         for j, (a, b) in enumerate(ranges):
