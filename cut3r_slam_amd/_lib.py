@@ -34,6 +34,8 @@ class GemmDesc(C.Structure):
 SIGNATURES = {
     "cut3r_abi_version": [],
     "cut3r_rope2d": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_ll, c_ll, c_ll, c_float, c_float, c_void_p],
+    "cut3r_rope2d_qk": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_ll, c_ll, c_ll, c_ll, c_float, c_float,
+                        c_void_p],
     "cut3r_layernorm": [c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                         c_void_p, c_void_p, c_void_p],
     "cut3r_gemm_f16": [C.POINTER(GemmDesc), c_void_p],

@@ -6,31 +6,53 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------- RoPE-2D
-// /root/reference/src/croco/models/curope/kernels.cu:17-82.  One wave per (b, n) token, lanes sweep the H*D/2 (u,v)
-// pairs of the token; cos/sin are evaluated once per (token, X, q) in fp32 with the reference's operation order
-// (inv_freq = fwd / powf(base, q/Q); freq = pos * inv_freq) and reused across heads.
+// /root/reference/src/croco/models/curope/kernels.cu:17-82.  One workgroup per (b, n) token, as in the reference kernel:
+// cos/sin of the token's (y, x) position are evaluated once per (X, q) in fp32 with the reference's operation order
+// (inv_freq = fwd / powf(base, q/Q); freq = pos * inv_freq) into LDS and shared by every head -- and by BOTH tensors
+// when a second one (k next to q, same positions) is passed.  Each thread rotates 4 consecutive (u, v) pairs with
+// 8/16-byte accesses.
+template <typename T> struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
+
 template <typename T>
-__global__ __launch_bounds__(256) void rope2d_kernel(T* __restrict__ tok, const int64_t* __restrict__ pos, int BN, int N, int H,
-                                                     int D, long long sB, long long sN, long long sH, float base, float fwd) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= BN) return;
+__global__ __launch_bounds__(256) void rope2d_kernel(T* __restrict__ tok, T* __restrict__ tok2, const int64_t* __restrict__ pos,
+                                                     int N, int H, int D, long long sB, long long sN, long long sH, long long sB2,
+                                                     long long sN2, float base, float fwd) {
+    __shared__ float cs[2][2][64];          // [X][cos|sin][q]   (Q <= 64, i.e. D <= 256)
+    const int t = blockIdx.x;
     const int b = t / N, n = t - b * N;
     const int Q = D >> 2;
-    T* p = tok + (size_t)b * sB + (size_t)n * sN;
-    const float py = (float)pos[(size_t)t * 2 + 0], px = (float)pos[(size_t)t * 2 + 1];
-    // pair index e in [0, 2Q): X = e / Q (0 = y half, 1 = x half), q = e % Q
-    for (int e = lane; e < 2 * Q; e += 64) {
-        const int X = e / Q, q = e - X * Q;
+    if (threadIdx.x < 2 * Q) {
+        const int X = threadIdx.x / Q, q = threadIdx.x - X * Q;
         const float inv = fwd / powf(base, (float)q / (float)Q);
-        const float fr = (X ? px : py) * inv;
-        const float c = cosf(fr), s = sinf(fr);
-        for (int h = 0; h < H; h++) {
-            T* th = p + (size_t)h * sH + X * 2 * Q;
-            const float u = (float)th[q], v = (float)th[q + Q];
-            th[q] = (T)(u * c - v * s);
-            th[q + Q] = (T)(v * c + u * s);
+        const float fr = (float)pos[(size_t)t * 2 + X] * inv;
+        cs[X][0][q] = cosf(fr);
+        cs[X][1][q] = sinf(fr);
+    }
+    __syncthreads();
+    const int Q4 = Q >> 2;                  // 4-pair chunks per (head, X)
+    const int per_tensor = H * 2 * Q4;
+    const int total = tok2 ? 2 * per_tensor : per_tensor;
+    for (int w = threadIdx.x; w < total; w += blockDim.x) {
+        const int which = w / per_tensor;
+        int r = w - which * per_tensor;
+        const int h = r / (2 * Q4);
+        r -= h * 2 * Q4;
+        const int X = r / Q4, c = r - X * Q4;
+        T* base_p = which ? (tok2 + (size_t)b * sB2 + (size_t)n * sN2) : (tok + (size_t)b * sB + (size_t)n * sN);
+        T* pu = base_p + (size_t)h * sH + X * 2 * Q + 4 * c;
+        T* pv = pu + Q;
+        Vec4<T> u = *reinterpret_cast<Vec4<T>*>(pu);
+        Vec4<T> v = *reinterpret_cast<Vec4<T>*>(pv);
+        Vec4<T> ou, ov;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float co = cs[X][0][4 * c + e], si = cs[X][1][4 * c + e];
+            const float uf = (float)u.v[e], vf = (float)v.v[e];
+            ou.v[e] = (T)(uf * co - vf * si);
+            ov.v[e] = (T)(vf * co + uf * si);
         }
+        *reinterpret_cast<Vec4<T>*>(pu) = ou;
+        *reinterpret_cast<Vec4<T>*>(pv) = ov;
     }
 }
 
@@ -135,17 +157,27 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, 
     }
 }
 
-// column mean: each block owns 64 columns; 4 waves split the rows, LDS combine.  Deterministic summation order.
+// column mean: each block owns 64 columns; its 4 waves split the rows (stride 4) with 4 independent accumulators per
+// thread for memory-level parallelism; partials are combined through LDS in fixed order (deterministic).
 __global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ x, int ldx, int M, int C, float* __restrict__ y) {
-    __shared__ float part[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < C)
-        for (int m = w; m < M; m += 4) s += x[(size_t)m * ldx + c];
-    part[w][lane] = s;
+    __shared__ float part[16][64];
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;      // 4 row groups per block
+    const int c = blockIdx.x * 64 + col;
+    // 4 independent accumulators per thread (ILP), rows strided by 16
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int m = rg;
+        for (; m + 12 < M; m += 16) {
+            s0 += x[(size_t)m * ldx + c];
+            s1 += x[(size_t)(m + 4) * ldx + c];
+            s2 += x[(size_t)(m + 8) * ldx + c];
+            s3 += x[(size_t)(m + 12) * ldx + c];
+        }
+        for (; m < M; m += 4) s0 += x[(size_t)m * ldx + c];
+    }
+    part[rg][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (w == 0 && c < C) y[c] = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)M;
+    if (rg == 0 && c < C) y[c] = (part[0][col] + part[1][col] + part[2][col] + part[3][col]) / (float)M;
 }
 
 // ------------------------------------------------------------------------------------------------- bilinear x2 (align_corners)
@@ -264,19 +296,37 @@ inline int grid_for(size_t total, int block = 256) {
 
 extern "C" int cut3r_abi_version(void) { return 1; }
 
-extern "C" int cut3r_rope2d(void* tokens, int dtype, const int64_t* positions, int B, int N, int H, int D, long long sB,
-                            long long sN, long long sH, float base, float fwd, void* stream) {
-    if (!tokens || !positions || B <= 0 || N <= 0 || H <= 0 || D <= 0 || (D & 3)) return CUT3R_ERR_ARG;
-    const int BN = B * N;
-    dim3 grid((BN + 3) / 4), block(256);
+static int launch_rope(void* tokens, void* tokens2, int dtype, const int64_t* positions, int B, int N, int H, int D, long long sB,
+                       long long sN, long long sH, long long sB2, long long sN2, float base, float fwd, void* stream) {
+    if (!tokens || !positions || B <= 0 || N <= 0 || H <= 0 || D <= 0 || (D & 15) || D > 256) return CUT3R_ERR_ARG;
+    if ((sB | sN | sH | sB2 | sN2) & 3) return CUT3R_ERR_ARG;        // 8/16-byte vector accesses
+    const int work = (tokens2 ? 2 : 1) * H * 2 * (D / 16);
+    int threads = ((work + 63) / 64) * 64;
+    if (threads < 64) threads = 64;
+    if (threads < D / 2) threads = ((D / 2 + 63) / 64) * 64;
+    if (threads > 256) threads = 256;
+    dim3 grid(B * N), block(threads);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == 0)
-        hipLaunchKernelGGL((rope2d_kernel<float>), grid, block, 0, s, (float*)tokens, positions, BN, N, H, D, sB, sN, sH, base, fwd);
+        hipLaunchKernelGGL((rope2d_kernel<float>), grid, block, 0, s, (float*)tokens, (float*)tokens2, positions, N, H, D, sB, sN, sH, sB2,
+                           sN2, base, fwd);
     else if (dtype == 1)
-        hipLaunchKernelGGL((rope2d_kernel<h16>), grid, block, 0, s, (h16*)tokens, positions, BN, N, H, D, sB, sN, sH, base, fwd);
+        hipLaunchKernelGGL((rope2d_kernel<h16>), grid, block, 0, s, (h16*)tokens, (h16*)tokens2, positions, N, H, D, sB, sN, sH, sB2, sN2,
+                           base, fwd);
     else
         return CUT3R_ERR_ARG;
     return cut3r_check_launch();
+}
+
+extern "C" int cut3r_rope2d(void* tokens, int dtype, const int64_t* positions, int B, int N, int H, int D, long long sB,
+                            long long sN, long long sH, float base, float fwd, void* stream) {
+    return launch_rope(tokens, nullptr, dtype, positions, B, N, H, D, sB, sN, sH, 0, 0, base, fwd, stream);
+}
+
+extern "C" int cut3r_rope2d_qk(void* q, void* k, int dtype, const int64_t* positions, int B, int N, int H, int D, long long q_sB,
+                               long long q_sN, long long k_sB, long long k_sN, float base, float fwd, void* stream) {
+    if (!k) return CUT3R_ERR_ARG;
+    return launch_rope(q, k, dtype, positions, B, N, H, D, q_sB, q_sN, D, k_sB, k_sN, base, fwd, stream);
 }
 
 extern "C" int cut3r_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int M, int C, void* y16,

@@ -241,8 +241,7 @@ class Cut3rModel:
         v5 = qkv.view(B, N, 3, heads, D)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
         if pos is not None:
-            self._rope(q, pos)
-            self._rope(k, pos)
+            ops.rope_2d_qk(q, k, pos, self.cfg.rope_freq, 1.0)
         a = self.buf(tag + ".attn", (B, N, heads, D), F16)
         ops.attention(q, k, v, a, D ** -0.5)
         self._linear(a.view(B * N, Cc), p + ".proj", out, res1=res)

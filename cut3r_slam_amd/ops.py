@@ -60,6 +60,8 @@ def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
         raise RuntimeError("positions are not contiguous")
     if D % 4 != 0:
         raise RuntimeError("token dim must be multiple of 4")
+    if D % 16 != 0:
+        raise RuntimeError("cut3r_slam_amd.rope_2d: head dims that are multiples of 16 only (CUT3R uses 16/32/48/64)")
     if positions.dtype != torch.int64:
         raise RuntimeError("positions must be int64")
     dt = {F32: 0, F16: 1}.get(tokens.dtype)
@@ -68,6 +70,22 @@ def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
     lib = _lib.load()
     check(lib.cut3r_rope2d(_p(tokens), dt, _p(positions), B, N, H, D, tokens.stride(0), tokens.stride(1),
                            tokens.stride(2), float(base), float(fwd), _stream()), "cut3r_rope2d")
+
+
+def rope_2d_qk(q, k, positions, base, fwd):
+    """rope_2d(q) and rope_2d(k) with shared positions in one launch (self-attention).  q,k: (B,N,H,D) views, head stride D."""
+    for t in (q, k):
+        if t.dim() != 4 or t.stride(3) != 1 or t.stride(2) != t.size(3) or not t.is_cuda:
+            raise RuntimeError("tokens are not contiguous")
+    B, N, H, D = q.shape
+    if k.shape != q.shape or positions.shape != (B, N, 2) or positions.dtype != torch.int64 or not positions.is_contiguous():
+        raise RuntimeError("rope_2d_qk: shape/dtype mismatch")
+    dt = {F32: 0, F16: 1}.get(q.dtype)
+    if dt is None or k.dtype != q.dtype:
+        raise RuntimeError(f"unsupported token dtype {q.dtype}")
+    lib = _lib.load()
+    check(lib.cut3r_rope2d_qk(_p(q), _p(k), dt, _p(positions), B, N, H, D, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                              float(base), float(fwd), _stream()), "cut3r_rope2d_qk")
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm

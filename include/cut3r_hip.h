@@ -20,10 +20,14 @@ int cut3r_abi_version(void);                         /* bumps when a signature c
 /* ---- RoPE-2D -------------------------------------------------------------------------------------------------
  * replaces curope.rope_2d(tokens, positions, base, fwd)  (src/croco/models/curope/curope.cpp:49-67,
  * kernels.cu:17-108).  In place on a (B,N,H,D) view: element (b,n,h,d) at tokens + b*sB + n*sN + h*sH + d
- * (strides in elements; the reference requires sH == D, stride(3) == 1).  positions: int64 [B,N,2] contiguous,
+ * (strides in elements, multiples of 4; the reference requires sH == D, stride(3) == 1; D % 16 == 0).  positions: int64 [B,N,2] contiguous,
  * may be negative.  dtype: 0 = fp32, 1 = fp16 (fp32 math, rounded on store -- the CUDA kernel's contract). */
 int cut3r_rope2d(void* tokens, int dtype, const int64_t* positions, int B, int N, int H, int D,
                  long long sB, long long sN, long long sH, float base, float fwd, void* stream);
+/* the two rope_2d calls of a self-attention (croco/models/blocks.py:127-128, dust3r/blocks.py:118-119: q then k, same
+ * positions) in ONE launch: head stride == D for both; cos/sin are evaluated once per token. */
+int cut3r_rope2d_qk(void* q, void* k, int dtype, const int64_t* positions, int B, int N, int H, int D, long long q_sB,
+                    long long q_sN, long long k_sB, long long k_sN, float base, float fwd, void* stream);
 
 /* ---- LayerNorm (+adaLN modulation) -------------------------------------------------------------------------
  * replaces nn.LayerNorm(eps=1e-6) calls in croco/models/blocks.py:187-190, dust3r/blocks.py:292-297 and
