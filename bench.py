@@ -56,7 +56,7 @@ class GemmProbe:
         def wrapped(dref, stream):
             d = dref._obj
             big = ((d.M + 127) // 128) * ((d.N + 127) // 128) * max(d.batch, 1)
-            if (d.tile == 128) or (d.tile == 0 and big >= 192):
+            if (d.tile == 128) or (d.tile == 0 and big >= 128):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 rc = raw(dref, stream)

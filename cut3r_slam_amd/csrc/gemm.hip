@@ -325,7 +325,7 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const long long big_blocks = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
     int tile = d->tile;
-    if (tile == 0) tile = (big_blocks >= 192) ? 128 : 64;
+    if (tile == 0) tile = (big_blocks >= 128) ? 128 : 64;     // measured crossover (tools/bench_gemm.py)
     if (tile == 128) {
         dim3 grid((d->N + 127) / 128, (d->M + 127) / 128, batch);
         if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<128, 128, 3>), grid, dim3(256), 0, s, g);
