@@ -114,6 +114,56 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Specialised LayerNorm for C == 256*NV (768 / 1024 / 1536: every width of the production network): compile-time trip
+// counts, the row AND gamma/beta are fetched up front (one memory round trip instead of two), 16-byte accesses.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fast_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, int M, h16* __restrict__ y16,
+                                                             int ld16, float* __restrict__ y32, int ld32,
+                                                             const float* __restrict__ mscale, const float* __restrict__ mshift) {
+    constexpr int C = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    f32x4 v[NV], g[NV], bt[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = *reinterpret_cast<const f32x4*>(xr + (lane + i * 64) * 4);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        g[i] = *reinterpret_cast<const f32x4*>(gamma + (lane + i * 64) * 4);
+        bt[i] = *reinterpret_cast<const f32x4*>(beta + (lane + i * 64) * 4);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const float d = v[i][e] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int c = (lane + i * 64) * 4;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = (v[i][e] - mean) * rstd * g[i][e] + bt[i][e];
+        if (mscale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(mscale + c);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(mshift + c);
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = o[e] * (1.0f + sc[e]) + sh[e];
+        }
+        if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * ld32 + c) = o;
+        if (y16) {
+            const half4_t ho = {(h16)o[0], (h16)o[1], (h16)o[2], (h16)o[3]};
+            *reinterpret_cast<half4_t*>(y16 + (size_t)row * ld16 + c) = ho;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------- im2col (patch embed)
 // out[(b, py, px), (c, iy, ix)] = img[b, c, py*P+iy, px*P+ix]; one thread per 8 contiguous ix.
 template <bool U8>
@@ -335,8 +385,16 @@ extern "C" int cut3r_layernorm(const float* x, int ldx, const float* gamma, cons
     if (!y16 && !y32) return CUT3R_ERR_ARG;
     if ((y16 && (ld16 & 3)) || (y32 && (ld32 & 3))) return CUT3R_ERR_ARG;
     if ((mod_scale == nullptr) != (mod_shift == nullptr)) return CUT3R_ERR_ARG;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, M, C,
-                       (h16*)y16, ld16, y32, ld32, mod_scale, mod_shift);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((M + 3) / 4), block(256);
+    if (C == 768)
+        hipLaunchKernelGGL((layernorm_fast_kernel<3>), grid, block, 0, s, x, ldx, gamma, beta, eps, M, (h16*)y16, ld16, y32, ld32, mod_scale, mod_shift);
+    else if (C == 1024)
+        hipLaunchKernelGGL((layernorm_fast_kernel<4>), grid, block, 0, s, x, ldx, gamma, beta, eps, M, (h16*)y16, ld16, y32, ld32, mod_scale, mod_shift);
+    else if (C == 1536)
+        hipLaunchKernelGGL((layernorm_fast_kernel<6>), grid, block, 0, s, x, ldx, gamma, beta, eps, M, (h16*)y16, ld16, y32, ld32, mod_scale, mod_shift);
+    else
+        hipLaunchKernelGGL(layernorm_kernel, grid, block, 0, s, x, ldx, gamma, beta, eps, M, C, (h16*)y16, ld16, y32, ld32, mod_scale, mod_shift);
     return cut3r_check_launch();
 }
 
