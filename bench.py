@@ -44,7 +44,7 @@ class GemmProbe:
     """HIP-event timing of every launch of the dominant kernel (tile-128 GEMM) on the launch stream."""
 
     def __init__(self):
-        self.ev, self.flops = [], 0.0
+        self.ev, self.flops, self.bytes = [], 0.0, 0.0
 
     def install(self):
         from cut3r_slam_amd import ops, _lib
@@ -63,6 +63,9 @@ class GemmProbe:
                 e.record()
                 probe.ev.append((s, e))
                 probe.flops += 2.0 * d.M * d.N * d.K * max(d.batch, 1)
+                a_bytes = (d.M * d.Cin * 2 / max(d.conv_stride, 1) ** 0) if d.conv_k == 3 else d.M * d.K * 2   # conv input is read once
+                probe.bytes += max(d.batch, 1) * (a_bytes + d.N * d.K * 2 + d.M * d.N * (2 if d.out_f16 else 4)
+                                                  + (d.M * d.N * (2 if d.res1_f16 else 4) if d.res1 else 0))
                 return rc
             return raw(dref, stream)
 
@@ -76,7 +79,7 @@ class GemmProbe:
         torch.cuda.synchronize()
         ms = sum(s.elapsed_time(e) for s, e in self.ev)
         n = len(self.ev)
-        return n, ms, self.flops
+        return n, ms, self.flops, self.bytes
 
 
 def log(msg):
@@ -198,14 +201,19 @@ def main():
             model.use_graphs = False      # events must bracket live launches, not a graph replay
             for _ in range(args.steps):
                 t = one_step(t)
-            n, ms, fl = probe.result()
+            n, ms, fl, by = probe.result()
             probe.remove()
             model.use_graphs = True
             if n:
                 ach = fl / (ms * 1e-3) / 1e12
+                traffic = None
+                pj = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_gemm128.json")
+                if os.path.isfile(pj):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/pmc_traffic.py)
+                    traffic = json.load(open(pj)).get("traffic_bytes_per_launch")
                 roofline = {"bound": "mfma", "kernel": "gemm_kernel<128,128,2,4,2> (v_mfma_f32_16x16x32_f16, 8 waves)", "achieved": round(ach, 2),
-                            "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
-                            "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n}
+                            "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
+                            "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n,
+                            "algorithmic_bytes_per_launch": by / n}
     if rank == 0 and not args.no_cpu_baseline and not args.small:
         log("cpu baseline (oracle on host cores)")
         cpu_base = cpu_baseline(cfg, sd, frames[:2].cpu(), frames_per_step)
