@@ -33,6 +33,7 @@ struct GemmArgs {
     int conv_k, H, W, Cin, cstride, Ho, Wo, relu_in;
     // pixel-shuffle scatter epilogue (ConvTranspose k == stride == shuf): n = (i*shuf + j)*Cout + co
     int shuf, shuf_cout, shuf_Hin, shuf_Win;
+    int swz;          // 1: 1-D grid with the XCD-aware tile rasterisation
 };
 
 DEVINL half8_t relu8(half8_t v) {
@@ -73,8 +74,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     const int z = blockIdx.z;
     const h16* __restrict__ A = g.A + (size_t)z * g.sA;
     const h16* __restrict__ Bm = g.B + (size_t)z * g.sB;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int M = g.M, N = g.N, K = g.K;
+    int pid_m, pid_n;
+    if (g.swz) {
+        // XCD-aware rasterisation (1-D grid): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+        // CONTIGUOUS range of tiles (bijective remap), then walk that range in bands of 8 row-tiles so neighbouring
+        // workgroups of one XCD share A row-panels and W column-panels in that XCD's L2.
+        const int npm = (M + BM - 1) / BM, npn = (N + BN - 1) / BN;
+        const int nwg = npm * npn;
+        const int orig = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        constexpr int GROUP = 8;
+        const int in_group = GROUP * npn;
+        const int group_id = wgid / in_group;
+        const int first_m = group_id * GROUP;
+        const int gsz = min(npm - first_m, GROUP);
+        const int rem = wgid - group_id * in_group;
+        pid_m = first_m + rem % gsz;
+        pid_n = rem / gsz;
+    } else {
+        pid_m = blockIdx.y;
+        pid_n = blockIdx.x;
+    }
+    const int m0 = pid_m * BM, n0 = pid_n * BN;
     const h16* zero = reinterpret_cast<const h16*>(g_zero16);
 
     // ---- per-thread loader coordinates (tile-invariant part)
@@ -182,11 +205,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
                 int r = wn * WN + j * 16 + fr;
                 fb[j] = *reinterpret_cast<const half8_t*>(sb + r * (BK * 2) + ((ch ^ (r & 7)) << 4));
             }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MT; i++)
 #pragma unroll
                 for (int j = 0; j < NT; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
         if (++stage == NSTAGE) stage = 0;
     }
@@ -321,6 +346,7 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     g.conv_k = d->conv_k; g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.cstride = d->conv_stride; g.Ho = d->Ho; g.Wo = d->Wo;
     g.relu_in = d->relu_in;
     g.shuf = d->shuf; g.shuf_cout = d->shuf_cout; g.shuf_Hin = d->shuf_Hin; g.shuf_Win = d->shuf_Win;
+    g.swz = 0;
     const int batch = d->batch > 0 ? d->batch : 1;
     hipStream_t s = (hipStream_t)stream;
     const long long big_blocks = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
@@ -328,6 +354,10 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     if (tile == 0) tile = (big_blocks >= 128) ? 128 : 64;     // measured crossover (tools/bench_gemm.py)
     if (tile == 128) {
         dim3 grid((d->N + 127) / 128, (d->M + 127) / 128, batch);
+        if (d->stages != 11) {         // 11 = tuning override: plain 2-D grid
+            g.swz = 1;
+            grid = dim3(grid.x * grid.y, 1, batch);
+        }
         if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<128, 128, 3>), grid, dim3(256), 0, s, g);
         else if (d->stages == 8) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 4>), grid, dim3(512), 0, s, g);   // 8 waves
         else if (d->stages == 9) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);   // 8 waves
