@@ -10,13 +10,16 @@
 //   * the S^T accumulator tile is converted in registers (fp32 -> packed fp16) and used directly as the B operand
 //     of O^T += V^T P^T (accumulator rows = MFMA k index; the k permutation inside a 16-step is folded into the
 //     V^T fragment addresses), so P never touches LDS.
-//   * K tile row-major in LDS (padded rows, conflict-free ds_read_b128); V tile stored transposed [d][key] so the
-//     A fragments of the second product are two ds_read_b64 per k-step.
+//   * K tile row-major in LDS (padded rows, conflict-free ds_read_b128); V tile ALSO row-major (16-byte staging
+//     writes) and consumed column-wise by the hardware transposing read ds_read_b64_tr_b16 (two per k-step), rows padded
+//     so that the 4-row x 16-column blocks of a 32-lane half fall on disjoint banks.
 //   * register prefetch of the next K/V tile overlaps the global loads with the MFMAs of the current tile.
 #include "common.h"
 #include "../../include/cut3r_hip.h"
 
 namespace {
+
+typedef __fp16 fp16x4_t __attribute__((ext_vector_type(4)));
 
 struct AttnArgs {
     const h16* q; const h16* k; const h16* v; h16* o;
@@ -32,11 +35,12 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
     constexpr int DQ = D / 16;                   // k-steps of the QK^T product
     constexpr int DP = (D + 31) / 32;            // 32-row d-tiles of the PV product
     constexpr int KS_LD = D + 8;                 // halves per K row in LDS (pad 16 B)
-    constexpr int VT_LD = KT + 4;                // halves per V^T row in LDS (pad 8 B)
+    constexpr int VS_BYTES = (64 * DP) % 128 == 0 ? 64 * DP + 64 : 64 * DP;   // V row stride: == 64 (mod 128) bytes
+    constexpr int V_LD = VS_BYTES / 2;           // halves per V row (DP*32 data/zero columns + pad)
     constexpr int CHUNKS = KT * (D / 8);         // 16-B chunks per K (or V) tile
     constexpr int NCH = (CHUNKS + NTHR - 1) / NTHR;
     __shared__ __attribute__((aligned(16))) h16 Ks[KT * KS_LD];
-    __shared__ __attribute__((aligned(16))) h16 Vt[DP * 32 * VT_LD];
+    __shared__ __attribute__((aligned(16))) h16 Vs[KT * V_LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -46,8 +50,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
     const h16* kp = a.k + (size_t)b * a.k_sb + (size_t)h * D;
     const h16* vp = a.v + (size_t)b * a.v_sb + (size_t)h * D;
 
-    // zero the V^T image once (covers the d >= D padding rows and the pad columns)
-    for (int i = tid; i < DP * 32 * VT_LD; i += NTHR) Vt[i] = (h16)0;
+    // zero the V image once (covers the d >= D padding columns read by the last d-tile)
+    for (int i = tid; i < KT * V_LD; i += NTHR) Vs[i] = (h16)0;
 
     // Q fragments (B operand: element j = Q[q0+r][16 s + 8 hh + j])
     half8_t qf[DQ];
@@ -91,8 +95,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
             if (id < CHUNKS) {
                 int key = id / (D / 8), ch = id - key * (D / 8);
                 *reinterpret_cast<half8_t*>(&Ks[key * KS_LD + ch * 8]) = rk[c];
-#pragma unroll
-                for (int j = 0; j < 8; j++) Vt[(ch * 8 + j) * VT_LD + key] = rv[c][j];
+                *reinterpret_cast<half8_t*>(&Vs[key * V_LD + ch * 8]) = rv[c];
             }
         }
     };
@@ -120,18 +123,25 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
         // ---- online softmax (per query column == per lane; partner lane^32 holds the other 32 keys)
         const int kbase = t * KT;
         float mloc = -INFINITY;
+        if (kbase + KT <= a.Nk) {                 // full tile: no masking
 #pragma unroll
-        for (int kt2 = 0; kt2 < 2; kt2++)
+            for (int kt2 = 0; kt2 < 2; kt2++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                int key = kbase + kt2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                float s = st[kt2][i] * a.scale_log2;
-                s = key < a.Nk ? s : -INFINITY;
-                st[kt2][i] = s;
-                mloc = fmaxf(mloc, s);
-            }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                for (int i = 0; i < 16; i++) mloc = fmaxf(mloc, st[kt2][i]);
+        } else {
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; kt2++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int key = kbase + kt2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    const float sv = key < a.Nk ? st[kt2][i] : -INFINITY;
+                    st[kt2][i] = sv;
+                    mloc = fmaxf(mloc, sv);
+                }
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * a.scale_log2;      // scale > 0: max commutes with the scaling
         const float m_new = fmaxf(m_run, mloc);
+        const bool grew = m_new > m_run;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float lsum = 0.f;
@@ -139,17 +149,22 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
         for (int kt2 = 0; kt2 < 2; kt2++)
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                float p = __builtin_amdgcn_exp2f(st[kt2][i] - m_new);
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[kt2][i], a.scale_log2, -m_new));
                 st[kt2][i] = p;
                 lsum += p;
             }
         l_run = l_run * alpha + lsum;
+        if (__any(grew)) {                        // wave-uniform: after the first tiles the running max rarely moves
 #pragma unroll
-        for (int d = 0; d < DP; d++)
+            for (int d = 0; d < DP; d++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) ot[d][i] *= alpha;
+                for (int i = 0; i < 16; i++) ot[d][i] *= alpha;
+        }
 
-        // ---- O^T += V^T P^T   (B fragment of k-step s2 = accumulator registers 8 s2 .. 8 s2 + 7)
+        // ---- O^T += V^T P^T   (B fragment of k-step s2 = accumulator registers 8 s2 .. 8 s2 + 7; A fragment = V^T via
+        //      two transposing reads: 16-lane group g = lane>>4 reads the 4-key x 16-d block (keys k0..k0+3, d-columns
+        //      c0..c0+15) with lane j of the group addressing row j>>2, columns 4(j&3).., and receives column j)
+        const int g16 = lane >> 4, j16 = lane & 15;
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; kt2++)
 #pragma unroll
@@ -159,10 +174,14 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
                 for (int j = 0; j < 8; j++) pf[j] = (h16)st[kt2][8 * s2 + j];
 #pragma unroll
                 for (int d = 0; d < DP; d++) {
-                    const h16* vrow = &Vt[(d * 32 + r) * VT_LD + kt2 * 32 + 16 * s2 + 4 * hh];
-                    half4_t lo = *reinterpret_cast<const half4_t*>(vrow);
-                    half4_t hi = *reinterpret_cast<const half4_t*>(vrow + 8);
-                    half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const int k0 = kt2 * 32 + 16 * s2 + 4 * (g16 >> 1);
+                    const int c0 = d * 32 + 16 * (g16 & 1);
+                    const h16* vp = &Vs[(k0 + (j16 >> 2)) * V_LD + c0 + 4 * (j16 & 3)];
+                    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vp));
+                    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vp + 8 * V_LD));
+                    half8_t vf;
+                    __builtin_memcpy(&vf, &lo, 8);
+                    __builtin_memcpy(reinterpret_cast<char*>(&vf) + 8, &hi, 8);
                     ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[d], 0, 0, 0);
                 }
             }

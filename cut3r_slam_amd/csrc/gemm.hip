@@ -34,6 +34,7 @@ struct GemmArgs {
     // pixel-shuffle scatter epilogue (ConvTranspose k == stride == shuf): n = (i*shuf + j)*Cout + co
     int shuf, shuf_cout, shuf_Hin, shuf_Win;
     int swz;          // 1: 1-D grid with the XCD-aware tile rasterisation
+    int prio;         // 1: s_setprio(1) around the MFMA cluster
 };
 
 DEVINL half8_t relu8(half8_t v) {
@@ -205,13 +206,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
                 int r = wn * WN + j * 16 + fr;
                 fb[j] = *reinterpret_cast<const half8_t*>(sb + r * (BK * 2) + ((ch ^ (r & 7)) << 4));
             }
-            __builtin_amdgcn_s_setprio(1);
+            if (g.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MT; i++)
 #pragma unroll
                 for (int j = 0; j < NT; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            if (g.prio) __builtin_amdgcn_s_setprio(0);
         }
         if (++stage == NSTAGE) stage = 0;
     }
@@ -347,6 +348,7 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     g.relu_in = d->relu_in;
     g.shuf = d->shuf; g.shuf_cout = d->shuf_cout; g.shuf_Hin = d->shuf_Hin; g.shuf_Win = d->shuf_Win;
     g.swz = 0;
+    g.prio = (d->stages == 12) ? 1 : 0;
     const int batch = d->batch > 0 ? d->batch : 1;
     hipStream_t s = (hipStream_t)stream;
     const long long big_blocks = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
@@ -354,7 +356,7 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     if (tile == 0) tile = (big_blocks >= 128) ? 128 : 64;     // measured crossover (tools/bench_gemm.py)
     if (tile == 128) {
         dim3 grid((d->N + 127) / 128, (d->M + 127) / 128, batch);
-        if (d->stages != 11) {         // 11 = tuning override: plain 2-D grid
+        if (d->stages == 13) {         // tuning override: XCD-aware rasterisation (measured: no gain while operands fit L2/MALL)
             g.swz = 1;
             grid = dim3(grid.x * grid.y, 1, batch);
         }

@@ -29,7 +29,7 @@ def timeit(fn, reps=50):
 
 def main():
     g = torch.Generator().manual_seed(0)
-    CFG = [(64, 3), (128, 9), (128, 11)]
+    CFG = [(128, 9), (128, 12), (128, 9), (128, 12)]
     print(f"{'shape':34s} " + " ".join(f"t{t}s{s:>1d}".rjust(12) for t, s in CFG))
     for M, N, K, label in SHAPES:
         A = torch.randn(M, K, generator=g).half().to(DEV)
@@ -50,7 +50,7 @@ def main():
         wk = (torch.randn(Cout, 9 * Cin, generator=g) / (9 * Cin) ** 0.5).half().to(DEV)
         out = torch.empty(B, H, W_, Cout, dtype=torch.float16, device=DEV)
         row = []
-        for tile, st in [(128, 9), (128, 11)]:
+        for tile, st in [(128, 9), (128, 12)]:
             ops.GEMM_STAGES = st
             us = timeit(lambda: ops.conv3x3_nhwc(x, wk, out, None, tile=tile), reps=10)
             row.append(f"t{tile}s{st} {us:8.1f}us/{2.0*B*H*W_*Cout*9*Cin/us/1e6:5.0f}T")
