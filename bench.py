@@ -108,16 +108,21 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    if world > 1 or os.environ.get("CUT3R_FORCE_DIST") == "1":
         args.window_batch = 1          # ranks already process their windows concurrently; one window per rank per step
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or os.environ.get("CUT3R_FORCE_DIST") == "1"     # the env flag rehearses the RCCL path with one rank
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from cut3r_slam_amd.config import production_config, tiny_config
     from cut3r_slam_amd.model import Cut3rModel
