@@ -108,8 +108,6 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 or os.environ.get("CUT3R_FORCE_DIST") == "1":
-        args.window_batch = 1          # ranks already process their windows concurrently; one window per rank per step
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or os.environ.get("CUT3R_FORCE_DIST") == "1"     # the env flag rehearses the RCCL path with one rank
@@ -142,18 +140,18 @@ def main():
     t_build = time.time() - t0
     log(f"model resident in HBM after {t_build:.1f}s")
 
-    frames_per_step = KF_EVERY * WIN * WB          # one step = WB windows
+    frames_per_step = KF_EVERY * WIN * WB          # per rank: one step = WB windows, pushed through the network together
     total_steps = args.warmup + args.steps
-    # rank r tracks its own windows: window w of step s is global window s*world + r
     probe_steps = 0 if (args.no_roofline or dist_on) else args.steps      # second, instrumented pass
-    n_kf = 6 + WIN * WB * ((total_steps + probe_steps) * world) + 2 + WIN * WB
-    n_frames = n_kf * KF_EVERY
+    n_kf = 7 + WIN * WB * world * (total_steps + probe_steps) + 2
     config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": KF_EVERY},
-                           "frontend": {"iteration": 0, "window_batch": WB if not dist_on else 1}}}
+                           "frontend": {"iteration": 0, "window_batch": 1}}}
     slam = Cut3rSlam(model, config, (H, W), buffer=n_kf + 8, device=dev)
     intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])  # calib/replica.txt scaled
-    runner = cdist.ShardedTracker(slam, world, rank) if dist_on else None
-    frames = synth_frames(n_frames if not dist_on else runner.frames_needed(total_steps, KF_EVERY, WIN), H, W, dev, seed=0)
+    # rank r owns windows [r*WB, (r+1)*WB) of every step; chaining + graph update of step s overlap the network pass of step s+1
+    runner = cdist.ShardedTracker(slam, world, rank, wb=WB, pipelined=os.environ.get("CUT3R_PIPELINE", "1") == "1",
+                                  force_collective=dist_on)
+    frames = synth_frames(runner.frames_needed(total_steps + probe_steps, KF_EVERY, WIN), H, W, dev, seed=0)
 
     # prologue (untimed): the 6-keyframe initialisation window
     log(f"{frames.shape[0]} synthetic frames resident; running the initialisation window")
@@ -165,12 +163,7 @@ def main():
     log("initialised; warmup")
 
     def one_step(t):
-        if dist_on:
-            return runner.step(frames, t, KF_EVERY, WIN, intr)
-        for _ in range(frames_per_step):
-            slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
-            t += 1
-        return t
+        return runner.step(frames, t, KF_EVERY, WIN, intr)
 
     def barrier():
         torch.cuda.synchronize()
@@ -180,11 +173,15 @@ def main():
 
     for _ in range(args.warmup):
         t = one_step(t)
+    runner.flush()
     barrier()
     log("timed region")
+    for k in runner.stats:
+        runner.stats[k] = 0
     tic = time.perf_counter()
     for _ in range(args.steps):
         t = one_step(t)
+    runner.flush()                       # the timed region holds exactly K network passes and K replays
     barrier()
     elapsed = time.perf_counter() - tic
     if dist_on:
@@ -194,18 +191,20 @@ def main():
     frames_total = frames_per_step * args.steps * world
     value = frames_total / elapsed
     log(f"timed region done: {elapsed:.3f}s for {frames_total} frames -> {value:.1f} frames/s")
+    log("host wall-clock per step [ms]: " + ", ".join(f"{k[:-2]} {1e3 * v / max(1, runner.stats['steps']):.2f}" for k, v in runner.stats.items() if k != "steps"))
 
     roofline, cpu_base = None, None
     if rank == 0 and not args.no_roofline and not dist_on:
         # second, instrumented pass over the same number of steps: HIP events around every launch of the dominant
         # kernel (tile-128 MFMA GEMM: encoder linears + DPT convolutions) on the launch stream
         need = frames_per_step * args.steps
-        if t + need <= frames.shape[0]:
+        if t + need + 1 <= frames.shape[0]:
             probe = GemmProbe()
             probe.install()
             model.use_graphs = False      # events must bracket live launches, not a graph replay
             for _ in range(args.steps):
                 t = one_step(t)
+            runner.flush()
             n, ms, fl, by = probe.result()
             probe.remove()
             model.use_graphs = True

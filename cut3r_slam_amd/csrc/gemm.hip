@@ -15,6 +15,7 @@
 // LDS so bias / residual / output traffic is 16-B coalesced.  Tile 128x128 with 8 waves (4x2; two waves per SIMD hide
 // each other's LDS-DMA issue: +25-30 % over 4 waves) for large grids, 64x64 when the grid would not fill 256 CUs
 // (batch-1 decoder GEMMs; 8 waves when K >= 2048).  blockIdx.z batches independent problems with element strides.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/cut3r_hip.h"
 
@@ -49,6 +50,74 @@ __device__ __attribute__((aligned(16))) unsigned char g_zero16[16];
 template <int N>
 DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Fused output of 4 consecutive columns (gn..gn+3) of row gm: bias, GELU|ReLU, up to two residuals, fp16|fp32 store,
+// optional ConvTranspose pixel-shuffle scatter.  Shared by every GEMM kernel of this file.
+DEVINL void fused_store4(const GemmArgs& g, int z, const float* bias, int gm, int gn, f32x4 v) {
+    int bcol = gn;
+    size_t orow_off;
+    if (g.shuf) {
+        const int ij = gn / g.shuf_cout;
+        bcol = gn - ij * g.shuf_cout;
+        const int i_ = ij / g.shuf, j_ = ij - i_ * g.shuf;
+        const int hw = g.shuf_Hin * g.shuf_Win;
+        const int b = gm / hw, rem = gm - b * hw;
+        const int y = rem / g.shuf_Win, x = rem - y * g.shuf_Win;
+        orow_off = (((size_t)b * g.shuf_Hin * g.shuf + (y * g.shuf + i_)) * (g.shuf_Win * g.shuf) + (x * g.shuf + j_)) *
+                       (size_t)g.ldc + bcol;
+    } else {
+        orow_off = (size_t)gm * g.ldc + gn;
+    }
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + bcol);
+    if (g.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+    } else if (g.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (g.res1) {
+        if (g.res1_f16) {
+            half4_t rv = *reinterpret_cast<const half4_t*>((const h16*)g.res1 + (size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += (float)rv[e];
+        } else {
+            v += *reinterpret_cast<const f32x4*>((const float*)g.res1 + (size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn);
+        }
+    }
+    if (g.res2) {
+        if (g.res2_f16) {
+            half4_t rv = *reinterpret_cast<const half4_t*>((const h16*)g.res2 + (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += (float)rv[e];
+        } else {
+            v += *reinterpret_cast<const f32x4*>((const float*)g.res2 + (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn);
+        }
+    }
+    if (g.out_f16) {
+        half4_t o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        *reinterpret_cast<half4_t*>((h16*)g.C + (size_t)z * g.sC + orow_off) = o;
+    } else {
+        *reinterpret_cast<f32x4*>((float*)g.C + (size_t)z * g.sC + orow_off) = v;
+    }
+}
+
+// XCD-aware rasterisation of a 1-D grid: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+// CONTIGUOUS range of tiles (bijective remap), then walk that range in bands of 8 row-tiles so neighbouring
+// workgroups of one XCD share A row-panels and W column-panels in that XCD's L2.
+DEVINL void xcd_tile(int orig, int npm, int npn, int& pid_m, int& pid_n) {
+    const int nwg = npm * npn;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    constexpr int GROUP = 8;
+    const int in_group = GROUP * npn;
+    const int group_id = wgid / in_group;
+    const int first_m = group_id * GROUP;
+    const int gsz = min(npm - first_m, GROUP);
+    const int rem = wgid - group_id * in_group;
+    pid_m = first_m + rem % gsz;
+    pid_n = rem / gsz;
+}
+
 // Loader: global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write).  One wave-instruction
 // writes 1 KiB = 8 tile rows x 128 B linearly; the XOR swizzle that makes the ds_read_b128 fragment reads
 // conflict-free is applied to the per-lane SOURCE chunk (lane l sits at row l>>3, chunk l&7 of its 8-row group and
@@ -78,22 +147,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     const int M = g.M, N = g.N, K = g.K;
     int pid_m, pid_n;
     if (g.swz) {
-        // XCD-aware rasterisation (1-D grid): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
-        // CONTIGUOUS range of tiles (bijective remap), then walk that range in bands of 8 row-tiles so neighbouring
-        // workgroups of one XCD share A row-panels and W column-panels in that XCD's L2.
-        const int npm = (M + BM - 1) / BM, npn = (N + BN - 1) / BN;
-        const int nwg = npm * npn;
-        const int orig = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-        const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        constexpr int GROUP = 8;
-        const int in_group = GROUP * npn;
-        const int group_id = wgid / in_group;
-        const int first_m = group_id * GROUP;
-        const int gsz = min(npm - first_m, GROUP);
-        const int rem = wgid - group_id * in_group;
-        pid_m = first_m + rem % gsz;
-        pid_n = rem / gsz;
+        xcd_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, pid_m, pid_n);
     } else {
         pid_m = blockIdx.y;
         pid_n = blockIdx.x;
@@ -241,57 +295,229 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     for (int r = tid / TPR; r < BM; r += RPP) {
         const int gm = m0 + r;
         if (gm >= M) break;
-        f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
-        int bcol = gn;
-        size_t orow_off;
-        if (g.shuf) {
-            const int ij = gn / g.shuf_cout;
-            bcol = gn - ij * g.shuf_cout;
-            const int i_ = ij / g.shuf, j_ = ij - i_ * g.shuf;
-            const int hw = g.shuf_Hin * g.shuf_Win;
-            const int b = gm / hw, rem = gm - b * hw;
-            const int y = rem / g.shuf_Win, x = rem - y * g.shuf_Win;
-            orow_off = (((size_t)b * g.shuf_Hin * g.shuf + (y * g.shuf + i_)) * (g.shuf_Win * g.shuf) + (x * g.shuf + j_)) *
-                           (size_t)g.ldc + bcol;
-        } else {
-            orow_off = (size_t)gm * g.ldc + gn;
-        }
-        if (bias) {
-            f32x4 bv = *reinterpret_cast<const f32x4*>(bias + bcol);
-            v += bv;
-        }
-        if (g.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
-        } else if (g.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (g.res1) {
-            if (g.res1_f16) {
-                half4_t rv = *reinterpret_cast<const half4_t*>((const h16*)g.res1 + (size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn);
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] += (float)rv[e];
-            } else {
-                v += *reinterpret_cast<const f32x4*>((const float*)g.res1 + (size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn);
-            }
-        }
-        if (g.res2) {
-            if (g.res2_f16) {
-                half4_t rv = *reinterpret_cast<const half4_t*>((const h16*)g.res2 + (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn);
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] += (float)rv[e];
-            } else {
-                v += *reinterpret_cast<const f32x4*>((const float*)g.res2 + (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn);
-            }
-        }
-        if (g.out_f16) {
-            half4_t o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
-            *reinterpret_cast<half4_t*>((h16*)g.C + (size_t)z * g.sC + orow_off) = o;
-        } else {
-            *reinterpret_cast<f32x4*>((float*)g.C + (size_t)z * g.sC + orow_off) = v;
-        }
+        fused_store4(g, z, bias, gm, gn, *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4));
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 x 4, 128 x 64 outputs per wave), ping-pong schedule: the kernel for the large GEMMs
+// (ViT-L encoder linears at batch >= 8 keyframes, DPT 3x3 convolutions, decoder linears at window batch >= 8).
+//
+// Why a second tile: a 128^2 tile moves (128+128)*64*2 B from L2 into LDS per 2.1 MFLOP (64 FLOP/B); measured on
+// MI355X the L2->LDS path delivers ~45-50 GB/s per CU, which caps that tile near 700-800 TFLOP/s whatever the MFMA
+// schedule does.  256^2 halves the bytes per FLOP, and one workgroup per CU with 128 KiB of LDS is the natural
+// occupancy for it; latency is then hidden inside the workgroup instead of by a co-resident one:
+//   * waves 0-3 (wr = 0) and waves 4-7 (wr = 1) share the 4 SIMDs pairwise and run ONE s_barrier apart: while one
+//     group is in a 16-MFMA section (a 64 x 32 quadrant of its outputs x K = 64) the other group is in its load
+//     section (ds_read_b128 fragment reads + 2 LDS-DMA pieces), so each SIMD's matrix pipe always has a feeder;
+//   * a K-tile is staged as four 16-KiB units ordered by first use: U0 = A rows of quadrant-row 0, U1 = B rows
+//     (output columns) of quadrant-column 0, U2 = B of quadrant-column 1, U3 = A of quadrant-row 1; two K-tiles of
+//     LDS (2 x 64 KiB).  Phase p of K-tile t reads {U0,U1 | U2 | U3 | -} and re-stages {U2(t+1) | U3(t+1) | U0(t+2) |
+//     U1(t+2)}: every unit is overwritten >= 2 phases (4 barriers) after its last ds_read has been retired (WAR) and
+//     is issued >= 4 phases before its first read; ONE counted wait per K-tile (phase 3: s_waitcnt vmcnt(4), two
+//     units stay in flight across the barriers) retires it a full phase + barrier before that read (RAW).
+//   * B fragments of both quadrant-columns stay in registers, so a K-tile costs 24 ds_read_b128 per wave for 64
+//     MFMAs (LDS array ~45 % busy incl. the DMA writes).
+// Epilogue: each wave stages its own 128 x 64 block through its private 16 KiB of LDS (no workgroup barrier) and
+// stores full 128/256-B row segments through fused_store4.
+#ifndef EPI_UNROLL
+#define EPI_UNROLL 1
+#endif
+template <bool CONV3, bool RELU_IN>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) {
+    constexpr int UNIT = 128 * BK * 2;      // 16 KiB: 128 rows x 64 halfs
+    constexpr int BUF = 4 * UNIT;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int z = blockIdx.z;
+    const h16* __restrict__ A = g.A + (size_t)z * g.sA;
+    const h16* __restrict__ Bm = g.B + (size_t)z * g.sB;
+    const int M = g.M, N = g.N, K = g.K;
+    int pid_m, pid_n;
+    xcd_tile(blockIdx.x, (M + 255) / 256, (N + 255) / 256, pid_m, pid_n);
+    const int m0 = pid_m * 256, n0 = pid_n * 256;
+    const h16* zero = reinterpret_cast<const h16*>(g_zero16);
+
+    // ---- loader coordinates: the two LDS-DMA pieces a thread contributes to a unit cover unit rows u0 and u0 + 64
+    const int lrow = lane >> 3;
+    const int csrc = (lane & 7) ^ lrow;            // swizzled source chunk (unit rows are 8-aligned per piece)
+    const h16* a_ptr[2][2];                        // [quadrant-row][piece]
+    int a_oy[2][2], a_ox[2][2];
+    bool a_ok[2][2];
+    const h16* b_ptr[2][2];                        // [quadrant-column][piece]
+    bool b_ok[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int u = (wave + 8 * i) * 8 + lrow;                       // unit row 0..127
+            const int gm = m0 + (u >> 6) * 128 + q * 64 + (u & 63);        // A unit row -> wave-row block wr = u>>6
+            a_ok[q][i] = gm < M;
+            if (CONV3) {
+                const int gmc = a_ok[q][i] ? gm : 0;
+                const int hw = g.Ho * g.Wo;
+                const int b = gmc / hw, rem = gmc - b * hw;
+                const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+                a_oy[q][i] = oy * g.cstride - 1;
+                a_ox[q][i] = ox * g.cstride - 1;
+                a_ptr[q][i] = A + (size_t)b * g.H * g.W * g.Cin;
+            } else {
+                a_oy[q][i] = a_ox[q][i] = 0;
+                a_ptr[q][i] = A + (size_t)(a_ok[q][i] ? gm : 0) * g.lda;
+            }
+            const int gn = n0 + (u >> 5) * 64 + q * 32 + (u & 31);         // B unit row -> wave-column block wc = u>>5
+            b_ok[q][i] = gn < N;
+            b_ptr[q][i] = Bm + (size_t)(b_ok[q][i] ? gn : 0) * g.ldb;
+        }
+
+    const int nt = (K + BK - 1) / BK;
+    // unit U of K-tile kt -> LDS-DMA (skipped past the last tile; the vmcnt below accounts for that)
+    auto issue_a = [&](int q, int kt, int unit) {
+        if (kt >= nt) return;
+        unsigned char* slot = smem + (kt & 1) * BUF + unit * UNIT;
+        const int k = kt * BK + csrc * 8;
+        const bool kok = k < K;
+        int ci = 0, dy = 0, dx = 0;
+        if (CONV3) {
+            const int tap = k / g.Cin;
+            ci = k - tap * g.Cin;
+            dy = tap / 3; dx = tap - dy * 3;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const h16* src = zero;
+            if (CONV3) {
+                const int iy = a_oy[q][i] + dy, ix = a_ox[q][i] + dx;
+                if (kok && a_ok[q][i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                    src = a_ptr[q][i] + ((size_t)iy * g.W + ix) * g.Cin + ci;
+            } else if (kok && a_ok[q][i]) {
+                src = a_ptr[q][i] + k;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(slot + (wave + 8 * i) * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_b = [&](int q, int kt, int unit) {
+        if (kt >= nt) return;
+        unsigned char* slot = smem + (kt & 1) * BUF + unit * UNIT;
+        const int k = kt * BK + csrc * 8;
+        const bool kok = k < K;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const h16* src = (kok && b_ok[q][i]) ? b_ptr[q][i] + k : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(slot + (wave + 8 * i) * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a unit): row = block*16*i + fr, 16-B chunk (kk*4 + fq) ^ (row & 7)
+    const int fr = lane & 15, fq = lane >> 4;
+    const int offk0 = fr * 128 + (((0 + fq) ^ (fr & 7)) << 4);
+    const int offk1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);
+    const int a_base = wr * 64 * 128;              // this wave's 64 rows inside an A unit
+    const int b_base = wc * 32 * 128;              // this wave's 32 rows inside a B unit
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    half8_t fa[4][2], fb0[2][2], fb1[2][2];
+
+    auto read_a = [&](const unsigned char* unit) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            fa[i][0] = *reinterpret_cast<const half8_t*>(unit + a_base + i * 2048 + offk0);
+            fa[i][1] = *reinterpret_cast<const half8_t*>(unit + a_base + i * 2048 + offk1);
+            if (RELU_IN) { fa[i][0] = relu8(fa[i][0]); fa[i][1] = relu8(fa[i][1]); }
+        }
+    };
+    auto read_b = [&](const unsigned char* unit, half8_t (&fb)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            fb[j][0] = *reinterpret_cast<const half8_t*>(unit + b_base + j * 2048 + offk0);
+            fb[j][1] = *reinterpret_cast<const half8_t*>(unit + b_base + j * 2048 + offk1);
+        }
+    };
+#define CUT3R_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define CUT3R_QUADRANT(I0, J0, FB)                                                                              \
+    do {                                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        _Pragma("unroll") for (int kk = 0; kk < 2; kk++)                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; i++)                                                        \
+                _Pragma("unroll") for (int j = 0; j < 2; j++)                                                    \
+                    acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][kk], FB[j][kk], acc[I0 + i][J0 + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+    } while (0)
+
+    // ---- prologue: K-tile 0 complete, U0/U1 of K-tile 1 in flight
+    issue_a(0, 0, 0); issue_b(0, 0, 1); issue_b(1, 0, 2); issue_a(1, 0, 3);
+    issue_a(0, 1, 0); issue_b(0, 1, 1);
+    if (nt > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    CUT3R_BARRIER();
+    if (wr == 1) CUT3R_BARRIER();          // stagger: the second wave group runs one barrier behind the first
+
+    for (int t = 0; t < nt; t++) {
+        const unsigned char* buf = smem + (t & 1) * BUF;
+        // phase 0: quadrant (0,0)
+        read_a(buf);
+        read_b(buf + UNIT, fb0);
+        issue_b(1, t + 1, 2);
+        CUT3R_BARRIER();
+        CUT3R_QUADRANT(0, 0, fb0);
+        CUT3R_BARRIER();
+        // phase 1: quadrant (0,1)
+        read_b(buf + 2 * UNIT, fb1);
+        issue_a(1, t + 1, 3);
+        CUT3R_BARRIER();
+        CUT3R_QUADRANT(0, 2, fb1);
+        CUT3R_BARRIER();
+        // phase 2: quadrant (1,1)
+        read_a(buf + 3 * UNIT);
+        issue_a(0, t + 2, 0);
+        CUT3R_BARRIER();
+        CUT3R_QUADRANT(4, 2, fb1);
+        CUT3R_BARRIER();
+        // phase 3: quadrant (1,0); the one counted wait of the K-tile retires every unit of K-tile t+1
+        issue_b(0, t + 2, 1);
+        if (t + 2 < nt) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        CUT3R_BARRIER();
+        CUT3R_QUADRANT(4, 0, fb0);
+        CUT3R_BARRIER();
+    }
+    if (wr == 0) CUT3R_BARRIER();          // re-join the two groups: every ds_read of the workgroup has been consumed
+#undef CUT3R_QUADRANT
+
+    // ---- epilogue: per-wave staging (32 rows x 64 columns per pass) in this wave's private 16 KiB
+    // (measured alternative: operand-swapped MFMAs + direct 8-byte stores from the accumulators -- 32-B row segments,
+    //  +8 us per tile)
+    constexpr int CP = 68;
+    float* cs = reinterpret_cast<float*>(smem + wave * 16384);
+    const float* bias = g.bias ? g.bias + (size_t)z * g.sBias : nullptr;
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+    const int gn = n0 + wc * 64 + ec;
+#pragma unroll
+    for (int mp = 0; mp < 4; mp++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) cs[(i * 16 + fq * 4 + e) * CP + j * 16 + fr] = acc[mp * 2 + i][j][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (gn < N) {
+#pragma unroll EPI_UNROLL
+            for (int it = 0; it < 8; it++) {
+                const int rr = it * 4 + er;
+                const int gm = m0 + wr * 128 + mp * 32 + rr;
+                if (gm < M) fused_store4(g, z, bias, gm, gn, *reinterpret_cast<const f32x4*>(cs + rr * CP + ec));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#undef CUT3R_BARRIER
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -354,9 +580,16 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     const long long big_blocks = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
     int tile = d->tile;
     if (tile == 0) tile = (big_blocks >= 128) ? 128 : 64;     // measured crossover (tools/bench_gemm.py)
-    if (tile == 128) {
+    if (tile == 256) {
+        dim3 grid(((d->N + 255) / 256) * ((d->M + 255) / 256), 1, batch);
+        if (d->conv_k == 3 && d->relu_in) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, dim3(512), 0, s, g);
+        else if (d->conv_k == 3) hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, dim3(512), 0, s, g);
+        else if (d->relu_in) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, dim3(512), 0, s, g);
+    } else if (tile == 128) {
         dim3 grid((d->N + 127) / 128, (d->M + 127) / 128, batch);
-        if (d->stages == 13) {         // tuning override: XCD-aware rasterisation (measured: no gain while operands fit L2/MALL)
+        static const long long swz_min = [] { const char* e = getenv("CUT3R_GEMM_SWZ_MIN"); return e ? atoll(e) : 200LL; }();
+        if (d->stages == 13 || (d->stages == 0 && (long long)grid.x * grid.y >= swz_min)) {   // XCD-aware rasterisation
             g.swz = 1;
             grid = dim3(grid.x * grid.y, 1, batch);
         }

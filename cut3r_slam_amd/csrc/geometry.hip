@@ -124,6 +124,109 @@ __global__ __launch_bounds__(256) void logdepth_kernel(const float* __restrict__
     if (threadIdx.x == 0) atomicAdd(out, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
 }
 
+// ------------------------------------------------------------------------------------------------ whole-window update
+// One tracking window = V consecutive keyframes t0..t0+V-1 whose network outputs sit in one [V,H,W,*] block.  The
+// per-view launches above (2 align + memset + fwd + memset + bwd per keyframe, ~35 launches per window) become FOUR
+// launches; per-element arithmetic is the same code (align chain, proj_valid), so every count is unchanged.
+struct WinArgs { float P[6][12]; float s; int V, t0, first; };
+
+__global__ __launch_bounds__(256) void win_align_kernel(const float* __restrict__ pts, const float* __restrict__ conf, int H, int W,
+                                                        WinArgs wa, int ds, float* __restrict__ pm_ds, float* __restrict__ conf_ds,
+                                                        float* __restrict__ depth) {
+    const int v = blockIdx.y;
+    const size_t n = (size_t)H * W;
+    const float* p = pts + (size_t)v * n * 3;
+    const float* c = conf + (size_t)v * n;
+    float* d = depth + (size_t)v * n;
+    const float s = wa.s;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s * p[3 * i + 2];
+    const int Hd = H / ds, Wd = W / ds;
+    const size_t total = (size_t)Hd * Wd;
+    const float* P = wa.P[v];
+    float* po = pm_ds + (size_t)v * total * 3;
+    float* co = conf_ds + (size_t)v * total;
+    for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(o / Wd), x = (int)(o - (size_t)y * Wd);
+        const size_t i = (size_t)(y * ds) * W + (size_t)(x * ds);
+        const float px = s * p[3 * i], py = s * p[3 * i + 1], pz = s * p[3 * i + 2];
+        po[3 * o + 0] = fmaf(P[2], pz, fmaf(P[1], py, fmaf(P[0], px, P[3])));
+        po[3 * o + 1] = fmaf(P[6], pz, fmaf(P[5], py, fmaf(P[4], px, P[7])));
+        po[3 * o + 2] = fmaf(P[10], pz, fmaf(P[9], py, fmaf(P[8], px, P[11])));
+        co[o] = 1.0f - 1.0f / c[i];
+    }
+}
+
+// forward counts of every keyframe of the window: blockIdx.y = view v, keyframe i = t0 + v sees cameras 0..i-1
+__global__ __launch_bounds__(256) void win_fwd_kernel(const float* __restrict__ pts, int N, const float* __restrict__ w2c, Cam cam,
+                                                      int32_t* __restrict__ counts, int ldc, WinArgs wa) {
+    __shared__ int32_t cnt[OVL_MAXB];
+    const int v = blockIdx.y, kfi = wa.t0 + v;
+    if (kfi < wa.first) return;
+    const int B = kfi;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int p = blockIdx.x * 256 + tid;
+    const bool ok = p < N;
+    const float* pm = pts + (size_t)v * N * 3;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (ok) { x = pm[3 * (size_t)p]; y = pm[3 * (size_t)p + 1]; z = pm[3 * (size_t)p + 2]; }
+    {
+        const float* P = wa.P[v];
+        const float px = wa.s * x, py = wa.s * y, pz = wa.s * z;
+        x = fmaf(P[2], pz, fmaf(P[1], py, fmaf(P[0], px, P[3])));
+        y = fmaf(P[6], pz, fmaf(P[5], py, fmaf(P[4], px, P[7])));
+        z = fmaf(P[10], pz, fmaf(P[9], py, fmaf(P[8], px, P[11])));
+    }
+    int32_t* out = counts + (size_t)v * 2 * ldc;
+    for (int b0 = 0; b0 < B; b0 += OVL_MAXB) {
+        const int nb = min(OVL_MAXB, B - b0);
+        for (int i = tid; i < nb; i += 256) cnt[i] = 0;
+        __syncthreads();
+        for (int b = 0; b < nb; b++) {
+            const int ins = ok ? proj_valid(w2c + 12 * (size_t)(b0 + b), x, y, z, cam, true) : 0;
+            const unsigned long long bal = __ballot(ins);
+            if (lane == 0) atomicAdd(&cnt[b], (int)__popcll(bal));
+        }
+        __syncthreads();
+        for (int i = tid; i < nb; i += 256)
+            if (cnt[i]) atomicAdd(&out[b0 + i], cnt[i]);
+        __syncthreads();
+    }
+}
+
+// backward counts: blockIdx.z = view v (camera of keyframe i = t0 + v), blockIdx.y = stored pointmap b < i
+__global__ __launch_bounds__(256) void win_bwd_kernel(const float* __restrict__ pms, int N, int grp, int grp_stride,
+                                                      const float* __restrict__ w2c, Cam cam, int32_t* __restrict__ counts, int ldc,
+                                                      WinArgs wa) {
+    __shared__ int32_t wsum[4];
+    __shared__ float m[12];
+    const int v = blockIdx.z, kfi = wa.t0 + v, b = blockIdx.y;
+    if (kfi < wa.first || b >= kfi) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 12) m[tid] = w2c[12 * (size_t)kfi + tid];
+    __syncthreads();
+    const int slot = grp > 0 ? (b / grp) * grp_stride + (b % grp) : b;
+    const float* pm = pms + (size_t)slot * N * 3;
+    int c = 0;
+    const int nquad = N >> 2;
+    for (int qd = blockIdx.x * 256 + tid; qd < nquad; qd += gridDim.x * 256) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(pm + (size_t)qd * 12);
+        const f32x4 a = p4[0], bb = p4[1], cc = p4[2];
+        c += proj_valid(m, a[0], a[1], a[2], cam, false);
+        c += proj_valid(m, a[3], bb[0], bb[1], cam, false);
+        c += proj_valid(m, bb[2], bb[3], cc[0], cam, false);
+        c += proj_valid(m, cc[1], cc[2], cc[3], cam, false);
+    }
+    if (blockIdx.x == 0)
+        for (int p = (nquad << 2) + tid; p < N; p += 256) c += proj_valid(m, pm[3 * p], pm[3 * p + 1], pm[3 * p + 2], cam, false);
+    c = wave_sum_i(c);
+    if (lane == 0) wsum[wave] = c;
+    __syncthreads();
+    if (tid == 0) {
+        const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t) atomicAdd(&counts[(size_t)v * 2 * ldc + ldc + b], t);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ patch overlap
 // F.normalize(x, dim=1): x / max(||x||, 1e-12); one wave per row; rows 1.. only (row 0 dropped by the reference).
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ f, int Nv, int C, float* __restrict__ out) {
@@ -228,6 +331,37 @@ extern "C" int cut3r_align_view(const float* pts, const float* conf, int H, int 
     hipLaunchKernelGGL(align_depth_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, st, pts, H * W, s, depth);
     hipLaunchKernelGGL(align_ds_kernel, dim3(grid_for((size_t)(H / ds) * (W / ds))), dim3(256), 0, st, pts, conf, H, W, a, ds, pm_ds,
                        conf_ds);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_window_update(const float* pts, const float* conf, int V, int H, int W, const float* P_host, float s, int ds,
+                                   float* pm_ds, float* conf_ds, float* depth, const float* store, int grp, int grp_stride,
+                                   const float* w2c, int t0, int first, float fx, float fy, float cx, float cy,
+                                   int32_t* counts, int ldc, void* stream) {
+    if (!pts || !conf || !P_host || !pm_ds || !conf_ds || !depth || !store || !w2c || !counts) return CUT3R_ERR_ARG;
+    if (V < 1 || V > 6 || H <= 0 || W <= 0 || ds <= 0 || t0 < 0 || ldc < t0 + V || grp < 0 || (grp > 0 && grp_stride < grp)) return CUT3R_ERR_ARG;
+    const int Nd = (H / ds) * (W / ds);
+    if (((uintptr_t)store & 15) || (((size_t)Nd * 12) & 15)) return CUT3R_ERR_ARG;
+    WinArgs wa;
+    for (int v = 0; v < V; v++)
+        for (int i = 0; i < 12; i++) wa.P[v][i] = P_host[v * 12 + i];
+    wa.s = s; wa.V = V; wa.t0 = t0; wa.first = first;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(win_align_kernel, dim3(grid_for((size_t)H * W), V), dim3(256), 0, st, pts, conf, H, W, wa, ds, pm_ds, conf_ds, depth);
+    const int last = t0 + V - 1;                  // newest keyframe: it sees cameras / pointmaps 0..last-1
+    if (last >= first && last >= 1) {
+        if (hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)V * 2 * ldc, st) != hipSuccess) return CUT3R_ERR_LAUNCH;
+        Cam camf{fx, fy, cx, cy, W, H};
+        hipLaunchKernelGGL(win_fwd_kernel, dim3((H * W + 255) / 256, V), dim3(256), 0, st, pts, H * W, w2c, camf, counts, ldc, wa);
+        // the reference tests the stored (stride-ds) pointmaps against the bounds of the DOWNSAMPLED map with the
+        // full-resolution intrinsics (factor_graph.py:284-315 takes H, W from pointmap_i.shape: quirk kept)
+        Cam camb{fx, fy, cx, cy, W / ds, H / ds};
+        int gx = ((Nd >> 2) + 255) / 256;
+        if (gx < 1) gx = 1;
+        if (gx > 64) gx = 64;
+        if (last > 65535) return CUT3R_ERR_ARG;
+        hipLaunchKernelGGL(win_bwd_kernel, dim3(gx, last, V), dim3(256), 0, st, store, Nd, grp, grp_stride, w2c, camb, counts, ldc, wa);
+    }
     return cut3r_check_launch();
 }
 

@@ -1,84 +1,156 @@
-"""Multi-GPU tracking: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the
-CPU tests).
+"""Throughput driver of the tracking loop: window-sharded across GPUs and software-pipelined on each GPU.
+
+One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 What shards: every `inference()` call re-initialises the recurrent state and the pose memory
 (/root/reference/src/dust3r/model.py:819-822), so tracking WINDOWS are independent network evaluations; only the cheap
 post-hoc chaining (/root/reference/hislam2/track_frontend.py:216-234: needs the previous window's last depth and pose)
-and the graph update are sequential.  So per step each rank runs the ViT on ONE window (its 5 keyframe-filter encodes
-+ the 6-view inference), the three consumed outputs (pts3d_in_self_view, conf_self, camera_pose) are exchanged with
-ONE all_gather per tensor (19 MB per rank at 384x512 -- small messages: latency, not ring bandwidth, matters), and
-every rank replays the chaining + graph update of the N windows in sequence order, keeping the keyframe store and the
-graph replicated (no second collective, and any rank can serve the trajectory).
+and the graph update are sequential.  Per step every rank pushes `wb` consecutive windows through the network in one
+batched pass (encoder for its new keyframes, decoder + heads batched over the windows), the three consumed outputs
+(pts3d_in_self_view, conf_self, camera_pose: 19 MB per window at 384x512) are exchanged with ONE all_gather per tensor
+-- small messages: latency, not ring bandwidth, matters -- and every rank replays the chaining + graph update of all
+world*wb windows in sequence order, keeping the keyframe store and the graph replicated (no second collective; any rank
+can serve the trajectory).
+
+Pipelining: the replay of step s runs on a side HIP stream while the network pass of step s+1 is already executing on
+the main stream (the replay is host-latency-bound: tiny kernels + small device->host reads), so a step costs
+max(network time, replay time) instead of their sum.  `flush()` drains the last replay.
 """
 from __future__ import annotations
 
+import contextlib
+import os
+import time
 from typing import Callable, List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
-def window_ranges(first_t0: int, world: int, win: int = 5) -> List[Tuple[int, int]]:
-    """keyframe ranges [t0, t1) of the `world` windows of one step; consecutive windows share one keyframe."""
-    return [(first_t0 + win * j, first_t0 + win * j + win + 1) for j in range(world)]
+def window_ranges(first_t0: int, count: int, win: int = 5) -> List[Tuple[int, int]]:
+    """keyframe ranges [t0, t1) of `count` consecutive windows; consecutive windows share one keyframe."""
+    return [(first_t0 + win * j, first_t0 + win * j + win + 1) for j in range(count)]
 
 
-def all_gather_outputs(outs: Sequence[torch.Tensor], world: int) -> List[List[torch.Tensor]]:
-    """outs: this rank's tensors (same shapes on every rank).  Returns per-rank lists, in rank order."""
-    gathered = []
+def all_gather_outputs(outs: Sequence[torch.Tensor], world: int, force_collective: bool = False) -> List[torch.Tensor]:
+    """outs: this rank's tensors (same shapes on every rank, leading dim = its windows*views).  Returns each tensor
+    concatenated over ranks in rank order.  world == 1: private copies (the network outputs are static graph buffers
+    that the next replay overwrites)."""
+    if not dist.is_initialized() or (world == 1 and not force_collective):
+        return [t.clone() for t in outs]
+    res = []
     for t in outs:
         t = t.contiguous()
-        buf = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         if t.is_cuda:
+            buf = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
             dist.all_gather_into_tensor(buf.view(-1), t.view(-1))       # one RCCL all-gather per tensor
         else:
             parts = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(parts, t)                                   # gloo (CPU tests)
             buf = torch.stack(parts, 0)
-        gathered.append(buf)
-    return [[g[r] for g in gathered] for r in range(world)]
+        res.append(buf.reshape((world * t.shape[0],) + tuple(t.shape[1:])))
+    return res
 
 
 class ShardedTracker:
-    """Drives a replicated `Cut3rSlam` with window-sharded network inference."""
+    """Drives a replicated `Cut3rSlam` with window-sharded, batched, pipelined network inference."""
 
-    def __init__(self, slam, world: int, rank: int, infer_fn: Callable = None, track_fn: Callable = None,
-                 append_fn: Callable = None):
-        self.slam, self.world, self.rank = slam, world, rank
-        self.infer_fn = infer_fn or (lambda t0, t1: slam.tracker.infer(t0=t0, t1=t1))
+    def __init__(self, slam, world: int, rank: int, wb: int = 1, infer_fn: Callable = None, track_fn: Callable = None,
+                 append_fn: Callable = None, pipelined: bool = True, views: int = 6, force_collective: bool = False):
+        self.slam, self.world, self.rank, self.wb = slam, world, rank, max(1, int(wb))
+        self.infer_fn = infer_fn or self._infer
         self.track_fn = track_fn or (lambda t0, t1, outs: slam.tracker.track(t0, t1, outputs=outs))
         self.append_fn = append_fn or self._append
+        self.pipelined = pipelined
+        self.views = views
+        self.force_collective = force_collective    # world == 1 rehearsal of the RCCL exchange
+        self._pending = None
+        self._next_t0 = None            # first keyframe of the next window to be scheduled
+        self._side = None
+        self.side_priority = int(os.environ.get("CUT3R_SIDE_PRIORITY", "-1"))         # side stream on its own high-priority hardware queue
+        self.stats = {"issue_s": 0.0, "replay_s": 0.0, "exchange_s": 0.0, "steps": 0}     # host wall-clock per phase
 
     def frames_needed(self, total_steps: int, kf_every: int, win: int) -> int:
-        """frames consumed by the 7-keyframe initialisation plus `total_steps` sharded steps"""
-        return (7 + win * self.world * total_steps + 1) * kf_every + 1
+        """frames consumed by the 7-keyframe initialisation plus `total_steps` steps"""
+        return (7 + win * self.world * self.wb * total_steps + 1) * kf_every + 1
 
+    # ---- default callbacks on the real SLAM objects
     def _append(self, kf_index: int, frame, tstamp, intr, mine: bool):
-        slam = self.slam
-        # fixed cadence: the encoder pass of a keyframe is deferred to the window that owns it (TrackFrontend.window_features)
-        slam.keyframes.append(tstamp, frame[0], None, None, None, None, intr, None, None)
+        # fixed cadence: the encoder pass of a keyframe is deferred to the rank that owns its window
+        self.slam.keyframes.append(tstamp, frame[0], None, None, None, None, intr, None, None)
+
+    def _infer(self, ranges):
+        """batched network pass over this rank's windows -> (pts [wb*V,H,W,3], conf [wb*V,H,W], pose [wb*V,7])"""
+        tr, kf = self.slam.tracker, self.slam.keyframes
+        tr.window_features(ranges[0][0], ranges[-1][1])                 # encode the not-yet-encoded keyframes, batched
+        feats = torch.stack([tr.window_features(a, b) for a, b in ranges], 0)
+        res = self.slam.model.decode_windows(feats, kf.ht, kf.wd)
+        return tuple(res[k] for k in ("pts3d_in_self_view", "conf_self", "camera_pose"))
+
+    # ---- the pipeline
+    def _replay(self, pending):
+        ranges_all, gathered, ev = pending
+        V = self.views
+        tic = time.perf_counter()
+        if ev is not None and self.pipelined:
+            if self._side is None:
+                self._side = torch.cuda.Stream(priority=self.side_priority)
+            self._side.wait_event(ev)
+            for g in gathered:
+                g.record_stream(self._side)         # allocated on the main stream, consumed on the side stream
+            ctx = torch.cuda.stream(self._side)
+        else:
+            ctx = contextlib.nullcontext()
+        with ctx:
+            for j, (a, b) in enumerate(ranges_all):
+                sl = slice(j * V, (j + 1) * V)
+                self.track_fn(a, b, tuple(g[sl] for g in gathered))
+                self.slam.tracker.t1 = b
+        self.stats["replay_s"] += time.perf_counter() - tic
 
     def step(self, frames, t, kf_every, win, intr):
-        """Advance `world` windows (= world*win*kf_every frames).  Returns the new frame counter."""
-        slam, world, rank = self.slam, self.world, self.rank
-        tracker = slam.tracker
-        first_t0 = tracker.t1 - 1
-        ranges = window_ranges(first_t0, world, win)
+        """Advance world*wb windows (= world*wb*win*kf_every frames).  Returns the new frame counter."""
+        slam, world, rank, wb = self.slam, self.world, self.rank, self.wb
+        if self._next_t0 is None:
+            self._next_t0 = slam.tracker.t1 - 1
+        first_t0 = self._next_t0
+        ranges_all = window_ranges(first_t0, world * wb, win)
+        mine = ranges_all[rank * wb:(rank + 1) * wb]
         # 1. keyframe filter in fixed-cadence mode: every kf_every-th frame is a keyframe (motion_filter.py:83,109,124);
-        #    every rank registers all of them, but only the owner of a window runs the encoder on its new keyframes
-        n_frames = world * win * kf_every
+        #    every rank registers all of them, only the owner of a window ever encodes them
+        n_frames = world * wb * win * kf_every
         for f in range(t, t + n_frames):
             if f % kf_every == 0:
                 k = slam.keyframes.counter.value
-                owner = min(max((k - first_t0 - 1) // win, 0), world - 1) if k > first_t0 else 0
+                owner = min(max((k - first_t0 - 1) // (win * wb), 0), world - 1) if k > first_t0 else 0
                 self.append_fn(k, frames[f:f + 1], f, intr, owner == rank)
-        # 2. this rank's window through the network
-        t0, t1 = ranges[rank]
-        outs = self.infer_fn(t0, t1)
-        # 3. one exchange over xGMI
-        per_rank = all_gather_outputs(outs, world)
-        # 4. replicated sequential chaining + graph update, in window order
-        for (a, b), o in zip(ranges, per_rank):
-            self.track_fn(a, b, tuple(o))
-            tracker.t1 = b
+        # 2. this rank's windows through the network (asynchronous on the main stream)
+        tic = time.perf_counter()
+        outs = self.infer_fn(mine)
+        self.stats["issue_s"] += time.perf_counter() - tic
+        # 3. meanwhile: replay the previous step's chaining + graph update (host-bound) on the side stream
+        if self._pending is not None:
+            self._replay(self._pending)
+            self._pending = None
+        # 4. one exchange over xGMI (private copies when world == 1)
+        tic = time.perf_counter()
+        gathered = all_gather_outputs(outs, world, self.force_collective)
+        self.stats["exchange_s"] += time.perf_counter() - tic
+        self.stats["steps"] += 1
+        ev = None
+        if gathered[0].is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pending = (ranges_all, gathered, ev)
+        self._next_t0 = ranges_all[-1][1] - 1
+        if not self.pipelined:
+            self.flush()
         return t + n_frames
+
+    def flush(self):
+        """drain the pipeline: replay the last step and join the side stream"""
+        if self._pending is not None:
+            self._replay(self._pending)
+            self._pending = None
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)

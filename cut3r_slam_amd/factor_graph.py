@@ -171,19 +171,26 @@ class FactorGraph:
         cnt = self.backend.bwd(pointmap_i, w2c_row.contiguous(), self._K4(K), W, H)
         return (cnt.float() / float(H * W)).reshape(B1, 1)
 
-    def add(self, current_idx, all_poses, all_pointmaps, current_pose, current_pointmap, K,
-            all_w2c_rows=None, current_w2c_row=None):
-        """factor_graph.py:148-197.  all_poses [i,4,4] c2w, all_pointmaps [i,h,w,3], current_pose [4,4],
-        current_pointmap [H,W,3] (tensors, or the AlignedPoints / SubmapStore descriptors of resident data);
-        optional precomputed world->camera rows avoid any host inverse."""
+    def add_begin(self, current_idx, all_poses, all_pointmaps, current_pose, current_pointmap, K,
+                  all_w2c_rows=None, current_w2c_row=None):
+        """Launch half of `add`: host distance classes + the two counting kernels, nothing read back.  Returns the
+        ticket `add_finish` consumes.  Lets a caller issue the launches of several keyframes before ONE read-back."""
         c2w = all_poses.detach().cpu().numpy() if isinstance(all_poses, torch.Tensor) else np.asarray(all_poses)
         cur = current_pose.detach().cpu().numpy() if isinstance(current_pose, torch.Tensor) else np.asarray(current_pose)
-        c2w = c2w.astype(np.float32).reshape(-1, 4, 4)
-        cur = cur.astype(np.float32).reshape(4, 4)
-        d = c2w[:, :3, 3] - cur[None, :3, 3]
+        c2w, cur = c2w.astype(np.float32, copy=False), cur.astype(np.float32, copy=False)
+        if c2w.ndim == 2 and c2w.shape[1] == 3:
+            # camera centres only ([n,3] / [3]): the caller supplies the world->camera rows, nothing else is needed here
+            if all_w2c_rows is None or current_w2c_row is None:
+                raise ValueError("add_begin: camera centres alone need all_w2c_rows and current_w2c_row")
+            centres, cur_c = c2w, cur.reshape(3)
+        else:
+            c2w = c2w.reshape(-1, 4, 4)
+            cur = cur.reshape(4, 4)
+            centres, cur_c = c2w[:, :3, 3], cur[:3, 3]
+        d = centres - cur_c[None]
         dists = np.sqrt((d * d).sum(axis=1, dtype=np.float32), dtype=np.float32)
         cond1 = dists <= np.float32(1.0)
-        n = c2w.shape[0]
+        n = centres.shape[0]
         if all_w2c_rows is None:
             all_w2c_rows = torch.from_numpy(gh.w2c_rows(c2w)).to(self.device)
         if current_w2c_row is None:
@@ -198,14 +205,49 @@ class FactorGraph:
         hb, wb = all_pointmaps.shape[1], all_pointmaps.shape[2]
         if idx2.size:
             cnt_b = self.backend.bwd(all_pointmaps, current_w2c_row.contiguous(), K4, wb, hb)
-        # single device->host hop for the decisions
-        if cnt_b is not None:
-            both = torch.cat([cnt_f.reshape(-1), cnt_b.reshape(-1)]).cpu().numpy()
-            cf, cb = both[:n], both[n:][idx2]
-        else:
-            cf, cb = cnt_f.cpu().numpy(), None
-        ratio_f = cf.astype(np.float32) / np.float32(H * W)
-        idx1 = np.nonzero(cond1)[0]
+        return {"idx": current_idx, "n": n, "cnt_f": cnt_f, "cnt_b": cnt_b, "idx1": np.nonzero(cond1)[0], "idx2": idx2,
+                "npix_f": H * W, "npix_b": hb * wb}
+
+    def window_tickets(self, t0, t1, centres, counts_host, npix_f, npix_b, first=3):
+        """tickets + counts of keyframes t0..t1-1 from ONE cut3r_window_update call (ops.window_update): the host half
+        of add_begin (distance classes from the camera centres [>= t1, 3]) and the slices of counts_host [V,2,ldc]."""
+        out = []
+        for i in range(max(t0, first), t1):
+            d = centres[:i] - centres[i][None]
+            dists = np.sqrt((d * d).sum(axis=1, dtype=np.float32), dtype=np.float32)
+            cond1 = dists <= np.float32(1.0)
+            tk = {"idx": i, "n": i, "cnt_f": None, "cnt_b": None, "idx1": np.nonzero(cond1)[0], "idx2": np.nonzero(~cond1)[0],
+                  "npix_f": npix_f, "npix_b": npix_b}
+            out.append((tk, counts_host[i - t0, 0, :i], counts_host[i - t0, 1, :i]))
+        return out
+
+    @staticmethod
+    def read_counts(tickets):
+        """single device->host hop for the counts of any number of tickets -> [(cf, cb|None)]"""
+        parts = []
+        for tk in tickets:
+            parts.append(tk["cnt_f"].reshape(-1))
+            if tk["cnt_b"] is not None:
+                parts.append(tk["cnt_b"].reshape(-1))
+        if not parts:
+            return []
+        host = (torch.cat(parts) if len(parts) > 1 else parts[0]).cpu().numpy()
+        res, o = [], 0
+        for tk in tickets:
+            n = tk["n"]
+            cf = host[o:o + n]
+            o += n
+            cb = None
+            if tk["cnt_b"] is not None:
+                cb = host[o:o + n]
+                o += n
+            res.append((cf, cb))
+        return res
+
+    def add_finish(self, tk, cf, cb):
+        """decision half of `add` (factor_graph.py:170-197), host only"""
+        current_idx, idx1, idx2 = tk["idx"], tk["idx1"], tk["idx2"]
+        ratio_f = cf.astype(np.float32) / np.float32(tk["npix_f"])
         if idx1.size:
             jj = idx1[ratio_f[idx1] > np.float32(0.3)]
             if jj.size:
@@ -213,7 +255,7 @@ class FactorGraph:
                 self.add_factors(ii, jj)
                 self.add_factors(jj, ii)
         if idx2.size:
-            ratio_b = cb.astype(np.float32) / np.float32(hb * wb)
+            ratio_b = cb[idx2].astype(np.float32) / np.float32(tk["npix_b"])
             mask = (ratio_f[idx2] > np.float32(0.3)) | (ratio_b > np.float32(0.3))
             jj = idx2[mask]
             if jj.size:
@@ -222,6 +264,16 @@ class FactorGraph:
                 self.add_factors(jj, ii)
         self._age = [a + 1 for a in self._age]
         self._cache = None
+
+    def add(self, current_idx, all_poses, all_pointmaps, current_pose, current_pointmap, K,
+            all_w2c_rows=None, current_w2c_row=None):
+        """factor_graph.py:148-197.  all_poses [i,4,4] c2w, all_pointmaps [i,h,w,3], current_pose [4,4],
+        current_pointmap [H,W,3] (tensors, or the AlignedPoints / SubmapStore descriptors of resident data);
+        optional precomputed world->camera rows avoid any host inverse."""
+        tk = self.add_begin(current_idx, all_poses, all_pointmaps, current_pose, current_pointmap, K,
+                            all_w2c_rows, current_w2c_row)
+        (cf, cb), = self.read_counts([tk])
+        self.add_finish(tk, cf, cb)
 
     # ------------------------------------------------------------------ loop detection (factor_graph.py:503-543)
     def detect_loop(self, current_idx, current_featI=None, all_featI=None, temporal_window=8, feat_th=0.7,

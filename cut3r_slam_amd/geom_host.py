@@ -46,6 +46,13 @@ def matrix_to_pose_vec(T: np.ndarray) -> np.ndarray:
     return np.concatenate([np.asarray(T[:3, 3], np.float32), q.astype(np.float32)])
 
 
+def matrices_to_pose_vecs(T: np.ndarray) -> np.ndarray:
+    """c2w [B,4,4] -> [B,7] (t, quat xyzw) fp32: one vectorised scipy call for a whole window (same per-matrix math)."""
+    T = np.asarray(T)
+    q = Rotation.from_matrix(np.asarray(T[:, :3, :3], np.float64)).as_quat()
+    return np.concatenate([np.asarray(T[:, :3, 3], np.float32), q.astype(np.float32)], axis=1)
+
+
 def inv4(T: np.ndarray) -> np.ndarray:
     return np.linalg.inv(np.asarray(T, np.float32)).astype(np.float32)
 

@@ -63,6 +63,14 @@ class KeyFrame:
         rows = gh.w2c_rows(gh.pose_vec_to_matrix(p.numpy()[None]))
         self.w2c[index].copy_(torch.from_numpy(rows[0]), non_blocking=True)
 
+    def set_poses(self, start: int, poses7) -> None:
+        """set_pose for the consecutive keyframes start.. in one host->device copy"""
+        p = np.asarray(poses7, np.float32).reshape(-1, 7)
+        n = p.shape[0]
+        self.pose[start:start + n] = torch.from_numpy(p)
+        rows = gh.w2c_rows(gh.pose_vec_to_matrix(p))
+        self.w2c[start:start + n].copy_(torch.from_numpy(rows), non_blocking=True)
+
     def pointmap_slot(self, kf: int, sub_num: int, t0: int):
         """(submap, slot) holding the current estimate of keyframe `kf` as seen from window `sub_num` starting at t0
         (track_frontend.py:251-255: earlier submaps contribute slots 0..4, the running window its own slots)."""

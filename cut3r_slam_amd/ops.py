@@ -367,6 +367,30 @@ def align_view(pts, conf, P12, s, ds, pm_ds, conf_ds, depth):
     check(lib.cut3r_align_view(_p(pts), _p(conf), H, W, arr, float(s), int(ds), _p(pm_ds), _p(conf_ds), _p(depth), _stream()), "cut3r_align_view")
 
 
+def window_update(pts, conf, P12s, s, ds, pm_ds, conf_ds, depth, store, w2c, t0, first, K4, counts, grp=5, grp_stride=6):
+    """Whole-window align + overlap counts (cut3r_window_update).  pts [V,H,W,3], conf [V,H,W]; pm_ds [V,h,w,3], conf_ds [V,h,w],
+    depth [V,H,W] are the window's consecutive store slots; store = the full [submaps,6,h,w,3] pointmap store; w2c [>=t0+V,12];
+    counts int32 [V,2,ldc] receives forward (row 0) / backward (row 1) counts of keyframes t0+v >= first."""
+    _cuda(pts, conf, pm_ds, conf_ds, depth, store, w2c, counts)
+    V, H, W = conf.shape
+    h, w = H // ds, W // ds
+    _req(pts.dtype == F32 and pts.is_contiguous() and pts.shape == (V, H, W, 3) and conf.dtype == F32 and conf.is_contiguous(), "window inputs")
+    _req(1 <= V <= 6 and len(P12s) == V * 12, "V <= 6 views with 12 floats each")
+    _req(pm_ds.is_contiguous() and pm_ds.numel() == V * h * w * 3 and conf_ds.is_contiguous() and conf_ds.numel() == V * h * w, "ds outputs")
+    _req(depth.is_contiguous() and depth.numel() == V * H * W and depth.dtype == F32, "depth rows")
+    _req(store.dtype == F32 and store.is_contiguous() and w2c.dtype == F32 and w2c.is_contiguous() and w2c.shape[0] >= t0 + V and w2c.shape[1] == 12, "store / w2c")
+    last = t0 + V - 1
+    nslots = store.numel() // (3 * h * w)
+    _req(last < 1 or ((last - 1) // grp) * grp_stride + (last - 1) % grp < nslots, "pointmap store too small")
+    ldc = counts.shape[-1]
+    _req(counts.dtype == torch.int32 and counts.is_contiguous() and counts.shape == (V, 2, ldc) and ldc >= t0 + V, "counts int32 [V,2,ldc]")
+    arr = (C.c_float * (12 * V))(*[float(v) for v in P12s])
+    lib = _lib.load()
+    check(lib.cut3r_window_update(_p(pts), _p(conf), V, H, W, arr, float(s), int(ds), _p(pm_ds), _p(conf_ds), _p(depth), _p(store),
+                                  int(grp), int(grp_stride), _p(w2c), int(t0), int(first), *[float(v) for v in K4], _p(counts), ldc,
+                                  _stream()), "cut3r_window_update")
+
+
 def logdepth_sum(prev_depth, pts, out):
     _cuda(prev_depth, pts, out)
     n = prev_depth.numel()

@@ -53,6 +53,7 @@ class TrackFrontend:
         # below stays sequential).  Trades latency (window_batch*5 keyframes) for MFMA-bound decoder GEMMs.
         self.window_batch = int(config.get("window_batch", 1))
         self._lsum = torch.zeros(1, dtype=torch.float64, device=device)
+        self._counts = None
 
     def prepare_input(self, images):
         return make_views(self.model, images)
@@ -91,12 +92,12 @@ class TrackFrontend:
             graph.add_neighborhood_factors(0, 3, r=3)
         pts, conf, pose_enc = outputs if outputs is not None else self.infer(t0=t0, t1=t1)
         V, H, W, _ = pts.shape
-        lsum = None
         if not init:
             ops.logdepth_sum(kf.depth[t0], pts[0], self._lsum)           # window k's view 0 == previous window's last KF
-        host = pose_enc.detach().cpu().numpy()                             # the one sync point of the window
-        if not init:
-            lsum = float(self._lsum.item())
+            packed = torch.cat([pose_enc.detach().reshape(-1).double(), self._lsum]).cpu().numpy()   # sync point 1 of 2
+            host, lsum = packed[:-1].astype(np.float32).reshape(V, 7), float(packed[-1])
+        else:
+            host, lsum = pose_enc.detach().cpu().numpy(), None
         poses = gh.pose_encoding_to_camera(host)
         first_w2c = gh.inv4(poses[0])
         sub_num = t0 // 5
@@ -105,29 +106,48 @@ class TrackFrontend:
             align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
             prev_c2w = gh.pose_vec_to_matrix(kf.pose[t0].numpy()[None])[0]
             align = (prev_c2w[:3, :3], prev_c2w[:3, 3], align_s)
+        # host: chained pose of every view, one vectorised matrix->quaternion conversion, ONE host->device copy of the
+        # world->camera rows (the reference converts and stores per keyframe, track_frontend.py:236-245)
+        chained, scales = [], []
+        for v in range(t1 - t0):
+            if init:
+                chained.append(gh.chain_pose(first_w2c, poses[v]))
+                scales.append(np.float32(1.0))
+            else:
+                chained.append(gh.chain_pose(first_w2c, poses[v], *align))
+                scales.append(align[2])
+        kf.set_poses(t0, gh.matrices_to_pose_vecs(np.stack(chained)))
+        centres = kf.pose[:t1, :3].numpy()                                  # zero-copy view of the host pose table
+        # device: ONE fused call stores every view (downsampled chained pointmap, confidence, depth) and counts the
+        # forward / backward overlaps of every keyframe of the window; the counts come back in one hop (the reference
+        # re-uploads all previous pointmaps and reads ratios back per keyframe, track_frontend.py:248-259)
+        V = t1 - t0
+        if self._counts is None or self._counts.shape[-1] < t1:
+            self._counts = torch.zeros(6, 2, max(256, 2 * t1), dtype=torch.int32, device=self.device)
+        intr = kf.intrinsic[t0:t1].numpy()
+        # one call per run of keyframes with equal intrinsics (a sequence has ONE calibration: normally one call)
+        groups, g0 = [], 0
+        for v in range(1, V + 1):
+            if v == V or not np.array_equal(intr[v], intr[g0]):
+                groups.append((g0, v))
+                g0 = v
+        done = {}
+        h, w = kf.submap_ds.shape[2:4]
+        for (a, b) in groups:
+            counts = self._counts[:b - a]
+            P12s = np.concatenate([c[:3, :4].reshape(-1) for c in chained[a:b]])
+            ops.window_update(pts[a:b], conf[a:b], P12s, float(scales[0]), ds, kf.submap_ds[sub_num, a:b], kf.conf_ds[sub_num, a:b],
+                              kf.depth[t0 + a:t0 + b], kf.submap_ds, kf.w2c, t0 + a, 3, [float(x) for x in intr[a]], counts)
+            if t0 + b - 1 >= 3:
+                host = counts.cpu().numpy()                                              # sync point 2 of 2
+                for tk, cf, cb in graph.window_tickets(t0 + a, t0 + b, centres, host, H * W, h * w):
+                    done[tk["idx"]] = (tk, cf.copy(), cb.copy())
+        # decision phase, in the reference's order: neighbourhood factors of keyframe i, then its overlap factors
         for i in range(t0, t1):
             if not init:
                 graph.add_neighborhood_factors(i - 3, i + 1, r=3)
-            v = i - t0
-            if init:
-                pose = gh.chain_pose(first_w2c, poses[v])
-                s = np.float32(1.0)
-            else:
-                pose = gh.chain_pose(first_w2c, poses[v], *align)
-                s = align[2]
-            ops.align_view(pts[v], conf[v], pose[:3, :4].reshape(-1), float(s), ds,
-                           kf.submap_ds[sub_num, v], kf.conf_ds[sub_num, v], kf.depth[i])
-            kf.set_pose(i, gh.matrix_to_pose_vec(pose))
-            if i > 2:
-                # current pointmap at full resolution as the reference passes it (track_frontend.py:259), fused into
-                # the projection kernel; previous pointmaps are read in place from the resident submap store
-                cur_pm = AlignedPoints(pts[v], pose[:3, :4], float(s))
-                all_c2w = gh.pose_vec_to_matrix(kf.pose[:i].numpy())
-                cur_c2w = gh.pose_vec_to_matrix(kf.pose[i].numpy()[None])[0]
-                intr = kf.intrinsic[i].numpy()
-                K = np.array([[intr[0], 0, intr[2]], [0, intr[1], intr[3]], [0, 0, 1]])
-                graph.add(i, all_c2w, SubmapStore(kf.submap_ds, i), cur_c2w, cur_pm, K,
-                          all_w2c_rows=kf.w2c[:i], current_w2c_row=kf.w2c[i])
+            if i in done:
+                graph.add_finish(*done[i])
 
     def track_batch(self, ranges):
         """several consecutive 6-keyframe windows: ONE batched decoder/head inference, then the reference's sequential

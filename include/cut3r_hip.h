@@ -122,6 +122,19 @@ int cut3r_overlap_fwd(const float* pm, int N, const float* P_host, float s_align
 int cut3r_overlap_bwd(const float* pms, int B, int N, int grp, int grp_stride, const float* w2c, float fx, float fy, float cx,
                       float cy, int W, int H, int32_t* counts, void* stream);
 
+/* ---- whole-window update -------------------------------------------------------------------------------------------
+ * One call for everything TrackFrontend.track does per pixel for a window of V <= 6 consecutive keyframes t0..t0+V-1
+ * (hislam2/track_frontend.py:193-262 + factor_graph.py:148-197, :255-315): the V cut3r_align_view results (pm_ds, conf_ds,
+ * depth are the V consecutive slots / rows of the resident stores) and, for every keyframe i = t0+v >= first, the forward
+ * counts of its full-resolution chained pointmap in cameras 0..i-1 and the backward counts of stored pointmaps 0..i-1
+ * (slot addressing as cut3r_overlap_bwd, over `store`) in camera i.  pts [V,H,W,3], conf [V,H,W] contiguous; P_host
+ * V*12 HOST floats; w2c device [>= t0+V, 12]; counts int32 device [V][2][ldc] (row 0 forward, row 1 backward; ldc >=
+ * t0+V), zeroed here.  Four launches instead of ~6 per keyframe; every count equals the per-keyframe entry points'. */
+int cut3r_window_update(const float* pts, const float* conf, int V, int H, int W, const float* P_host, float s, int ds,
+                        float* pm_ds, float* conf_ds, float* depth, const float* store, int grp, int grp_stride,
+                        const float* w2c, int t0, int first, float fx, float fy, float cx, float cy, int32_t* counts, int ldc,
+                        void* stream);
+
 /* ---- window alignment -----------------------------------------------------------------------------------------------
  * replaces the per-view tensor math of TrackFrontend.track (hislam2/track_frontend.py:193-243): pointmap = P*(s*pts),
  * conf <- 1-1/conf, depth = s*z, stride-`ds` downsample.  P_host: 12 HOST floats (chained c2w 3x4, row-major), s by value

@@ -39,31 +39,39 @@ class _FakeSlam:
         self.tracker = T()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, wb):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     slam = _FakeSlam()
     slam.keyframes.counter.value = 7
-    appended, tracked = [], []
+    appended, tracked, lag = [], [], []
 
     def append_fn(k, frame, tstamp, intr, mine):
         assert k == slam.keyframes.counter.value
         slam.keyframes.counter.value += 1
         appended.append((k, int(tstamp), bool(mine)))
 
-    def infer_fn(t0, t1):
-        # "network output" that encodes who computed which window
-        return (torch.full((6, 4, 5, 3), float(100 * rank + t0)), torch.full((6, 4, 5), float(t0)), torch.full((6, 7), float(rank)))
+    def infer_fn(ranges):
+        # "network output" that encodes who computed which window: [wb*6, ...] like the batched decoder returns
+        assert len(ranges) == wb
+        pts = torch.cat([torch.full((6, 4, 5, 3), float(100 * rank + t0)) for t0, _ in ranges])
+        conf = torch.cat([torch.full((6, 4, 5), float(t0)) for t0, _ in ranges])
+        pose = torch.full((6 * wb, 7), float(rank))
+        lag.append(len(tracked))
+        return pts, conf, pose
 
     def track_fn(t0, t1, outs):
+        assert outs[0].shape[0] == 6
         tracked.append((t0, t1, float(outs[0][0, 0, 0, 0]), float(outs[2][0, 0])))
 
-    st = ShardedTracker(slam, world, rank, infer_fn, track_fn, append_fn)
+    st = ShardedTracker(slam, world, rank, wb=wb, infer_fn=infer_fn, track_fn=track_fn, append_fn=append_fn)
     frames = torch.zeros(st.frames_needed(2, 10, 5), 1)
     t = 61
     for _ in range(2):
         t = st.step(frames, t, 10, 5, None)
-    q.put((rank, appended, tracked, t, slam.tracker.t1))
+    n_before_flush = len(tracked)
+    st.flush()
+    q.put((rank, appended, tracked, t, slam.tracker.t1, lag, n_before_flush))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,18 +82,22 @@ def test_window_ranges_chain():
     assert all(a[1] - 1 == b[0] for a, b in zip(r, r[1:]))         # consecutive windows share one keyframe
 
 
-def test_sharded_tracker_world2_gloo():
+def _run_world2(wb):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, wb)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, app0, trk0, t0, t1_0), (r1, app1, trk1, t1, t1_1) = res
+    return res
+
+
+def test_sharded_tracker_world2_gloo():
+    (r0, app0, trk0, t0, t1_0, lag0, nb0), (r1, app1, trk1, t1, t1_1, lag1, nb1) = _run_world2(1)
     # both ranks replay the same windows, in sequence order, with the owner's outputs
     assert trk0 == trk1
     assert [(a, b) for a, b, _, _ in trk0] == [(5, 11), (10, 16), (15, 21), (20, 26)]
@@ -95,3 +107,21 @@ def test_sharded_tracker_world2_gloo():
     # every keyframe is registered on every rank, encoded by exactly one
     assert [(k, ts) for k, ts, _ in app0] == [(k, ts) for k, ts, _ in app1] == [(7 + i, 70 + 10 * i) for i in range(20)]
     assert all(m0 != m1 for (_, _, m0), (_, _, m1) in zip(app0, app1))
+    # software pipeline: the network pass of step 2 is issued BEFORE step 1 is replayed; flush() drains the last step
+    assert lag0 == lag1 == [0, 0] and nb0 == nb1 == 2
+
+
+def test_sharded_tracker_world2_window_batch2():
+    (r0, app0, trk0, t0, t1_0, lag0, nb0), (r1, app1, trk1, t1, t1_1, lag1, nb1) = _run_world2(2)
+    assert trk0 == trk1
+    want = [(5 + 5 * j, 11 + 5 * j) for j in range(8)]
+    assert [(a, b) for a, b, _, _ in trk0] == want
+    # rank r owns wb=2 consecutive windows of every step
+    assert [owner for *_, owner in trk0] == [0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 1.0, 1.0]
+    assert [v for _, _, v, _ in trk0] == [a + 100 * o for (a, _), o in zip(want, [0, 0, 1, 1, 0, 0, 1, 1])]
+    assert t0 == t1 == 61 + 2 * 4 * 50 and t1_0 == t1_1 == 46
+    assert [(k, ts) for k, ts, _ in app0] == [(k, ts) for k, ts, _ in app1] == [(7 + i, 70 + 10 * i) for i in range(40)]
+    assert all(m0 != m1 for (_, _, m0), (_, _, m1) in zip(app0, app1))
+    # keyframes 7..16 belong to rank 0's two windows of step 1 (the shared keyframe 5/6 were initialised earlier)
+    assert [m for k, _, m in app0 if k <= 15] == [True] * 9
+    assert nb0 == 4

@@ -40,7 +40,10 @@ def _report(name, got, ref, tol):
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K,tile", [
     (768, 1024, 1024, 0), (769, 768, 768, 0), (4608, 3072, 1024, 128), (4608, 1024, 4096, 0), (1, 1536, 1536, 0),
-    (6, 64, 48, 0), (13, 144, 48, 64), (256, 4608, 1536, 0), (130, 8, 192, 0), (200, 132, 72, 128)])
+    (6, 64, 48, 0), (13, 144, 48, 64), (256, 4608, 1536, 0), (130, 8, 192, 0), (200, 132, 72, 128),
+    # 256^2 ping-pong kernel: full tiles, ragged M / N / K (K tail inside a 64-deep tile), one K-tile, two K-tiles
+    (3072, 1024, 1024, 256), (769, 768, 768, 256), (1000, 516, 200, 256), (300, 260, 64, 256), (257, 256, 128, 256),
+    (5, 12, 8, 256)])
 def test_gemm_bias_gelu_residual(M, N, K, tile):
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g).half()
@@ -62,6 +65,24 @@ def test_gemm_bias_gelu_residual(M, N, K, tile):
         _report(f"gemm M{M} N{N} K{K} act{act} res{use_res} {out_dt}", out.float(), r, 2e-3 if out_dt == torch.float16 else 2e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 2048, 1024), (3076, 768, 3072), (2500, 1024, 192)])
+def test_gemm256_race_screen(M, N, K):
+    """The 256^2 kernel orders its LDS-DMA ring only by counted vmcnt + barriers: repeated launches under load must
+    be bit-identical to each other and match the 128^2 kernel (same MFMA, same K order -> same fp32 sums)."""
+    g = torch.Generator().manual_seed(K)
+    A = torch.randn(M, K, generator=g).half().to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(DEV)
+    ref = torch.empty(M, N, device=DEV)
+    ops.linear(A, W, ref, None, 0, tile=128)
+    outs = [torch.empty(M, N, device=DEV) for _ in range(4)]
+    for rep in range(40):
+        ops.linear(A, W, outs[rep % 4], None, 0, tile=256)
+        if rep % 4 == 3:
+            torch.cuda.synchronize()
+            for o in outs:
+                assert torch.equal(o, ref), f"rep {rep}: {(o != ref).sum().item()} elements differ, max {(o - ref).abs().max().item()}"
+
+
 def test_gemm_strided_output_and_inplace_residual():
     g = torch.Generator().manual_seed(1)
     M, N, K = 70, 96, 64
@@ -76,10 +97,11 @@ def test_gemm_strided_output_and_inplace_residual():
     assert float(big[0].abs().max()) == 0 and float(big[:, N:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("tile", [0, 256])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,relu_in", [
     (1, 12, 16, 256, 256, 1, True), (2, 5, 7, 96, 256, 1, False), (1, 24, 32, 768, 768, 2, False), (3, 2, 3, 256, 128, 1, False),
-    (1, 1, 2, 256, 256, 1, True), (2, 9, 9, 128, 128, 2, False)])
-def test_conv3x3_implicit_gemm(B, H, W, Cin, Cout, stride, relu_in):
+    (1, 1, 2, 256, 256, 1, True), (2, 9, 9, 128, 128, 2, False), (2, 24, 32, 256, 256, 1, True)])
+def test_conv3x3_implicit_gemm(B, H, W, Cin, Cout, stride, relu_in, tile):
     g = torch.Generator().manual_seed(H * 31 + W)
     x = torch.randn(B, Cin, H, W, generator=g).half()
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).half()
@@ -91,7 +113,7 @@ def test_conv3x3_implicit_gemm(B, H, W, Cin, Cout, stride, relu_in):
     wk = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
     out = torch.full(ref.shape, float("nan"), dtype=torch.float16, device=DEV)
     ops.conv3x3_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wk.to(DEV), out, b.to(DEV), stride, relu_in, 0,
-                     res1=r1.permute(0, 2, 3, 1).contiguous().to(DEV))
+                     res1=r1.permute(0, 2, 3, 1).contiguous().to(DEV), tile=tile)
     torch.cuda.synchronize()
     _report(f"conv3x3 {B}x{H}x{W} {Cin}->{Cout} s{stride}", out.float(), ref, 2e-3)
 
@@ -349,3 +371,52 @@ def test_patch_overlap_count_matches_oracle_and_reference():
     ratio, mx = G.patch_overlap_ratio(a.numpy(), b.numpy())
     border = int((np.abs(mx - 0.7) < 1e-5).sum())
     assert abs(cnt.item() - round(ratio * 767)) <= border
+
+
+def test_window_update_matches_per_keyframe_calls():
+    """cut3r_window_update (4 launches per window) == the per-keyframe entry points, bit for bit: stored pointmaps,
+    confidences, depths and every forward / backward overlap count."""
+    g = torch.Generator().manual_seed(11)
+    V, H, W, ds, t0 = 6, 48, 64, 2, 10
+    h, w = H // ds, W // ds
+    nsub = 4
+    store = (torch.randn(nsub, 6, h, w, 3, generator=g) * 0.5 + torch.tensor([0, 0, 2.0])).to(DEV)
+    pts = (torch.randn(V, H, W, 3, generator=g) * 0.4 + torch.tensor([0, 0, 1.5])).to(DEV)
+    conf = (1.0 + torch.rand(V, H, W, generator=g) * 4).to(DEV)
+    w2c = torch.eye(4)[:3].reshape(1, 12).repeat(t0 + V, 1)
+    w2c[:, 3] = torch.randn(t0 + V, generator=g) * 0.3
+    w2c[:, 7] = torch.randn(t0 + V, generator=g) * 0.3
+    w2c = w2c.contiguous().to(DEV)
+    P = torch.eye(4)[:3].reshape(1, 12).repeat(V, 1)
+    P[:, 3] = torch.randn(V, generator=g) * 0.2
+    P[:, 11] = torch.randn(V, generator=g) * 0.2
+    s, K4 = 1.37, [40.0, 42.0, 31.5, 23.5]
+    sub = t0 // 5
+    # per-keyframe path
+    ref_store = store.clone()
+    ref_conf = torch.zeros(nsub, 6, h, w, device=DEV)
+    ref_depth = torch.zeros(V, H, W, device=DEV)
+    ref_f, ref_b = [], []
+    for v in range(V):
+        ops.align_view(pts[v], conf[v], P[v].tolist(), s, ds, ref_store[sub, v], ref_conf[sub, v], ref_depth[v])
+        i = t0 + v
+        cf = torch.zeros(i, dtype=torch.int32, device=DEV)
+        cb = torch.zeros(i, dtype=torch.int32, device=DEV)
+        ops.overlap_fwd(pts[v], w2c[:i].contiguous(), K4, W, H, cf, P[v].tolist(), s)
+        ops.overlap_bwd(ref_store, w2c[i].contiguous(), K4, w, h, cb, B=i, N=w * h, grp=5, grp_stride=6)
+        ref_f.append(cf.cpu())
+        ref_b.append(cb.cpu())
+    # fused path
+    got_store = store.clone()
+    got_conf = torch.zeros(nsub, 6, h, w, device=DEV)
+    got_depth = torch.zeros(V, H, W, device=DEV)
+    counts = torch.full((V, 2, 64), -1, dtype=torch.int32, device=DEV)
+    ops.window_update(pts, conf, P.reshape(-1).tolist(), s, ds, got_store[sub, :V], got_conf[sub, :V], got_depth, got_store, w2c, t0, 3,
+                      K4, counts)
+    torch.cuda.synchronize()
+    assert torch.equal(got_store, ref_store) and torch.equal(got_conf, ref_conf) and torch.equal(got_depth, ref_depth)
+    c = counts.cpu()
+    for v in range(V):
+        i = t0 + v
+        assert torch.equal(c[v, 0, :i], ref_f[v]) and torch.equal(c[v, 1, :i], ref_b[v]), f"view {v}"
+        assert int(c[v, 0, :i].sum()) > 0 and int(c[v, 1, :i].sum()) > 0          # the case is not vacuous
