@@ -103,11 +103,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: tiny network (NOT a valid benchmark line)")
-    ap.add_argument("--window-batch", type=int, default=4, help="tracking windows pushed through the decoder together "
+    ap.add_argument("--window-batch", type=int, default=8, help="tracking windows pushed through the decoder together "
                     "(buffered-stream throughput mode; 1 = the reference's one-window-at-a-time schedule)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    emu = int(os.environ.get("CUT3R_EMULATE_WORLD", "0"))     # debug: rank 0 of an `emu`-GPU job on ONE GPU (replay load only)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or os.environ.get("CUT3R_FORCE_DIST") == "1"     # the env flag rehearses the RCCL path with one rank
@@ -140,6 +141,8 @@ def main():
     t_build = time.time() - t0
     log(f"model resident in HBM after {t_build:.1f}s")
 
+    if emu > 1:
+        world = emu                                # after the process-group decisions above: no collective is created
     frames_per_step = KF_EVERY * WIN * WB          # per rank: one step = WB windows, pushed through the network together
     total_steps = args.warmup + args.steps
     probe_steps = 0 if (args.no_roofline or dist_on) else args.steps      # second, instrumented pass
@@ -151,6 +154,7 @@ def main():
     # rank r owns windows [r*WB, (r+1)*WB) of every step; chaining + graph update of step s overlap the network pass of step s+1
     runner = cdist.ShardedTracker(slam, world, rank, wb=WB, pipelined=os.environ.get("CUT3R_PIPELINE", "1") == "1",
                                   force_collective=dist_on)
+    runner.emulate_gather = emu > 1
     frames = synth_frames(runner.frames_needed(total_steps + probe_steps, KF_EVERY, WIN), H, W, dev, seed=0)
 
     # prologue (untimed): the 6-keyframe initialisation window
@@ -191,6 +195,9 @@ def main():
     frames_total = frames_per_step * args.steps * world
     value = frames_total / elapsed
     log(f"timed region done: {elapsed:.3f}s for {frames_total} frames -> {value:.1f} frames/s")
+    from cut3r_slam_amd.track_frontend import TIMING
+    log(f"replay round trips per window [ms]: log-depth {1e3 * TIMING['sync1_s'] / max(1, TIMING['windows']):.2f}, "
+        f"window update {1e3 * TIMING['sync2_s'] / max(1, TIMING['windows']):.2f}")
     log("host wall-clock per step [ms]: " + ", ".join(f"{k[:-2]} {1e3 * v / max(1, runner.stats['steps']):.2f}" for k, v in runner.stats.items() if k != "steps"))
 
     roofline, cpu_base = None, None
@@ -225,7 +232,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "frames/sec (ViT pointmap + covisibility-graph tracking step) on 640x480", "value": round(value, 2),
+            "metric": "frames/sec (ViT pointmap + covisibility-graph tracking step) on 640x480" + (f" [DEBUG: rank 0 of an emulated {emu}-GPU job]" if emu > 1 else ""), "value": round(value, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",

@@ -56,7 +56,9 @@ SIGNATURES = {
     "cut3r_overlap_bwd": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_int, c_int,
                           c_void_p, c_void_p],
     "cut3r_window_update": [c_void_p, c_void_p, c_int, c_int, c_int, C.POINTER(c_float), c_float, c_int, c_void_p, c_void_p, c_void_p,
-                            c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_void_p, c_int, c_void_p],
+                            c_void_p, c_int, c_int, c_void_p, C.POINTER(c_float), c_int, c_int, c_float, c_float, c_float, c_float,
+                            c_void_p, c_int, c_void_p, c_void_p],
+    "cut3r_logdepth_accum": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "cut3r_align_view": [c_void_p, c_void_p, c_int, c_int, C.POINTER(c_float), c_float, c_int, c_void_p, c_void_p,
                          c_void_p, c_void_p],
     "cut3r_logdepth_sum": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],

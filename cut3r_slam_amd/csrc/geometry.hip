@@ -128,12 +128,20 @@ __global__ __launch_bounds__(256) void logdepth_kernel(const float* __restrict__
 // One tracking window = V consecutive keyframes t0..t0+V-1 whose network outputs sit in one [V,H,W,*] block.  The
 // per-view launches above (2 align + memset + fwd + memset + bwd per keyframe, ~35 launches per window) become FOUR
 // launches; per-element arithmetic is the same code (align chain, proj_valid), so every count is unchanged.
-struct WinArgs { float P[6][12]; float s; int V, t0, first; };
+struct WinArgs { float P[6][12]; float w2c_new[6][12]; float s; int V, t0, first, has_w2c; };
 
 __global__ __launch_bounds__(256) void win_align_kernel(const float* __restrict__ pts, const float* __restrict__ conf, int H, int W,
                                                         WinArgs wa, int ds, float* __restrict__ pm_ds, float* __restrict__ conf_ds,
-                                                        float* __restrict__ depth) {
+                                                        float* __restrict__ depth, float* __restrict__ w2c, int32_t* __restrict__ counts,
+                                                        int ldc, double* __restrict__ lsum_reset) {
     const int v = blockIdx.y;
+    // housekeeping that used to be separate stream operations: this view's world->camera row (host math, by value),
+    // its zeroed count rows, and the reset of the log-depth accumulator for the NEXT window
+    if (blockIdx.x == 0) {
+        if (wa.has_w2c && threadIdx.x < 12) w2c[12 * (size_t)(wa.t0 + v) + threadIdx.x] = wa.w2c_new[v][threadIdx.x];
+        if (v == 0 && threadIdx.x == 0 && lsum_reset) *lsum_reset = 0.0;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * ldc; i += gridDim.x * blockDim.x) counts[(size_t)v * 2 * ldc + i] = 0;
     const size_t n = (size_t)H * W;
     const float* p = pts + (size_t)v * n * 3;
     const float* c = conf + (size_t)v * n;
@@ -336,8 +344,8 @@ extern "C" int cut3r_align_view(const float* pts, const float* conf, int H, int 
 
 extern "C" int cut3r_window_update(const float* pts, const float* conf, int V, int H, int W, const float* P_host, float s, int ds,
                                    float* pm_ds, float* conf_ds, float* depth, const float* store, int grp, int grp_stride,
-                                   const float* w2c, int t0, int first, float fx, float fy, float cx, float cy,
-                                   int32_t* counts, int ldc, void* stream) {
+                                   float* w2c, const float* w2c_new_host, int t0, int first, float fx, float fy, float cx, float cy,
+                                   int32_t* counts, int ldc, double* lsum_reset, void* stream) {
     if (!pts || !conf || !P_host || !pm_ds || !conf_ds || !depth || !store || !w2c || !counts) return CUT3R_ERR_ARG;
     if (V < 1 || V > 6 || H <= 0 || W <= 0 || ds <= 0 || t0 < 0 || ldc < t0 + V || grp < 0 || (grp > 0 && grp_stride < grp)) return CUT3R_ERR_ARG;
     const int Nd = (H / ds) * (W / ds);
@@ -345,12 +353,14 @@ extern "C" int cut3r_window_update(const float* pts, const float* conf, int V, i
     WinArgs wa;
     for (int v = 0; v < V; v++)
         for (int i = 0; i < 12; i++) wa.P[v][i] = P_host[v * 12 + i];
-    wa.s = s; wa.V = V; wa.t0 = t0; wa.first = first;
+    wa.s = s; wa.V = V; wa.t0 = t0; wa.first = first; wa.has_w2c = w2c_new_host ? 1 : 0;
+    for (int v = 0; v < V; v++)
+        for (int i = 0; i < 12; i++) wa.w2c_new[v][i] = w2c_new_host ? w2c_new_host[v * 12 + i] : 0.f;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(win_align_kernel, dim3(grid_for((size_t)H * W), V), dim3(256), 0, st, pts, conf, H, W, wa, ds, pm_ds, conf_ds, depth);
+    hipLaunchKernelGGL(win_align_kernel, dim3(grid_for((size_t)H * W), V), dim3(256), 0, st, pts, conf, H, W, wa, ds, pm_ds, conf_ds, depth,
+                       w2c, counts, ldc, lsum_reset);
     const int last = t0 + V - 1;                  // newest keyframe: it sees cameras / pointmaps 0..last-1
     if (last >= first && last >= 1) {
-        if (hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)V * 2 * ldc, st) != hipSuccess) return CUT3R_ERR_LAUNCH;
         Cam camf{fx, fy, cx, cy, W, H};
         hipLaunchKernelGGL(win_fwd_kernel, dim3((H * W + 255) / 256, V), dim3(256), 0, st, pts, H * W, w2c, camf, counts, ldc, wa);
         // the reference tests the stored (stride-ds) pointmaps against the bounds of the DOWNSAMPLED map with the
@@ -372,6 +382,14 @@ extern "C" int cut3r_logdepth_sum(const float* prev_depth, const float* pts, int
     int g = grid_for((size_t)n);
     if (g > 512) g = 512;
     hipLaunchKernelGGL(logdepth_kernel, dim3(g), dim3(256), 0, s, prev_depth, pts, n, out);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_logdepth_accum(const float* prev_depth, const float* pts, int n, double* out, void* stream) {
+    if (!prev_depth || !pts || !out || n <= 0) return CUT3R_ERR_ARG;
+    int g = grid_for((size_t)n);
+    if (g > 512) g = 512;
+    hipLaunchKernelGGL(logdepth_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, prev_depth, pts, n, out);
     return cut3r_check_launch();
 }
 

@@ -59,16 +59,19 @@ class ShardedTracker:
                  append_fn: Callable = None, pipelined: bool = True, views: int = 6, force_collective: bool = False):
         self.slam, self.world, self.rank, self.wb = slam, world, rank, max(1, int(wb))
         self.infer_fn = infer_fn or self._infer
-        self.track_fn = track_fn or (lambda t0, t1, outs: slam.tracker.track(t0, t1, outputs=outs))
+        self.track_fn = track_fn          # None: TrackFrontend.track_many over all windows of the step (one round trip each)
         self.append_fn = append_fn or self._append
         self.pipelined = pipelined
         self.views = views
         self.force_collective = force_collective    # world == 1 rehearsal of the RCCL exchange
+        self.emulate_gather = False
         self._pending = None
         self._next_t0 = None            # first keyframe of the next window to be scheduled
         self._side = None
-        self.side_priority = int(os.environ.get("CUT3R_SIDE_PRIORITY", "-1"))         # side stream on its own high-priority hardware queue
-        self.stats = {"issue_s": 0.0, "replay_s": 0.0, "exchange_s": 0.0, "steps": 0}     # host wall-clock per phase
+        self._pose_pinned = [None, None]
+        self._first_event = None
+        self.side_priority = int(os.environ.get("CUT3R_SIDE_PRIORITY", "0"))         # 0: measured best; -1 (high) starves the network pass once the host runs ahead
+        self.stats = {"append_s": 0.0, "issue_s": 0.0, "replay_s": 0.0, "replay_wait_s": 0.0, "exchange_s": 0.0, "steps": 0}     # host wall-clock per phase
 
     def frames_needed(self, total_steps: int, kf_every: int, win: int) -> int:
         """frames consumed by the 7-keyframe initialisation plus `total_steps` steps"""
@@ -88,6 +91,26 @@ class ShardedTracker:
         return tuple(res[k] for k in ("pts3d_in_self_view", "conf_self", "camera_pose"))
 
     # ---- the pipeline
+    def _side_ctx(self, gathered, ev):
+        if ev is None or not self.pipelined:
+            return contextlib.nullcontext()
+        if self._side is None:
+            self._side = torch.cuda.Stream(priority=self.side_priority)
+        return torch.cuda.stream(self._side)
+
+    def _prefetch(self, pending):
+        """queue the log-depth reduction of the pending replay's first window (side stream, behind the exchange event)"""
+        self._first_event = None
+        if pending is None or self.track_fn is not None or not self.pipelined:
+            return
+        ranges_all, gathered, ev = pending
+        if ev is None:
+            return
+        with self._side_ctx(gathered, ev):
+            torch.cuda.current_stream().wait_event(ev)
+            V = self.views
+            self._first_event = self.slam.tracker.prefetch_logdepth(ranges_all[0][0], gathered[0][:V], gathered[2][:V])
+
     def _replay(self, pending):
         ranges_all, gathered, ev = pending
         V = self.views
@@ -96,16 +119,27 @@ class ShardedTracker:
             if self._side is None:
                 self._side = torch.cuda.Stream(priority=self.side_priority)
             self._side.wait_event(ev)
+            ev.synchronize()                        # pinned pose copy complete (issued a whole network pass ago)
+            self.stats["replay_wait_s"] += time.perf_counter() - tic
             for g in gathered:
-                g.record_stream(self._side)         # allocated on the main stream, consumed on the side stream
+                if g.is_cuda:
+                    g.record_stream(self._side)     # allocated on the main stream, consumed on the side stream
             ctx = torch.cuda.stream(self._side)
         else:
+            if ev is not None:
+                ev.synchronize()
+                self.stats["replay_wait_s"] += time.perf_counter() - tic
             ctx = contextlib.nullcontext()
         with ctx:
-            for j, (a, b) in enumerate(ranges_all):
-                sl = slice(j * V, (j + 1) * V)
-                self.track_fn(a, b, tuple(g[sl] for g in gathered))
-                self.slam.tracker.t1 = b
+            outs = [tuple(g[j * V:(j + 1) * V] for g in gathered) for j in range(len(ranges_all))]
+            if self.track_fn is not None:
+                for (a, b), o in zip(ranges_all, outs):
+                    self.track_fn(a, b, o)
+                    self.slam.tracker.t1 = b
+            else:
+                self.slam.tracker.track_many(ranges_all, outs, first_event=self._first_event)
+                self._first_event = None
+                self.slam.tracker.t1 = ranges_all[-1][1]
         self.stats["replay_s"] += time.perf_counter() - tic
 
     def step(self, frames, t, kf_every, win, intr):
@@ -119,13 +153,17 @@ class ShardedTracker:
         # 1. keyframe filter in fixed-cadence mode: every kf_every-th frame is a keyframe (motion_filter.py:83,109,124);
         #    every rank registers all of them, only the owner of a window ever encodes them
         n_frames = world * wb * win * kf_every
+        tic0 = time.perf_counter()
         for f in range(t, t + n_frames):
             if f % kf_every == 0:
                 k = slam.keyframes.counter.value
                 owner = min(max((k - first_t0 - 1) // (win * wb), 0), world - 1) if k > first_t0 else 0
                 self.append_fn(k, frames[f:f + 1], f, intr, owner == rank)
+        # 1b. the first device step of the pending replay goes onto the side stream BEFORE the network pass is queued
+        self._prefetch(self._pending)
         # 2. this rank's windows through the network (asynchronous on the main stream)
         tic = time.perf_counter()
+        self.stats["append_s"] += tic - tic0
         outs = self.infer_fn(mine)
         self.stats["issue_s"] += time.perf_counter() - tic
         # 3. meanwhile: replay the previous step's chaining + graph update (host-bound) on the side stream
@@ -134,11 +172,21 @@ class ShardedTracker:
             self._pending = None
         # 4. one exchange over xGMI (private copies when world == 1)
         tic = time.perf_counter()
-        gathered = all_gather_outputs(outs, world, self.force_collective)
+        if self.emulate_gather:      # debug (bench CUT3R_EMULATE_WORLD): this rank's outputs stand in for every other rank's
+            gathered = [torch.cat([t] * world, 0) for t in outs]
+        else:
+            gathered = all_gather_outputs(outs, world, self.force_collective)
         self.stats["exchange_s"] += time.perf_counter() - tic
         self.stats["steps"] += 1
         ev = None
         if gathered[0].is_cuda:
+            # the V x 7 camera poses go to pinned host memory now, on the main stream: the replay never waits for them
+            slot = self.stats["steps"] & 1          # two pinned buffers: the previous step's poses are still being replayed
+            if self._pose_pinned[slot] is None or self._pose_pinned[slot].shape != gathered[2].shape:
+                self._pose_pinned[slot] = torch.empty(gathered[2].shape, dtype=gathered[2].dtype).pin_memory()
+            pose_host = self._pose_pinned[slot]
+            pose_host.copy_(gathered[2], non_blocking=True)
+            gathered = [gathered[0], gathered[1], pose_host]
             ev = torch.cuda.Event()
             ev.record()
         self._pending = (ranges_all, gathered, ev)

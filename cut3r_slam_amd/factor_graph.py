@@ -70,10 +70,16 @@ class FactorGraph:
         self.keyframes = keyframes
         self.device = device
         self.max_factors = max_factors
-        self._ii, self._jj, self._age = [], [], []
+        self._ii, self._jj, self._born = [], [], []     # age of an edge = adds since its insertion = _epoch - _born (O(1) ageing)
+        self._epoch = 0
         self._eset = set()
         self._cache = None
         self.backend = backend if backend is not None else HipOverlapBackend(device)
+
+    @property
+    def _age(self):
+        """ages as the reference keeps them (age += 1 on every edge per add(), factor_graph.py:197)"""
+        return (self._epoch - np.asarray(self._born, dtype=np.int64)).tolist()
 
     # ------------------------------------------------------------------ tensor views (reference attribute names)
     def _tensors(self):
@@ -117,7 +123,7 @@ class FactorGraph:
         for i, j in new:
             self._ii.append(i)
             self._jj.append(j)
-            self._age.append(0)
+            self._born.append(self._epoch)
             self._eset.add((i, j))
         self._cache = None
 
@@ -126,7 +132,7 @@ class FactorGraph:
         keep = ~m.astype(bool)
         self._ii = [v for v, k in zip(self._ii, keep) if k]
         self._jj = [v for v, k in zip(self._jj, keep) if k]
-        self._age = [v for v, k in zip(self._age, keep) if k]
+        self._born = [v for v, k in zip(self._born, keep) if k]
         self._eset = set(zip(self._ii, self._jj))
         self._cache = None
 
@@ -262,7 +268,7 @@ class FactorGraph:
                 ii = np.full_like(jj, current_idx)
                 self.add_factors(ii, jj)
                 self.add_factors(jj, ii)
-        self._age = [a + 1 for a in self._age]
+        self._epoch += 1
         self._cache = None
 
     def add(self, current_idx, all_poses, all_pointmaps, current_pose, current_pointmap, K,

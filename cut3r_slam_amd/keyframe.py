@@ -24,7 +24,7 @@ class KeyFrame:
         self.device = torch.device(device)
         self._counter = 0
         dev = self.device
-        self.tstamp = torch.zeros(buffer, device=dev, dtype=torch.float)
+        self.tstamp = torch.zeros(buffer, dtype=torch.float)                              # host (a device scalar write would block on the stream)
         self.image = torch.zeros(buffer, 3, ht, wd, device=dev, dtype=torch.uint8)
         self.intrinsic = torch.zeros(buffer, 4, dtype=torch.float)                       # host
         self.pose = torch.zeros(buffer, 7, dtype=torch.float)                            # host, c2w (t, q_xyzw)
@@ -63,13 +63,16 @@ class KeyFrame:
         rows = gh.w2c_rows(gh.pose_vec_to_matrix(p.numpy()[None]))
         self.w2c[index].copy_(torch.from_numpy(rows[0]), non_blocking=True)
 
-    def set_poses(self, start: int, poses7) -> None:
-        """set_pose for the consecutive keyframes start.. in one host->device copy"""
+    def set_poses(self, start: int, poses7, upload: bool = True) -> np.ndarray:
+        """set_pose for the consecutive keyframes start..; returns their world->camera rows [n,12].  upload=False leaves
+        the device mirror to the caller (ops.window_update writes the rows from kernel arguments: no copy operation)."""
         p = np.asarray(poses7, np.float32).reshape(-1, 7)
         n = p.shape[0]
         self.pose[start:start + n] = torch.from_numpy(p)
         rows = gh.w2c_rows(gh.pose_vec_to_matrix(p))
-        self.w2c[start:start + n].copy_(torch.from_numpy(rows), non_blocking=True)
+        if upload:
+            self.w2c[start:start + n].copy_(torch.from_numpy(rows), non_blocking=True)
+        return rows
 
     def pointmap_slot(self, kf: int, sub_num: int, t0: int):
         """(submap, slot) holding the current estimate of keyframe `kf` as seen from window `sub_num` starting at t0

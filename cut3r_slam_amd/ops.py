@@ -367,10 +367,12 @@ def align_view(pts, conf, P12, s, ds, pm_ds, conf_ds, depth):
     check(lib.cut3r_align_view(_p(pts), _p(conf), H, W, arr, float(s), int(ds), _p(pm_ds), _p(conf_ds), _p(depth), _stream()), "cut3r_align_view")
 
 
-def window_update(pts, conf, P12s, s, ds, pm_ds, conf_ds, depth, store, w2c, t0, first, K4, counts, grp=5, grp_stride=6):
+def window_update(pts, conf, P12s, s, ds, pm_ds, conf_ds, depth, store, w2c, t0, first, K4, counts, grp=5, grp_stride=6,
+                  w2c_new=None, lsum_reset=None):
     """Whole-window align + overlap counts (cut3r_window_update).  pts [V,H,W,3], conf [V,H,W]; pm_ds [V,h,w,3], conf_ds [V,h,w],
     depth [V,H,W] are the window's consecutive store slots; store = the full [submaps,6,h,w,3] pointmap store; w2c [>=t0+V,12];
-    counts int32 [V,2,ldc] receives forward (row 0) / backward (row 1) counts of keyframes t0+v >= first."""
+    counts int32 [V,2,ldc] receives forward (row 0) / backward (row 1) counts of keyframes t0+v >= first.  w2c_new: V*12 host
+    floats written to rows t0.. of w2c by the kernel; lsum_reset: fp64[1] accumulator zeroed for the next window."""
     _cuda(pts, conf, pm_ds, conf_ds, depth, store, w2c, counts)
     V, H, W = conf.shape
     h, w = H // ds, W // ds
@@ -385,10 +387,17 @@ def window_update(pts, conf, P12s, s, ds, pm_ds, conf_ds, depth, store, w2c, t0,
     ldc = counts.shape[-1]
     _req(counts.dtype == torch.int32 and counts.is_contiguous() and counts.shape == (V, 2, ldc) and ldc >= t0 + V, "counts int32 [V,2,ldc]")
     arr = (C.c_float * (12 * V))(*[float(v) for v in P12s])
+    arr_w = None
+    if w2c_new is not None:
+        _req(len(w2c_new) == 12 * V, "w2c_new: V*12 floats")
+        arr_w = (C.c_float * (12 * V))(*[float(v) for v in w2c_new])
+    if lsum_reset is not None:
+        _cuda(lsum_reset)
+        _req(lsum_reset.dtype == torch.float64 and lsum_reset.numel() == 1, "lsum_reset fp64[1]")
     lib = _lib.load()
     check(lib.cut3r_window_update(_p(pts), _p(conf), V, H, W, arr, float(s), int(ds), _p(pm_ds), _p(conf_ds), _p(depth), _p(store),
-                                  int(grp), int(grp_stride), _p(w2c), int(t0), int(first), *[float(v) for v in K4], _p(counts), ldc,
-                                  _stream()), "cut3r_window_update")
+                                  int(grp), int(grp_stride), _p(w2c), arr_w, int(t0), int(first), *[float(v) for v in K4], _p(counts), ldc,
+                                  _p(lsum_reset), _stream()), "cut3r_window_update")
 
 
 def logdepth_sum(prev_depth, pts, out):
@@ -398,6 +407,16 @@ def logdepth_sum(prev_depth, pts, out):
     _req(out.dtype == torch.float64 and out.numel() == 1, "out fp64[1]")
     lib = _lib.load()
     check(lib.cut3r_logdepth_sum(_p(prev_depth), _p(pts), n, _p(out), _stream()), "cut3r_logdepth_sum")
+
+
+def logdepth_accum(prev_depth, pts, out):
+    """out += sum(log prev - log z); out must hold 0 beforehand (window_update's lsum_reset keeps it so)."""
+    _cuda(prev_depth, pts, out)
+    n = prev_depth.numel()
+    _req(prev_depth.dtype == F32 and prev_depth.is_contiguous() and pts.dtype == F32 and pts.is_contiguous() and pts.numel() == 3 * n, "logdepth inputs")
+    _req(out.dtype == torch.float64 and out.numel() == 1, "out fp64[1]")
+    lib = _lib.load()
+    check(lib.cut3r_logdepth_accum(_p(prev_depth), _p(pts), n, _p(out), _stream()), "cut3r_logdepth_accum")
 
 
 # ------------------------------------------------------------------------------------------------ loop closure

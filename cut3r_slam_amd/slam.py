@@ -62,7 +62,7 @@ class Cut3rSlam:
     def trajectory(self):
         """(tstamps [t], poses [t,7] c2w (t, q_xyzw)) of the tracked keyframes (demo_s.py:97-100)."""
         t = self.keyframes.counter.value - 1
-        return self.keyframes.tstamp[:t].cpu().numpy(), self.keyframes.pose[:t].numpy().copy()
+        return self.keyframes.tstamp[:t].numpy().copy(), self.keyframes.pose[:t].numpy().copy()
 
     def save_trajectory(self, path, tstamps_full=None):
         ts, poses = self.trajectory()

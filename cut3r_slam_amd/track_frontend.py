@@ -8,6 +8,7 @@ camera poses + one fp64 scalar (the log-depth sum); pointmaps, confidences and d
 from __future__ import annotations
 
 import math
+import time
 
 import numpy as np
 import torch
@@ -33,6 +34,9 @@ def make_views(model, images_u8):
     return views
 
 
+TIMING = {"sync1_s": 0.0, "sync2_s": 0.0, "windows": 0}     # host wall-clock of the two device round trips per window
+
+
 class TrackFrontend:
     def __init__(self, slam, keyframes, config, device="cuda:0"):
         self.device = device
@@ -52,8 +56,12 @@ class TrackFrontend:
         # keyframes and push them through the decoder TOGETHER (windows are independent network evaluations; the chaining
         # below stays sequential).  Trades latency (window_batch*5 keyframes) for MFMA-bound decoder GEMMs.
         self.window_batch = int(config.get("window_batch", 1))
-        self._lsum = torch.zeros(1, dtype=torch.float64, device=device)
+        self._lsum = torch.zeros(1, dtype=torch.float64, device=device)     # kept at 0 between windows (window_update resets it)
+        self._lsum_host = torch.zeros(1, dtype=torch.float64).pin_memory()
         self._counts = None
+        self._counts_host = None
+        self._pose_host = torch.zeros(8, 7, dtype=torch.float32).pin_memory()
+        self._ev = None
 
     def prepare_input(self, images):
         return make_views(self.model, images)
@@ -65,9 +73,19 @@ class TrackFrontend:
         kf = self.keyframes
         missing = [i for i in range(t0, t1) if not kf.feat_valid[i]]
         if missing:
-            idx = torch.as_tensor(missing, device=kf.image.device)
-            feats = self.model.encode_batch(kf.image[idx])
-            kf.featI[idx] = feats
+            # runs of consecutive keyframes -> slices of the resident image store (no index tensor: a host->device copy
+            # of pageable memory would block until the stream drains)
+            runs, a = [], missing[0]
+            for p, q in zip(missing, missing[1:] + [None]):
+                if q != p + 1:
+                    runs.append((a, p + 1))
+                    a = q
+            imgs = kf.image[runs[0][0]:runs[0][1]] if len(runs) == 1 else torch.cat([kf.image[a:b] for a, b in runs], 0)
+            feats = self.model.encode_batch(imgs)
+            o = 0
+            for a, b in runs:
+                kf.featI[a:b] = feats[o:o + b - a]
+                o += b - a
             for i in missing:
                 kf.feat_valid[i] = True
         return kf.featI[t0:t1]
@@ -87,67 +105,130 @@ class TrackFrontend:
     def track(self, t0, t1, init=False, outputs=None):
         """track_frontend.py:166-262.  `outputs` = (pts, conf, pose_enc) lets callers (tests, the multi-GPU
         driver) supply precomputed network outputs."""
-        kf, graph, ds = self.keyframes, self.graph, self.downsample_ratio
-        if init:
-            graph.add_neighborhood_factors(0, 3, r=3)
-        pts, conf, pose_enc = outputs if outputs is not None else self.infer(t0=t0, t1=t1)
-        V, H, W, _ = pts.shape
-        if not init:
-            ops.logdepth_sum(kf.depth[t0], pts[0], self._lsum)           # window k's view 0 == previous window's last KF
-            packed = torch.cat([pose_enc.detach().reshape(-1).double(), self._lsum]).cpu().numpy()   # sync point 1 of 2
-            host, lsum = packed[:-1].astype(np.float32).reshape(V, 7), float(packed[-1])
-        else:
-            host, lsum = pose_enc.detach().cpu().numpy(), None
-        poses = gh.pose_encoding_to_camera(host)
-        first_w2c = gh.inv4(poses[0])
-        sub_num = t0 // 5
-        align = None
-        if not init:
-            align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
-            prev_c2w = gh.pose_vec_to_matrix(kf.pose[t0].numpy()[None])[0]
-            align = (prev_c2w[:3, :3], prev_c2w[:3, 3], align_s)
-        # host: chained pose of every view, one vectorised matrix->quaternion conversion, ONE host->device copy of the
-        # world->camera rows (the reference converts and stores per keyframe, track_frontend.py:236-245)
-        chained, scales = [], []
-        for v in range(t1 - t0):
-            if init:
-                chained.append(gh.chain_pose(first_w2c, poses[v]))
-                scales.append(np.float32(1.0))
-            else:
-                chained.append(gh.chain_pose(first_w2c, poses[v], *align))
-                scales.append(align[2])
-        kf.set_poses(t0, gh.matrices_to_pose_vecs(np.stack(chained)))
-        centres = kf.pose[:t1, :3].numpy()                                  # zero-copy view of the host pose table
-        # device: ONE fused call stores every view (downsampled chained pointmap, confidence, depth) and counts the
-        # forward / backward overlaps of every keyframe of the window; the counts come back in one hop (the reference
-        # re-uploads all previous pointmaps and reads ratios back per keyframe, track_frontend.py:248-259)
-        V = t1 - t0
-        if self._counts is None or self._counts.shape[-1] < t1:
-            self._counts = torch.zeros(6, 2, max(256, 2 * t1), dtype=torch.int32, device=self.device)
-        intr = kf.intrinsic[t0:t1].numpy()
-        # one call per run of keyframes with equal intrinsics (a sequence has ONE calibration: normally one call)
-        groups, g0 = [], 0
-        for v in range(1, V + 1):
-            if v == V or not np.array_equal(intr[v], intr[g0]):
-                groups.append((g0, v))
-                g0 = v
-        done = {}
-        h, w = kf.submap_ds.shape[2:4]
-        for (a, b) in groups:
-            counts = self._counts[:b - a]
-            P12s = np.concatenate([c[:3, :4].reshape(-1) for c in chained[a:b]])
-            ops.window_update(pts[a:b], conf[a:b], P12s, float(scales[0]), ds, kf.submap_ds[sub_num, a:b], kf.conf_ds[sub_num, a:b],
-                              kf.depth[t0 + a:t0 + b], kf.submap_ds, kf.w2c, t0 + a, 3, [float(x) for x in intr[a]], counts)
-            if t0 + b - 1 >= 3:
-                host = counts.cpu().numpy()                                              # sync point 2 of 2
-                for tk, cf, cb in graph.window_tickets(t0 + a, t0 + b, centres, host, H * W, h * w):
-                    done[tk["idx"]] = (tk, cf.copy(), cb.copy())
-        # decision phase, in the reference's order: neighbourhood factors of keyframe i, then its overlap factors
+        if outputs is None:
+            outputs = self.infer(t0=t0, t1=t1)
+        self.track_many([(t0, t1)], [outputs], init=init)
+
+    def _decide(self, t0, t1, init, done):
+        """decision half of a window, in the reference's order: neighbourhood factors of keyframe i, then its overlap
+        factors (track_frontend.py:246-261 -> factor_graph.py:109-117, 170-197).  Host only."""
+        graph = self.graph
         for i in range(t0, t1):
             if not init:
                 graph.add_neighborhood_factors(i - 3, i + 1, r=3)
             if i in done:
                 graph.add_finish(*done[i])
+
+    def prefetch_logdepth(self, t0, pts, pose_enc):
+        """Issue (no wait) the log-depth reduction + pose read-back of the first window of a coming track_many call, so a
+        pipelined driver can queue it AHEAD of the next network pass; pass the returned event as `first_event`."""
+        kf = self.keyframes
+        if pose_enc.is_cuda:
+            self._pose_host[:pose_enc.shape[0]].copy_(pose_enc.detach(), non_blocking=True)
+        ops.logdepth_accum(kf.depth[t0], pts[0], self._lsum)
+        self._lsum_host.copy_(self._lsum, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def track_many(self, ranges, outputs, init=False, first_event=None):
+        """The sequential part of tracking for consecutive windows `ranges` = [(t0, t1), ...] with their network outputs
+        [(pts [V,H,W,3], conf [V,H,W], pose_enc [V,7] device or host), ...]: log-depth scale + pose chaining
+        (track_frontend.py:193-245), keyframe store update and covisibility-graph update (:246-261).
+
+        ONE device round trip per window: the fused window update of window k is followed on the stream by the log-depth
+        reduction of window k+1 (it needs only the depth window k has just stored), both results come back together, and
+        the host-only graph decisions of window k run while the device works on window k+1."""
+        kf, graph, ds = self.keyframes, self.graph, self.downsample_ratio
+        if self._ev is None:
+            self._ev = torch.cuda.Event()
+        if init:
+            graph.add_neighborhood_factors(0, 3, r=3)
+        pending = None                    # (t0, t1, init, done) of the previous window: its decisions are still to be made
+        lsum_next = None                  # log-depth sum of the coming window when the previous round trip brought it back
+        h, w = kf.submap_ds.shape[2:4]
+        for k, ((t0, t1), (pts, conf, pose_enc)) in enumerate(zip(ranges, outputs)):
+            V, H, W, _ = pts.shape
+            if k == 0 and first_event is not None and not init:
+                tic = time.perf_counter()
+                first_event.synchronize()                                 # issued by prefetch_logdepth before the network pass
+                lsum_next = float(self._lsum_host[0])
+                TIMING["sync1_s"] += time.perf_counter() - tic
+            if pose_enc.is_cuda and lsum_next is None:
+                self._pose_host[:V].copy_(pose_enc.detach(), non_blocking=True)
+            if not init and lsum_next is None:
+                tic = time.perf_counter()
+                ops.logdepth_accum(kf.depth[t0], pts[0], self._lsum)     # window k's view 0 == previous window's last KF
+                self._lsum_host.copy_(self._lsum, non_blocking=True)
+                self._ev.record()
+                self._ev.synchronize()                                    # extra round trip: first window of a call only
+                lsum_next = float(self._lsum_host[0])
+                TIMING["sync1_s"] += time.perf_counter() - tic
+            elif init and pose_enc.is_cuda:
+                self._ev.record()
+                self._ev.synchronize()
+            host = (self._pose_host[:V] if pose_enc.is_cuda else pose_enc).numpy().copy()
+            lsum, lsum_next = lsum_next, None
+            poses = gh.pose_encoding_to_camera(host)
+            first_w2c = gh.inv4(poses[0])
+            sub_num = t0 // 5
+            align = None
+            if not init:
+                align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
+                prev_c2w = gh.pose_vec_to_matrix(kf.pose[t0].numpy()[None])[0]
+                align = (prev_c2w[:3, :3], prev_c2w[:3, 3], align_s)
+            # host: chained pose of every view, one vectorised matrix->quaternion conversion (the reference converts and
+            # stores per keyframe, track_frontend.py:236-245); the world->camera rows travel as kernel arguments
+            if init:
+                chained, s_win = [gh.chain_pose(first_w2c, poses[v]) for v in range(V)], np.float32(1.0)
+            else:
+                chained, s_win = [gh.chain_pose(first_w2c, poses[v], *align) for v in range(V)], align[2]
+            w2c_rows = kf.set_poses(t0, gh.matrices_to_pose_vecs(np.stack(chained)), upload=False)
+            centres = kf.pose[:t1, :3].numpy()                              # zero-copy view of the host pose table
+            # device: ONE fused call stores every view (downsampled chained pointmap, confidence, depth) and counts the
+            # forward / backward overlaps of every keyframe of the window (the reference re-uploads all previous pointmaps
+            # and reads ratios back per keyframe, track_frontend.py:248-259)
+            if self._counts is None or self._counts.shape[-1] < t1:
+                self._counts = torch.zeros(6, 2, max(256, 2 * t1), dtype=torch.int32, device=self.device)
+                self._counts_host = torch.zeros(6, 2, self._counts.shape[-1], dtype=torch.int32).pin_memory()
+            intr = kf.intrinsic[t0:t1].numpy()
+            # one call per run of keyframes with equal intrinsics (a sequence has ONE calibration: normally one call)
+            groups, g0 = [], 0
+            for v in range(1, V + 1):
+                if v == V or not np.array_equal(intr[v], intr[g0]):
+                    groups.append((g0, v))
+                    g0 = v
+            tic = time.perf_counter()
+            for (a, b) in groups:
+                ops.window_update(pts[a:b], conf[a:b], np.concatenate([c[:3, :4].reshape(-1) for c in chained[a:b]]), float(s_win), ds,
+                                  kf.submap_ds[sub_num, a:b], kf.conf_ds[sub_num, a:b], kf.depth[t0 + a:t0 + b], kf.submap_ds, kf.w2c,
+                                  t0 + a, 3, [float(x) for x in intr[a]], self._counts[a:b], w2c_new=w2c_rows[a:b].reshape(-1),
+                                  lsum_reset=self._lsum)
+            self._counts_host[:V].copy_(self._counts[:V], non_blocking=True)
+            prefetch = (not init) and k + 1 < len(ranges)
+            if prefetch:                 # the next window's log-depth sum (and poses) ride on the same round trip
+                nt0, (npts, _, npose) = ranges[k + 1][0], outputs[k + 1]
+                ops.logdepth_accum(kf.depth[nt0], npts[0], self._lsum)
+                self._lsum_host.copy_(self._lsum, non_blocking=True)
+                if npose.is_cuda:
+                    self._pose_host[:npose.shape[0]].copy_(npose.detach(), non_blocking=True)
+            self._ev.record()
+            if pending is not None:      # host-only decisions of the previous window while the device works on this one
+                self._decide(*pending)
+            self._ev.synchronize()                                        # THE round trip of the window
+            TIMING["sync2_s"] += time.perf_counter() - tic
+            TIMING["windows"] += 1
+            if prefetch:
+                lsum_next = float(self._lsum_host[0])
+            done = {}
+            host_counts = self._counts_host.numpy()
+            for (a, b) in groups:
+                if t0 + b - 1 >= 3:
+                    for tk, cf, cb in graph.window_tickets(t0 + a, t0 + b, centres, host_counts[a:b], H * W, h * w):
+                        done[tk["idx"]] = (tk, cf.copy(), cb.copy())
+            pending = (t0, t1, init, done)
+        if pending is not None:
+            self._decide(*pending)
 
     def track_batch(self, ranges):
         """several consecutive 6-keyframe windows: ONE batched decoder/head inference, then the reference's sequential
@@ -157,10 +238,10 @@ class TrackFrontend:
         feats = torch.stack([self.window_features(a, b) for a, b in ranges], 0)          # [Wb,6,N,E] (all cached now)
         res = self.model.decode_windows(feats, kf.ht, kf.wd)
         V = ranges[0][1] - ranges[0][0]
-        for j, (a, b) in enumerate(ranges):
-            sl = slice(j * V, (j + 1) * V)
-            self.track(a, b, outputs=(res["pts3d_in_self_view"][sl], res["conf_self"][sl], res["camera_pose"][sl]))
-            self.t1 = b
+        outs = [(res["pts3d_in_self_view"][j * V:(j + 1) * V], res["conf_self"][j * V:(j + 1) * V], res["camera_pose"][j * V:(j + 1) * V])
+                for j in range(len(ranges))]
+        self.track_many(ranges, outs)
+        self.t1 = ranges[-1][1]
 
     # ------------------------------------------------------------------ scheduling (track_frontend.py:285-330)
     def run(self, tstamp, last_frame=False):

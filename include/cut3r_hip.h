@@ -129,16 +129,23 @@ int cut3r_overlap_bwd(const float* pms, int B, int N, int grp, int grp_stride, c
  * counts of its full-resolution chained pointmap in cameras 0..i-1 and the backward counts of stored pointmaps 0..i-1
  * (slot addressing as cut3r_overlap_bwd, over `store`) in camera i.  pts [V,H,W,3], conf [V,H,W] contiguous; P_host
  * V*12 HOST floats; w2c device [>= t0+V, 12]; counts int32 device [V][2][ldc] (row 0 forward, row 1 backward; ldc >=
- * t0+V), zeroed here.  Four launches instead of ~6 per keyframe; every count equals the per-keyframe entry points'. */
+ * t0+V), zeroed here.  w2c_new_host (optional, V*12 HOST floats): rows t0..t0+V-1 of w2c are written from it first (the
+ * keyframe store's device mirror, hislam2/keyframe.py:24 pose) -- no separate upload.  lsum_reset (optional): a
+ * cut3r_logdepth_accum accumulator zeroed for the next window.  Three launches instead of ~6 per keyframe; every count
+ * equals the per-keyframe entry points'. */
 int cut3r_window_update(const float* pts, const float* conf, int V, int H, int W, const float* P_host, float s, int ds,
                         float* pm_ds, float* conf_ds, float* depth, const float* store, int grp, int grp_stride,
-                        const float* w2c, int t0, int first, float fx, float fy, float cx, float cy, int32_t* counts, int ldc,
-                        void* stream);
+                        float* w2c, const float* w2c_new_host, int t0, int first, float fx, float fy, float cx, float cy,
+                        int32_t* counts, int ldc, double* lsum_reset, void* stream);
 
 /* ---- window alignment -----------------------------------------------------------------------------------------------
  * replaces the per-view tensor math of TrackFrontend.track (hislam2/track_frontend.py:193-243): pointmap = P*(s*pts),
  * conf <- 1-1/conf, depth = s*z, stride-`ds` downsample.  P_host: 12 HOST floats (chained c2w 3x4, row-major), s by value
  * (both are products of tiny 4x4 host math on the 7-float camera poses, exactly as in the reference). */
+/* cut3r_logdepth_sum without the zeroing memset: *out += sum(log prev - log z) (the caller keeps *out zeroed, e.g. through
+ * cut3r_window_update's lsum_reset) */
+int cut3r_logdepth_accum(const float* prev_depth, const float* pts, int n, double* out, void* stream);
+
 int cut3r_align_view(const float* pts, const float* conf, int H, int W, const float* P_host, float s, int ds,
                      float* pm_ds, float* conf_ds, float* depth, void* stream);
 /* sum_i log(prev_depth[i]) - log(pts[i].z) -> out[0] (fp64 accumulate, device double[1], zeroed by the call) */

@@ -411,8 +411,12 @@ def test_window_update_matches_per_keyframe_calls():
     got_conf = torch.zeros(nsub, 6, h, w, device=DEV)
     got_depth = torch.zeros(V, H, W, device=DEV)
     counts = torch.full((V, 2, 64), -1, dtype=torch.int32, device=DEV)
-    ops.window_update(pts, conf, P.reshape(-1).tolist(), s, ds, got_store[sub, :V], got_conf[sub, :V], got_depth, got_store, w2c, t0, 3,
-                      K4, counts)
+    w2c_dev = w2c.clone()
+    w2c_dev[t0:] = 7.0                               # rows of the window's keyframes arrive through the kernel arguments
+    lsum = torch.full((1,), 3.0, dtype=torch.float64, device=DEV)
+    ops.window_update(pts, conf, P.reshape(-1).tolist(), s, ds, got_store[sub, :V], got_conf[sub, :V], got_depth, got_store, w2c_dev, t0, 3,
+                      K4, counts, w2c_new=w2c[t0:].reshape(-1).tolist(), lsum_reset=lsum)
+    assert torch.equal(w2c_dev, w2c) and float(lsum) == 0.0
     torch.cuda.synchronize()
     assert torch.equal(got_store, ref_store) and torch.equal(got_conf, ref_conf) and torch.equal(got_depth, ref_depth)
     c = counts.cpu()
