@@ -41,31 +41,36 @@ def synth_frames(n, H, W, device, seed=0):
 
 
 class GemmProbe:
-    """HIP-event timing of every launch of the dominant kernel (tile-128 GEMM) on the launch stream."""
+    """HIP-event timing of every launch of the two large-tile GEMM kernels (128^2 and 256^2) on the launch stream."""
+
+    KERNELS = {128: "gemm_kernel<128,128,2,4,2> (v_mfma_f32_16x16x32_f16, 8 waves, 2 workgroups/CU)",
+               256: "gemm256_kernel (256x256x64, v_mfma_f32_16x16x32_f16, 8 waves ping-pong, 1 workgroup/CU)"}
 
     def __init__(self):
-        self.ev, self.flops, self.bytes = [], 0.0, 0.0
+        self.ev = {128: [], 256: []}
+        self.flops = {128: 0.0, 256: 0.0}
+        self.bytes = {128: 0.0, 256: 0.0}
 
     def install(self):
-        from cut3r_slam_amd import ops, _lib
-        import ctypes as C
+        from cut3r_slam_amd import _lib
         lib = _lib.load()
         raw = lib.cut3r_gemm_f16
         probe = self
 
         def wrapped(dref, stream):
             d = dref._obj
-            big = ((d.M + 127) // 128) * ((d.N + 127) // 128) * max(d.batch, 1)
-            if (d.tile == 128) or (d.tile == 0 and big >= 128):
+            tile = lib.cut3r_gemm_tile_for(dref)
+            if tile in (128, 256):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 rc = raw(dref, stream)
                 e.record()
-                probe.ev.append((s, e))
-                probe.flops += 2.0 * d.M * d.N * d.K * max(d.batch, 1)
-                a_bytes = (d.M * d.Cin * 2 / max(d.conv_stride, 1) ** 0) if d.conv_k == 3 else d.M * d.K * 2   # conv input is read once
-                probe.bytes += max(d.batch, 1) * (a_bytes + d.N * d.K * 2 + d.M * d.N * (2 if d.out_f16 else 4)
-                                                  + (d.M * d.N * (2 if d.res1_f16 else 4) if d.res1 else 0))
+                probe.ev[tile].append((s, e))
+                nb = max(d.batch, 1)
+                probe.flops[tile] += 2.0 * d.M * d.N * d.K * nb
+                a_bytes = d.M * d.Cin * 2 if d.conv_k == 3 else d.M * d.K * 2        # a conv input is read once
+                probe.bytes[tile] += nb * (a_bytes + d.N * d.K * 2 + d.M * d.N * (2 if d.out_f16 else 4)
+                                           + (d.M * d.N * (2 if d.res1_f16 else 4) if d.res1 else 0))
                 return rc
             return raw(dref, stream)
 
@@ -76,10 +81,9 @@ class GemmProbe:
         self._lib.cut3r_gemm_f16 = self._raw
 
     def result(self):
+        """{tile: (launches, total ms, flops, algorithmic bytes)}"""
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e in self.ev)
-        n = len(self.ev)
-        return n, ms, self.flops, self.bytes
+        return {t: (len(ev), sum(s.elapsed_time(e) for s, e in ev), self.flops[t], self.bytes[t]) for t, ev in self.ev.items()}
 
 
 def log(msg):
@@ -212,19 +216,27 @@ def main():
             for _ in range(args.steps):
                 t = one_step(t)
             runner.flush()
-            n, ms, fl, by = probe.result()
+            res = probe.result()
             probe.remove()
             model.use_graphs = True
+            dom = max(res, key=lambda tk: res[tk][1])          # the kernel with the largest total time in this workload
+            n, ms, fl, by = res[dom]
             if n:
                 ach = fl / (ms * 1e-3) / 1e12
                 traffic = None
-                pj = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_gemm128.json")
+                pj = os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_gemm{dom}.json")
                 if os.path.isfile(pj):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/pmc_traffic.py)
                     traffic = json.load(open(pj)).get("traffic_bytes_per_launch")
-                roofline = {"bound": "mfma", "kernel": "gemm_kernel<128,128,2,4,2> (v_mfma_f32_16x16x32_f16, 8 waves)", "achieved": round(ach, 2),
+                other = {}
+                for tk, (n2, ms2, fl2, by2) in res.items():
+                    if tk != dom and n2:
+                        other = {"kernel": GemmProbe.KERNELS[tk], "launches": n2, "avg_launch_us": round(ms2 * 1e3 / n2, 2),
+                                 "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2), "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / 2500.0, 4),
+                                 "share_of_large_gemm_time": round(ms2 / (ms + ms2), 3)}
+                roofline = {"bound": "mfma", "kernel": GemmProbe.KERNELS[dom], "achieved": round(ach, 2),
                             "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
                             "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n,
-                            "algorithmic_bytes_per_launch": by / n}
+                            "algorithmic_bytes_per_launch": by / n, "second_kernel": other}
     if rank == 0 and not args.no_cpu_baseline and not args.small:
         log("cpu baseline (oracle on host cores)")
         cpu_base = cpu_baseline(cfg, sd, frames[:2].cpu(), frames_per_step)

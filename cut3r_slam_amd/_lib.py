@@ -39,6 +39,7 @@ SIGNATURES = {
     "cut3r_layernorm": [c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                         c_void_p, c_void_p, c_void_p],
     "cut3r_gemm_f16": [C.POINTER(GemmDesc), c_void_p],
+    "cut3r_gemm_tile_for": [C.POINTER(GemmDesc)],
     "cut3r_gemv_f16w": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                         c_void_p, c_int, c_int, c_void_p],
     "cut3r_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -36,6 +36,20 @@ DEVINL int wave_sum_i(int v) {
 // exact GELU (nn.GELU default, erf form) -- src/croco/models/blocks.py:75 act_layer=nn.GELU
 DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// The same function for fp16 OUTPUTS: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, three orders below the fp16
+// rounding of the result), written on |x| so the negative branch has no 1 + erf cancellation.  ~14 VALU instructions
+// instead of libm's ~35 with branches: in a GEMM epilogue this is the difference between VALU-bound and free.
+DEVINL float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float h = 0.5f * (p * t) * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);   // 0.5 * (1 - erf(z))
+    return x >= 0.0f ? x * (1.0f - h) : x * h;
+}
+
 static inline int cut3r_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CUT3R_OK : CUT3R_ERR_LAUNCH;

@@ -70,7 +70,7 @@ DEVINL void fused_store4(const GemmArgs& g, int z, const float* bias, int gm, in
     if (bias) v += *reinterpret_cast<const f32x4*>(bias + bcol);
     if (g.act == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+        for (int e = 0; e < 4; e++) v[e] = g.out_f16 ? gelu_fast(v[e]) : gelu_erf(v[e]);
     } else if (g.act == 2) {
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
@@ -554,6 +554,23 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ X, 
 
 }  // namespace
 
+extern "C" int cut3r_gemm_tile_for(const cut3r_gemm_desc* d) {
+    if (!d) return 0;
+    if (d->tile != 0) return d->tile;
+    const int batch = d->batch > 0 ? d->batch : 1;
+    const long long big_blocks = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
+    // measured (tools/bench_gemm256.py, tools/bench_gemm.py): the 256^2 ping-pong kernel wins once its grid fills the
+    // chip (>= 200 tiles) on plain linears with N a multiple of 256; 3x3 convolutions and short grids stay on 128^2
+    // (two co-resident workgroups hide each other's prologue / epilogue); 64^2 below 128 tiles of 128^2
+    static const long long t256_min = [] { const char* e = getenv("CUT3R_GEMM_T256_MIN"); return e ? atoll(e) : 200LL; }();
+    const long long blocks256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
+    // one workgroup per CU: a grid of 300 tiles costs two full rounds, so also require >= 85 % of the last round
+    const long long rounds = (blocks256 + 255) / 256;
+    const bool fills = blocks256 * 100 >= rounds * 256 * 85;
+    if (d->conv_k != 3 && !d->shuf && (d->N & 255) == 0 && blocks256 >= t256_min && fills) return 256;
+    return (big_blocks >= 128) ? 128 : 64;
+}
+
 extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->B || !d->C) return CUT3R_ERR_ARG;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return CUT3R_ERR_ARG;
@@ -577,9 +594,7 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     g.prio = (d->stages == 12) ? 1 : 0;
     const int batch = d->batch > 0 ? d->batch : 1;
     hipStream_t s = (hipStream_t)stream;
-    const long long big_blocks = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
-    int tile = d->tile;
-    if (tile == 0) tile = (big_blocks >= 128) ? 128 : 64;     // measured crossover (tools/bench_gemm.py)
+    const int tile = cut3r_gemm_tile_for(d);
     if (tile == 256) {
         dim3 grid(((d->N + 255) / 256) * ((d->M + 255) / 256), 1, batch);
         if (d->conv_k == 3 && d->relu_in) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, dim3(512), 0, s, g);
