@@ -3,18 +3,20 @@
 One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 What shards: every `inference()` call re-initialises the recurrent state and the pose memory
-(/root/reference/src/dust3r/model.py:819-822), so tracking WINDOWS are independent network evaluations; only the cheap
-post-hoc chaining (/root/reference/hislam2/track_frontend.py:216-234: needs the previous window's last depth and pose)
-and the graph update are sequential.  Per step every rank pushes `wb` consecutive windows through the network in one
-batched pass (encoder for its new keyframes, decoder + heads batched over the windows), the three consumed outputs
-(pts3d_in_self_view, conf_self, camera_pose: 19 MB per window at 384x512) are exchanged with ONE all_gather per tensor
--- small messages: latency, not ring bandwidth, matters -- and every rank replays the chaining + graph update of all
-world*wb windows in sequence order, keeping the keyframe store and the graph replicated (no second collective; any rank
-can serve the trajectory).
+(/root/reference/src/dust3r/model.py:819-822), so tracking WINDOWS are independent network evaluations; only the post-hoc
+chaining (/root/reference/hislam2/track_frontend.py:216-234: needs the previous window's last depth and pose) and the
+graph decisions are sequential.  Per step every rank
+  1. pushes `wb` consecutive windows through the network in one batched pass (encoder for its new keyframes, decoder +
+     heads batched over the windows),
+  2. exchanges the three consumed outputs (pts3d_in_self_view, conf_self, camera_pose: 19 MB per window at 384x512) with
+     ONE all_gather per tensor,
+  3. replays the chaining of all world*wb windows in sequence order (O(1) device work per window: the keyframe store stays
+     replicated, any rank can serve the trajectory), counts the O(#keyframes) reprojection overlaps only for the windows
+     it owns, sums the owners' counts with one small all-reduce, and takes the graph decisions (host only, replicated).
 
-Pipelining: the replay of step s runs on a side HIP stream while the network pass of step s+1 is already executing on
-the main stream (the replay is host-latency-bound: tiny kernels + small device->host reads), so a step costs
-max(network time, replay time) instead of their sum.  `flush()` drains the last replay.
+Pipelining: the replay of step s runs on a side HIP stream while the encoder graph of step s+1 executes on the main
+stream; the decoder graph of step s+1 is launched after the replay has been issued (a graph with parallel branches
+delays anything queued behind it on a shared hardware queue).  `flush()` drains the last replay.
 """
 from __future__ import annotations
 
@@ -58,20 +60,20 @@ class ShardedTracker:
     def __init__(self, slam, world: int, rank: int, wb: int = 1, infer_fn: Callable = None, track_fn: Callable = None,
                  append_fn: Callable = None, pipelined: bool = True, views: int = 6, force_collective: bool = False):
         self.slam, self.world, self.rank, self.wb = slam, world, rank, max(1, int(wb))
-        self.infer_fn = infer_fn or self._infer
+        self.infer_fn = infer_fn          # None: the real network (encoder graph, replay of the previous step, decoder graph)
         self.track_fn = track_fn          # None: TrackFrontend.track_many over all windows of the step (one round trip each)
         self.append_fn = append_fn or self._append
         self.pipelined = pipelined
         self.views = views
         self.force_collective = force_collective    # world == 1 rehearsal of the RCCL exchange
         self.emulate_gather = False
+        self.shard_counting = os.environ.get("CUT3R_SHARD_COUNTING", "1") == "1"
         self._pending = None
         self._next_t0 = None            # first keyframe of the next window to be scheduled
         self._side = None
         self._pose_pinned = [None, None]
-        self._first_event = None
         self.side_priority = int(os.environ.get("CUT3R_SIDE_PRIORITY", "0"))         # 0: measured best; -1 (high) starves the network pass once the host runs ahead
-        self.stats = {"append_s": 0.0, "issue_s": 0.0, "replay_s": 0.0, "replay_wait_s": 0.0, "exchange_s": 0.0, "steps": 0}     # host wall-clock per phase
+        self.stats = {"append_s": 0.0, "issue_s": 0.0, "issue_enc_s": 0.0, "replay_s": 0.0, "replay_wait_s": 0.0, "exchange_s": 0.0, "steps": 0}     # host wall-clock per phase
 
     def frames_needed(self, total_steps: int, kf_every: int, win: int) -> int:
         """frames consumed by the 7-keyframe initialisation plus `total_steps` steps"""
@@ -82,11 +84,19 @@ class ShardedTracker:
         # fixed cadence: the encoder pass of a keyframe is deferred to the rank that owns its window
         self.slam.keyframes.append(tstamp, frame[0], None, None, None, None, intr, None, None)
 
-    def _infer(self, ranges):
-        """batched network pass over this rank's windows -> (pts [wb*V,H,W,3], conf [wb*V,H,W], pose [wb*V,7])"""
-        tr, kf = self.slam.tracker, self.slam.keyframes
-        tr.window_features(ranges[0][0], ranges[-1][1])                 # encode the not-yet-encoded keyframes, batched
-        feats = torch.stack([tr.window_features(a, b) for a, b in ranges], 0)
+    def _encode(self, ranges):
+        """encoder pass over this rank's not-yet-encoded keyframes (batched) -> window features [wb,V,N,E]"""
+        tr = self.slam.tracker
+        if self.world > 1:
+            # keep the encoder batch shape the same in every step (one captured graph): with more than one rank the first
+            # keyframe of a rank's range is usually another rank's, so it is (re-)encoded always (bit-identical features)
+            self.slam.keyframes.feat_valid[ranges[0][0]] = False
+        tr.window_features(ranges[0][0], ranges[-1][1])
+        return torch.stack([tr.window_features(a, b) for a, b in ranges], 0)
+
+    def _decode(self, feats):
+        """batched decoder + heads over this rank's windows -> (pts [wb*V,H,W,3], conf [wb*V,H,W], pose [wb*V,7])"""
+        kf = self.slam.keyframes
         res = self.slam.model.decode_windows(feats, kf.ht, kf.wd)
         return tuple(res[k] for k in ("pts3d_in_self_view", "conf_self", "camera_pose"))
 
@@ -95,21 +105,25 @@ class ShardedTracker:
         if ev is None or not self.pipelined:
             return contextlib.nullcontext()
         if self._side is None:
-            self._side = torch.cuda.Stream(priority=self.side_priority)
+            self._side = self._make_side_stream()
         return torch.cuda.stream(self._side)
 
-    def _prefetch(self, pending):
-        """queue the log-depth reduction of the pending replay's first window (side stream, behind the exchange event)"""
-        self._first_event = None
-        if pending is None or self.track_fn is not None or not self.pipelined:
-            return
-        ranges_all, gathered, ev = pending
-        if ev is None:
-            return
-        with self._side_ctx(gathered, ev):
-            torch.cuda.current_stream().wait_event(ev)
-            V = self.views
-            self._first_event = self.slam.tracker.prefetch_logdepth(ranges_all[0][0], gathered[0][:V], gathered[2][:V])
+    def _make_side_stream(self):
+        # HIP deals streams onto the hardware queues round-robin; CUT3R_SIDE_SKIP throwaway streams shift the side stream to
+        # another queue (tuning knob: a queue shared with a graph branch delays the first replay operation of every step)
+        self._skipped = [torch.cuda.Stream() for _ in range(int(os.environ.get("CUT3R_SIDE_SKIP", "0")))]
+        return torch.cuda.Stream(priority=self.side_priority)
+
+    def _exchange_counts(self, counts):
+        """sum of the owners' overlap counts over the ranks (host int32 tensor; rows a rank does not own are zero)"""
+        if self.emulate_gather or not dist.is_initialized():
+            return counts
+        if dist.get_backend() == "nccl":
+            dev = counts.cuda(non_blocking=True)
+            dist.all_reduce(dev, op=dist.ReduceOp.SUM)
+            return dev.cpu()
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        return counts
 
     def _replay(self, pending):
         ranges_all, gathered, ev = pending
@@ -117,7 +131,7 @@ class ShardedTracker:
         tic = time.perf_counter()
         if ev is not None and self.pipelined:
             if self._side is None:
-                self._side = torch.cuda.Stream(priority=self.side_priority)
+                self._side = self._make_side_stream()
             self._side.wait_event(ev)
             ev.synchronize()                        # pinned pose copy complete (issued a whole network pass ago)
             self.stats["replay_wait_s"] += time.perf_counter() - tic
@@ -137,8 +151,12 @@ class ShardedTracker:
                     self.track_fn(a, b, o)
                     self.slam.tracker.t1 = b
             else:
-                self.slam.tracker.track_many(ranges_all, outs, first_event=self._first_event)
-                self._first_event = None
+                mask, exch = None, None
+                if self.world > 1 and self.shard_counting:
+                    # the O(#keyframes) overlap counting of a window runs on its owner only; one small all-reduce per step
+                    mask = [self.rank * self.wb <= j < (self.rank + 1) * self.wb for j in range(len(ranges_all))]
+                    exch = self._exchange_counts
+                self.slam.tracker.track_many(ranges_all, outs, count_mask=mask, exchange=exch)
                 self.slam.tracker.t1 = ranges_all[-1][1]
         self.stats["replay_s"] += time.perf_counter() - tic
 
@@ -159,17 +177,30 @@ class ShardedTracker:
                 k = slam.keyframes.counter.value
                 owner = min(max((k - first_t0 - 1) // (win * wb), 0), world - 1) if k > first_t0 else 0
                 self.append_fn(k, frames[f:f + 1], f, intr, owner == rank)
-        # 1b. the first device step of the pending replay goes onto the side stream BEFORE the network pass is queued
-        self._prefetch(self._pending)
-        # 2. this rank's windows through the network (asynchronous on the main stream)
         tic = time.perf_counter()
         self.stats["append_s"] += tic - tic0
-        outs = self.infer_fn(mine)
-        self.stats["issue_s"] += time.perf_counter() - tic
-        # 3. meanwhile: replay the previous step's chaining + graph update (host-bound) on the side stream
-        if self._pending is not None:
-            self._replay(self._pending)
-            self._pending = None
+        if self.infer_fn is not None:
+            # 2'. (test doubles) whole network pass, then the replay of the previous step
+            outs = self.infer_fn(mine)
+            self.stats["issue_s"] += time.perf_counter() - tic
+            if self._pending is not None:
+                self._replay(self._pending)
+                self._pending = None
+        else:
+            # 2. encoder graph of this rank's new keyframes (one stream), asynchronous on the main stream
+            feats = self._encode(mine)
+            self.stats["issue_s"] += time.perf_counter() - tic
+            self.stats["issue_enc_s"] += time.perf_counter() - tic
+            # 3. replay of the previous step's chaining + graph update (side stream) while the encoder runs.  It is
+            #    issued BEFORE the decoder graph on purpose: that graph has parallel branches on several hardware queues and
+            #    anything queued behind it on a shared queue waits for the whole branch (measured: ~40 ms per step)
+            if self._pending is not None:
+                self._replay(self._pending)
+                self._pending = None
+            # 4'. recurrent decoder + heads graph
+            tic = time.perf_counter()
+            outs = self._decode(feats)
+            self.stats["issue_s"] += time.perf_counter() - tic
         # 4. one exchange over xGMI (private copies when world == 1)
         tic = time.perf_counter()
         if self.emulate_gather:      # debug (bench CUT3R_EMULATE_WORLD): this rank's outputs stand in for every other rank's

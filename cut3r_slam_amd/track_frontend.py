@@ -131,15 +131,23 @@ class TrackFrontend:
         ev.record()
         return ev
 
-    def track_many(self, ranges, outputs, init=False, first_event=None):
+    def track_many(self, ranges, outputs, init=False, first_event=None, count_mask=None, exchange=None):
         """The sequential part of tracking for consecutive windows `ranges` = [(t0, t1), ...] with their network outputs
         [(pts [V,H,W,3], conf [V,H,W], pose_enc [V,7] device or host), ...]: log-depth scale + pose chaining
         (track_frontend.py:193-245), keyframe store update and covisibility-graph update (:246-261).
 
         ONE device round trip per window: the fused window update of window k is followed on the stream by the log-depth
         reduction of window k+1 (it needs only the depth window k has just stored), both results come back together, and
-        the host-only graph decisions of window k run while the device works on window k+1."""
+        the host-only graph decisions of window k run while the device works on window k+1.
+
+        Multi-GPU (`count_mask`, `exchange`): the O(#keyframes) overlap counting of a window is done only where
+        count_mask[k] is true (by the rank that owns the window; every rank still chains and stores every window, so the
+        stores stay replicated); `exchange(int32 tensor [n_windows, 6, 2, L])` then sums the owners' counts over the ranks
+        (one small all-reduce per call) and the decisions of all windows are taken afterwards, in order."""
         kf, graph, ds = self.keyframes, self.graph, self.downsample_ratio
+        deferred = [] if exchange is not None else None     # (t0, t1, groups, centres) per window, decisions after the exchange
+        L = ((ranges[-1][1] + 63) // 64) * 64
+        all_counts = torch.zeros(len(ranges), 6, 2, L, dtype=torch.int32) if exchange is not None else None
         if self._ev is None:
             self._ev = torch.cuda.Event()
         if init:
@@ -199,12 +207,14 @@ class TrackFrontend:
                     groups.append((g0, v))
                     g0 = v
             tic = time.perf_counter()
+            counting = count_mask is None or bool(count_mask[k])
             for (a, b) in groups:
                 ops.window_update(pts[a:b], conf[a:b], np.concatenate([c[:3, :4].reshape(-1) for c in chained[a:b]]), float(s_win), ds,
                                   kf.submap_ds[sub_num, a:b], kf.conf_ds[sub_num, a:b], kf.depth[t0 + a:t0 + b], kf.submap_ds, kf.w2c,
-                                  t0 + a, 3, [float(x) for x in intr[a]], self._counts[a:b], w2c_new=w2c_rows[a:b].reshape(-1),
-                                  lsum_reset=self._lsum)
-            self._counts_host[:V].copy_(self._counts[:V], non_blocking=True)
+                                  t0 + a, 3 if counting else (1 << 30), [float(x) for x in intr[a]], self._counts[a:b],
+                                  w2c_new=w2c_rows[a:b].reshape(-1), lsum_reset=self._lsum)
+            if counting:
+                self._counts_host[:V].copy_(self._counts[:V], non_blocking=True)
             prefetch = (not init) and k + 1 < len(ranges)
             if prefetch:                 # the next window's log-depth sum (and poses) ride on the same round trip
                 nt0, (npts, _, npose) = ranges[k + 1][0], outputs[k + 1]
@@ -220,6 +230,11 @@ class TrackFrontend:
             TIMING["windows"] += 1
             if prefetch:
                 lsum_next = float(self._lsum_host[0])
+            if deferred is not None:
+                if counting:
+                    all_counts[k, :V, :, :t1] = self._counts_host[:V, :, :t1]
+                deferred.append((t0, t1, groups, centres[:t1].copy(), H * W))
+                continue
             done = {}
             host_counts = self._counts_host.numpy()
             for (a, b) in groups:
@@ -229,6 +244,15 @@ class TrackFrontend:
             pending = (t0, t1, init, done)
         if pending is not None:
             self._decide(*pending)
+        if deferred is not None:
+            total = exchange(all_counts).numpy()
+            for k, (t0, t1, groups, centres, npix) in enumerate(deferred):
+                done = {}
+                for (a, b) in groups:
+                    if t0 + b - 1 >= 3:
+                        for tk, cf, cb in graph.window_tickets(t0 + a, t0 + b, centres, total[k, a:b], npix, h * w):
+                            done[tk["idx"]] = (tk, cf.copy(), cb.copy())
+                self._decide(t0, t1, init, done)
 
     def track_batch(self, ranges):
         """several consecutive 6-keyframe windows: ONE batched decoder/head inference, then the reference's sequential

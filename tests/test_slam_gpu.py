@@ -147,6 +147,62 @@ def test_window_batch_gives_the_same_trajectory_and_graph():
         np.testing.assert_array_equal(a, b)
 
 
+def test_sharded_overlap_counting_two_ranks_in_one_process():
+    """Multi-GPU replay (dist.ShardedTracker): every rank chains and stores every window, the overlap counting of a window
+    runs only on its owner and the owners' counts are summed before the decisions.  Two trackers play the two ranks here
+    (the sum stands in for the all-reduce); poses, stores and the ordered edge lists must equal the single-rank replay."""
+    frames = _frames(80, seed=5)
+    intr = torch.tensor([40.0, 40.0, 23.5, 15.5])
+    model = _model()
+    cfgd = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 1, "kf_every": 2}, "frontend": {"iteration": 0}}}
+    slams = [Cut3rSlam(model, cfgd, (H, W), buffer=48, device=DEV) for _ in range(3)]
+    nwin = 4
+    for slam in slams:
+        t = 0
+        while not slam.keyframes.is_initialized:
+            slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+            t += 1
+        while slam.keyframes.counter.value < slam.tracker.t1 + 5 * nwin:
+            if t % 2 == 0:
+                slam.keyframes.append(t, frames[t], None, None, None, None, intr, None, None)
+            t += 1
+    first = slams[0].tracker.t1 - 1
+    ranges = [(first + 5 * j, first + 5 * j + 6) for j in range(nwin)]
+    tr0 = slams[0].tracker
+    tr0.window_features(ranges[0][0], ranges[-1][1])
+    feats = torch.stack([tr0.window_features(a, b) for a, b in ranges], 0)
+    res = model.decode_windows(feats, H, W)
+    outs = [tuple(res[k][6 * j:6 * j + 6].clone() for k in ("pts3d_in_self_view", "conf_self", "camera_pose")) for j in range(nwin)]
+    tr0.track_many(ranges, outs)
+    trA, trB = slams[1].tracker, slams[2].tracker
+    maskA = [j % 2 == 0 for j in range(nwin)]
+    maskB = [not m for m in maskA]
+
+    def exchange_a(counts_a):
+        box = {}
+
+        def exchange_b(counts_b):
+            assert int((counts_a != 0).sum()) > 0 and int((counts_b != 0).sum()) > 0
+            assert int(((counts_a != 0) & (counts_b != 0)).sum()) == 0          # disjoint ownership
+            box["total"] = counts_a + counts_b
+            return box["total"]
+        trB.track_many(ranges, outs, count_mask=maskB, exchange=exchange_b)
+        return box["total"]
+
+    trA.track_many(ranges, outs, count_mask=maskA, exchange=exchange_a)
+    torch.cuda.synchronize()
+    n = ranges[-1][1]
+    e0 = slams[0].graph.edges_numpy()
+    assert len(e0[0]) > 40
+    for slam in slams[1:]:
+        np.testing.assert_array_equal(slam.keyframes.pose[:n].numpy(), slams[0].keyframes.pose[:n].numpy())
+        assert torch.equal(slam.keyframes.submap_ds, slams[0].keyframes.submap_ds)
+        assert torch.equal(slam.keyframes.depth[:n], slams[0].keyframes.depth[:n])
+        assert torch.equal(slam.keyframes.w2c[:n], slams[0].keyframes.w2c[:n])
+        for a, b in zip(slam.graph.edges_numpy(), e0):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_loop_closure_backend_runs_end_to_end_and_reduces_the_disagreement():
     """TrackBackend.run(): detection -> NMS -> re-tracking -> fused optimiser -> in-place rewrite, on a stream whose second
     half replays the first (so late keyframes are covisible with early ones).  Functional check (the tiny random network
