@@ -342,6 +342,46 @@ inline int grid_for(size_t total, int block = 256) {
     return (int)g;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// cv2.resize(img, (W1, H1)) with INTER_LINEAR on 8-bit interleaved images (demo_s.py:72,83): OpenCV's fixed-point
+// bilinear (11-bit coefficients, horizontal pass in int, vertical pass with the >>4 / >>16 / +2 >>2 rounding) and its
+// 2x-decimation special case (2x2 box with rounding).  One thread per output pixel, all channels; the output is written
+// channel-planar [C,H1,W1] (what the tracker consumes: demo_s.py:73 permutes to CHW) or interleaved.
+DEVINL short coef_q11(float v) { return (short)__float2int_rn(v * 2048.0f); }
+
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const unsigned char* __restrict__ src, int H0, int W0, int C,
+                                                               unsigned char* __restrict__ dst, int H1, int W1, int chw) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W1) return;
+    if (W0 == 2 * W1 && H0 == 2 * H1) {
+        for (int c = 0; c < C; c++) {
+            const unsigned char* p = src + ((size_t)(2 * y) * W0 + 2 * x) * C + c;
+            const int v = (p[0] + p[C] + p[(size_t)W0 * C] + p[(size_t)W0 * C + C] + 2) >> 2;
+            dst[chw ? ((size_t)c * H1 + y) * W1 + x : ((size_t)y * W1 + x) * C + c] = (unsigned char)v;
+        }
+        return;
+    }
+    const double sxs = (double)W0 / W1, sys = (double)H0 / H1;
+    float fy = (float)((y + 0.5) * sys - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    const short b0 = coef_q11(1.0f - fy), b1 = coef_q11(fy);
+    const int y0 = min(max(sy, 0), H0 - 1), y1 = min(max(sy + 1, 0), H0 - 1);
+    float fx = (float)((x + 0.5) * sxs - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= W0 - 1) { fx = 0.f; sx = W0 - 1; }
+    const short a0 = coef_q11(1.0f - fx), a1 = coef_q11(fx);
+    const int x1 = min(sx + 1, W0 - 1);
+    for (int c = 0; c < C; c++) {
+        const int d0 = src[((size_t)y0 * W0 + sx) * C + c] * a0 + src[((size_t)y0 * W0 + x1) * C + c] * a1;
+        const int d1 = src[((size_t)y1 * W0 + sx) * C + c] * a0 + src[((size_t)y1 * W0 + x1) * C + c] * a1;
+        const int v = (((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2;
+        dst[chw ? ((size_t)c * H1 + y) * W1 + x : ((size_t)y * W1 + x) * C + c] = (unsigned char)v;
+    }
+}
+
 }  // namespace
 
 extern "C" int cut3r_abi_version(void) { return 1; }
@@ -445,5 +485,12 @@ extern "C" int cut3r_postprocess_pts(const float* raw, int P, int nch, int pos_z
 extern "C" int cut3r_postprocess_pose(const float* raw, int B, float* out, void* stream) {
     if (!raw || !out || B <= 0) return CUT3R_ERR_ARG;
     hipLaunchKernelGGL(postprocess_pose_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, raw, B, out);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_resize_linear_u8(const void* src, int H0, int W0, int C, void* dst, int H1, int W1, int chw_out, void* stream) {
+    if (!src || !dst || H0 < 1 || W0 < 1 || H1 < 1 || W1 < 1 || C < 1 || C > 4 || H1 > 65535) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((W1 + 255) / 256, H1), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)src, H0, W0, C, (unsigned char*)dst, H1, W1, chw_out);
     return cut3r_check_launch();
 }

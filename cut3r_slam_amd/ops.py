@@ -419,6 +419,17 @@ def logdepth_accum(prev_depth, pts, out):
     check(lib.cut3r_logdepth_accum(_p(prev_depth), _p(pts), n, _p(out), _stream()), "cut3r_logdepth_accum")
 
 
+def resize_linear_u8(img_hwc, H1, W1, chw_out=True):
+    """cv2.resize(img, (W1, H1)) (INTER_LINEAR, u8) on the GPU.  img_hwc u8 [H0,W0,C] -> u8 [C,H1,W1] (or [H1,W1,C])."""
+    _cuda(img_hwc)
+    _req(img_hwc.dtype == torch.uint8 and img_hwc.dim() == 3 and img_hwc.is_contiguous() and img_hwc.shape[2] <= 4, "u8 [H,W,C<=4] contiguous")
+    H0, W0, Cc = img_hwc.shape
+    out = torch.empty((Cc, H1, W1) if chw_out else (H1, W1, Cc), dtype=torch.uint8, device=img_hwc.device)
+    lib = _lib.load()
+    check(lib.cut3r_resize_linear_u8(_p(img_hwc), H0, W0, Cc, _p(out), int(H1), int(W1), int(bool(chw_out)), _stream()), "cut3r_resize_linear_u8")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ loop closure
 def lc_optimize(submaps, mask, cur, cur_lc, iters, lr=5e-4, return_loss=False):
     """Fused Adam over per-submap se(3) corrections (track_backend.py:256-299).  submaps: [B,6,h,w,3] fp32 contiguous

@@ -205,6 +205,13 @@ int cut3r_ba_step(const float* Gij, const float* disps, const float* intr, const
                   int P, int ht, int wd, int N, int M, int fixedp, float ep, float lm, float* workspace, float* dx, float* dz, int* flag,
                   void* stream);
 
+/* ---- stream preprocessing -------------------------------------------------------------------------------------------
+ * replaces cv2.resize(image, (w1, h1)) of demo_s.py:72,83 (default INTER_LINEAR, 8-bit): OpenCV's fixed-point bilinear
+ * and its exact-2x box special case, restated from the published algorithm (OpenCV is not in the reference tree and cv2 is
+ * not in the build image: parity unpinned, see oracle/oracle_geom.c).  src u8 [H0,W0,C] interleaved (device); dst u8
+ * [C,H1,W1] when chw_out != 0 (the layout demo_s.py:73 permutes to) else [H1,W1,C]. */
+int cut3r_resize_linear_u8(const void* src, int H0, int W0, int C, void* dst, int H1, int W1, int chw_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

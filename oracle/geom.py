@@ -95,3 +95,12 @@ def patch_overlap_ratio(feat0, feat1, thr=0.7):
     b = b / np.maximum(np.linalg.norm(b, axis=1, keepdims=True), 1e-12)
     mx = (a @ b.T).max(axis=1)
     return float((mx > thr).mean()), mx
+
+
+def resize_linear_u8(img, H1, W1):
+    """cv2.resize(img, (W1, H1)) (INTER_LINEAR, u8 HWC) per the published OpenCV algorithm -- PARITY UNPINNED (no cv2 here)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H0, W0, Cc = img.shape
+    out = np.empty((H1, W1, Cc), np.uint8)
+    lib().oracle_resize_linear_u8(_ptr(img, C.c_ubyte), H0, W0, Cc, _ptr(out, C.c_ubyte), H1, W1)
+    return out

@@ -111,3 +111,52 @@ double oracle_logdepth_sum(const float *prev_depth, const float *pts, int n) {
     for (int i = 0; i < n; i++) acc += (double)logf(prev_depth[i]) - (double)logf(pts[3 * i + 2]);
     return acc;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * cv2.resize(src, (W1, H1)) with the default INTER_LINEAR on 8-bit images -- what demo_s.py:72,83 applies to every frame.
+ * cv2 is NOT in this container and OpenCV is not part of the reference tree: PARITY UNPINNED.  This restates the published
+ * algorithm of OpenCV 4.x imgproc/resize.cpp (resizeGeneric_ with HResizeLinear<uchar,int,short,INTER_RESIZE_COEF_SCALE>
+ * and VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,INTER_RESIZE_COEF_BITS*2>>):
+ *   scale = src/dst (double); f = (float)((d + 0.5) * scale - 0.5); s = floor(f); f -= s;
+ *   x only: s < 0 -> (s, f) = (0, 0);  s >= W0-1 -> (s, f) = (W0-1, 0);   y: the two rows s, s+1 are clipped to [0, H0-1]
+ *   coefficients short(round((1-f) * 2048)), short(round(f * 2048)) (round half to even, as cvRound);
+ *   horizontal: int D = S[s]*a0 + S[s+1]*a1;  vertical: u8 = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2.
+ * Exact 2x decimation (W0 == 2*W1 and H0 == 2*H1) takes OpenCV's INTER_AREA fast path instead: (a + b + c + d + 2) >> 2.
+ * src/dst interleaved HWC, C channels. */
+#include <math.h>
+static short coef_q11(float v) { return (short)lrintf(v * 2048.0f); }
+
+void oracle_resize_linear_u8(const unsigned char *src, int H0, int W0, int C, unsigned char *dst, int H1, int W1) {
+    if (W0 == 2 * W1 && H0 == 2 * H1) {
+        for (int y = 0; y < H1; y++)
+            for (int x = 0; x < W1; x++)
+                for (int c = 0; c < C; c++) {
+                    const unsigned char *p = src + ((size_t)(2 * y) * W0 + 2 * x) * C + c;
+                    dst[((size_t)y * W1 + x) * C + c] = (unsigned char)((p[0] + p[C] + p[(size_t)W0 * C] + p[(size_t)W0 * C + C] + 2) >> 2);
+                }
+        return;
+    }
+    const double sx_ = (double)W0 / W1, sy_ = (double)H0 / H1;
+    for (int y = 0; y < H1; y++) {
+        float fy = (float)((y + 0.5) * sy_ - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        const short b0 = coef_q11(1.0f - fy), b1 = coef_q11(fy);
+        int y0 = sy < 0 ? 0 : (sy > H0 - 1 ? H0 - 1 : sy);
+        int y1 = sy + 1 < 0 ? 0 : (sy + 1 > H0 - 1 ? H0 - 1 : sy + 1);
+        for (int x = 0; x < W1; x++) {
+            float fx = (float)((x + 0.5) * sx_ - 0.5);
+            int sx = (int)floorf(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0.f; sx = 0; }
+            if (sx >= W0 - 1) { fx = 0.f; sx = W0 - 1; }
+            const short a0 = coef_q11(1.0f - fx), a1 = coef_q11(fx);
+            const int x1 = sx + 1 > W0 - 1 ? W0 - 1 : sx + 1;
+            for (int c = 0; c < C; c++) {
+                const int d0 = src[((size_t)y0 * W0 + sx) * C + c] * a0 + src[((size_t)y0 * W0 + x1) * C + c] * a1;
+                const int d1 = src[((size_t)y1 * W0 + sx) * C + c] * a0 + src[((size_t)y1 * W0 + x1) * C + c] * a1;
+                dst[((size_t)y * W1 + x) * C + c] = (unsigned char)((((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+    }
+}

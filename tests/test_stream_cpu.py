@@ -1,0 +1,86 @@
+"""CPU: the image-sequence front end (cut3r_slam_amd/stream.py) -- file ordering, size / intrinsics arithmetic and the
+trajectory writers of demo_s.py:48-113 -- and the oracle's restatement of cv2.resize(INTER_LINEAR, u8) (parity unpinned:
+no cv2 in this image; checked against an independent float bilinear and against the closed-form special cases)."""
+import os
+
+import numpy as np
+import torch
+
+from cut3r_slam_amd import stream
+from oracle import geom as G
+
+
+def test_natural_sort_and_timestamps(tmp_path):
+    names = ["frame10.jpg", "frame9.jpg", "frame000100.jpg", "frame1.jpg", "Frame2.jpg"]
+    assert stream.natsorted(names) == ["frame1.jpg", "Frame2.jpg", "frame9.jpg", "frame10.jpg", "frame000100.jpg"]
+    for n in ["1305031102.175304.png", "1305031102.211214.png", "1305031102.143102.png"]:
+        (tmp_path / n).write_bytes(b"")
+    ts = stream.frame_timestamps(str(tmp_path))
+    assert ts.shape == (3, 1) and np.allclose(ts[:, 0], [1305031102.143102, 1305031102.175304, 1305031102.211214])
+
+
+def test_sizes_follow_demo_s():
+    assert stream.tracking_size(480, 640) == (384, 512)            # BASELINE: 640x480 -> 384x512
+    assert stream.tracking_size(680, 1200) == (288, 512)           # Replica
+    assert stream.mapping_size(680, 1200) == (290, 512)
+    assert stream.tracking_size(968, 1296) == (368, 512)           # ScanNet
+
+
+def _bilinear_float(img, H1, W1):
+    H0, W0, C = img.shape
+    ys = (np.arange(H1) + 0.5) * (H0 / H1) - 0.5
+    xs = (np.arange(W1) + 0.5) * (W0 / W1) - 0.5
+    y0 = np.floor(ys).astype(int); fy = ys - y0
+    x0 = np.floor(xs).astype(int); fx = xs - x0
+    fx = np.where((x0 < 0) | (x0 >= W0 - 1), 0.0, fx)
+    x0c = np.clip(x0, 0, W0 - 1); x1c = np.clip(x0c + 1, 0, W0 - 1)
+    y0c = np.clip(y0, 0, H0 - 1); y1c = np.clip(y0 + 1, 0, H0 - 1)
+    f = img.astype(np.float64)
+    top = f[y0c][:, x0c] * (1 - fx)[None, :, None] + f[y0c][:, x1c] * fx[None, :, None]
+    bot = f[y1c][:, x0c] * (1 - fx)[None, :, None] + f[y1c][:, x1c] * fx[None, :, None]
+    return top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
+
+
+def test_resize_oracle_against_float_bilinear_and_closed_forms():
+    rng = np.random.default_rng(0)
+    for (H0, W0, H1, W1, C) in [(48, 64, 38, 51, 3), (68, 120, 29, 51, 3), (24, 32, 38, 51, 1), (31, 45, 16, 16, 4)]:
+        img = rng.integers(0, 256, (H0, W0, C), dtype=np.uint8)
+        out = G.resize_linear_u8(img, H1, W1)
+        ref = _bilinear_float(img, H1, W1)
+        assert out.shape == (H1, W1, C)
+        assert np.abs(out.astype(np.float64) - ref).max() <= 1.0 + 0.26 * (H0 / H1 > 1 or W0 / W1 > 1)      # 11-bit coefficients + >>4 truncation
+    img = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    assert np.array_equal(G.resize_linear_u8(img, 20, 30), img)                          # identity scale: exact
+    box = (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(G.resize_linear_u8(img, 10, 15), box.astype(np.uint8))         # exact 2x: rounded 2x2 box
+    const = np.full((17, 23, 3), 201, np.uint8)
+    assert np.array_equal(G.resize_linear_u8(const, 40, 9), np.full((40, 9, 3), 201, np.uint8))
+
+
+class _FakeKF:
+    def __init__(self, n):
+        class C:
+            value = n + 1
+        self.counter = C()
+        self.tstamp = torch.arange(0, 10 * n, 10, dtype=torch.float)
+        self.pose = torch.cat([torch.rand(n, 3), torch.nn.functional.normalize(torch.rand(n, 4), dim=1)], 1)
+        self.intrinsic = torch.tensor([[256.0, 339.0, 255.8, 191.7]])
+
+
+def test_save_trajectory_format(tmp_path):
+    img_dir = tmp_path / "colors"
+    img_dir.mkdir()
+    for i in range(50):
+        (img_dir / f"frame{i:06d}.jpg").write_bytes(b"")
+
+    class S:
+        keyframes = _FakeKF(5)
+    out = tmp_path / "out"
+    out.mkdir()
+    traj = stream.save_trajectory(S, str(img_dir), str(out))
+    rows = open(out / "traj_kf.txt").read().strip().splitlines()
+    assert len(rows) == 5 and all(len(r.split()) == 8 for r in rows)
+    assert [float(r.split()[0]) for r in rows] == [0.0, 10.0, 20.0, 30.0, 40.0]          # stamp = number in the file name
+    assert rows[1].split()[0] == "10.0000" and len(rows[1].split()[1].split(".")[1]) == 7
+    np.testing.assert_allclose(np.load(out / "intrinsics.npy"), [256.0, 339.0, 255.8, 191.7])
+    assert traj.shape == (5, 8)
