@@ -152,7 +152,7 @@ class ShardedTracker:
                     self.slam.tracker.t1 = b
             else:
                 mask, exch = None, None
-                if self.world > 1 and self.shard_counting:
+                if (self.world > 1 or self.force_collective) and self.shard_counting:
                     # the O(#keyframes) overlap counting of a window runs on its owner only; one small all-reduce per step
                     mask = [self.rank * self.wb <= j < (self.rank + 1) * self.wb for j in range(len(ranges_all))]
                     exch = self._exchange_counts

@@ -71,6 +71,12 @@ def _worker(rank, world, port, q, wb):
         t = st.step(frames, t, 10, 5, None)
     n_before_flush = len(tracked)
     st.flush()
+    # the count exchange of the sharded overlap counting: every rank contributes the rows of the windows it owns
+    counts = torch.zeros(world * wb, 6, 2, 64, dtype=torch.int32)
+    counts[rank * wb:(rank + 1) * wb] = rank + 1
+    total = st._exchange_counts(counts)
+    for r in range(world):
+        assert bool((total[r * wb:(r + 1) * wb] == r + 1).all())
     q.put((rank, appended, tracked, t, slam.tracker.t1, lag, n_before_flush))
     dist.barrier()
     dist.destroy_process_group()
