@@ -521,6 +521,85 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Skinny GEMM on MFMA (M <= 64 rows): the pose-memory read blocks, pose MLP and proj_q run with one row per tracking
+// window (M = window batch).  Weight-read-bound: a 64-row tile puts only N/64 workgroups on the chip.  Here one workgroup
+// owns 16 output columns, its NW waves split K, every lane streams its 16 bytes of W per k-step straight from global
+// memory into the MFMA B operand (no LDS) and reuses it for the MB = ceil(M/16) row blocks; the per-wave partial sums
+// are added in wave order through LDS.  The summation order of a row depends on K only, never on M: results are
+// identical for every window batch.
+template <int NW, int MB>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const GemmArgs g) {
+    __shared__ f32x4 red[NW][MB][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int z = blockIdx.z;
+    const h16* __restrict__ A = g.A + (size_t)z * g.sA;
+    const h16* __restrict__ Bm = g.B + (size_t)z * g.sB;
+    const int M = g.M, N = g.N, K = g.K;
+    const int n0 = blockIdx.x * 16;
+    const int ksteps = (K + 31) / 32;
+    const int per = (ksteps + NW - 1) / NW;
+    const int ks0 = wave * per, ks1 = min(ksteps, ks0 + per);
+    const bool b_ok = n0 + fr < N;
+    const h16* bp = Bm + (size_t)(b_ok ? n0 + fr : 0) * g.ldb + fq * 8;
+    bool a_ok[MB];
+    const h16* ap[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+        a_ok[mb] = mb * 16 + fr < M;
+        ap[mb] = A + (size_t)(a_ok[mb] ? mb * 16 + fr : 0) * g.lda + fq * 8;
+    }
+    const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = MB == 1 ? 8 : (MB == 2 ? 4 : 2);
+    for (int ks = ks0; ks < ks1; ks += U) {
+        half8_t fa[U][MB], fb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = (ks + u) * 32 + fq * 8;
+            const bool ok = (ks + u) < ks1 && k < K;
+            fb[u] = (ok && b_ok) ? *reinterpret_cast<const half8_t*>(bp + (size_t)(ks + u) * 32) : zero8;
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++)
+                fa[u][mb] = (ok && a_ok[mb]) ? *reinterpret_cast<const half8_t*>(ap[mb] + (size_t)(ks + u) * 32) : zero8;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u][mb], fb[u], acc[mb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) red[wave][mb][lane] = acc[mb];
+    __syncthreads();
+    if (wave != 0) return;
+    const int gn = n0 + fr;
+    if (gn >= N) return;
+    const float bias = g.bias ? g.bias[(size_t)z * g.sBias + gn] : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+        f32x4 v = red[0][mb][lane];
+#pragma unroll
+        for (int w = 1; w < NW; w++) v += red[w][mb][lane];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int gm = mb * 16 + fq * 4 + e;
+            if (gm >= M) continue;
+            float o = v[e] + bias;
+            if (g.act == 1) o = g.out_f16 ? gelu_fast(o) : gelu_erf(o);
+            else if (g.act == 2) o = fmaxf(o, 0.f);
+            if (g.res1) o += g.res1_f16 ? (float)((const h16*)g.res1)[(size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn]
+                                        : ((const float*)g.res1)[(size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn];
+            if (g.res2) o += g.res2_f16 ? (float)((const h16*)g.res2)[(size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn]
+                                        : ((const float*)g.res2)[(size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn];
+            if (g.out_f16) ((h16*)g.C)[(size_t)z * g.sC + (size_t)gm * g.ldc + gn] = (h16)o;
+            else ((float*)g.C)[(size_t)z * g.sC + (size_t)gm * g.ldc + gn] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Skinny GEMM (M <= 8 rows): weight-read-bound GEMV.  One wave per output column block, x rows kept in registers.
 // Used for the 1-token pose-memory read, pose MLP and adaLN modulation (M = 1).
 __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ X, int ldx, const h16* __restrict__ W, int ldw,
@@ -595,7 +674,15 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     const int batch = d->batch > 0 ? d->batch : 1;
     hipStream_t s = (hipStream_t)stream;
     const int tile = cut3r_gemm_tile_for(d);
-    if (tile == 256) {
+    if (tile == 16) {
+        if (d->M > 64 || d->conv_k == 3 || d->shuf || d->relu_in) return CUT3R_ERR_ARG;
+        dim3 grid((d->N + 15) / 16, 1, batch);
+        const int mb = (d->M + 15) / 16;            // 1..4 row blocks; K >= 2048 splits over 8 waves, else 4
+#define CUT3R_SKINNY(NWV, MBV) hipLaunchKernelGGL((gemm_skinny_kernel<NWV, MBV>), grid, dim3(64 * NWV), 0, s, g)
+        if (d->K >= 2048) { if (mb == 1) CUT3R_SKINNY(8, 1); else if (mb == 2) CUT3R_SKINNY(8, 2); else CUT3R_SKINNY(8, 4); }
+        else { if (mb == 1) CUT3R_SKINNY(4, 1); else if (mb == 2) CUT3R_SKINNY(4, 2); else CUT3R_SKINNY(4, 4); }
+#undef CUT3R_SKINNY
+    } else if (tile == 256) {
         dim3 grid(((d->N + 255) / 256) * ((d->M + 255) / 256), 1, batch);
         if (d->conv_k == 3 && d->relu_in) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, dim3(512), 0, s, g);
         else if (d->conv_k == 3) hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, dim3(512), 0, s, g);

@@ -16,6 +16,8 @@ head runs once per window over all views (it does not feed the recurrence), and 
 """
 from __future__ import annotations
 
+import gc
+
 import math
 import re
 from dataclasses import dataclass
@@ -221,9 +223,11 @@ class Cut3rModel:
         return t
 
     # ------------------------------------------------------------------ primitives
-    def _linear(self, x16, name, out, act=0, res1=None, res2=None):
+    def _linear(self, x16, name, out, act=0, res1=None, res2=None, skinny=False):
+        """skinny: the operand has ONE row per independent sequence (pose token of a tracking window): weight-streaming
+        kernel whose per-row result does not depend on how many windows are batched"""
         L = self.w[name]
-        return ops.linear(x16, L.w, out, L.b, act, res1, res2)
+        return ops.linear(x16, L.w, out, L.b, act, res1, res2, tile=16 if skinny else 0)
 
     def _ln(self, x, name, out16=None, out32=None, mod=None):
         g, b = self.w[name]
@@ -236,22 +240,23 @@ class Cut3rModel:
         """x_ln16 fp16 [B*N,C] -> out(fp32) = res + proj(attn(qkv(x)))"""
         Cc = x_ln16.shape[1]
         D = Cc // heads
+        sk = N == 1
         qkv = self.buf(tag + ".qkv", (B * N, 3 * Cc), F16)
-        self._linear(x_ln16, p + ".qkv", qkv)
+        self._linear(x_ln16, p + ".qkv", qkv, skinny=sk)
         v5 = qkv.view(B, N, 3, heads, D)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
         if pos is not None:
             ops.rope_2d_qk(q, k, pos, self.cfg.rope_freq, 1.0)
         a = self.buf(tag + ".attn", (B, N, heads, D), F16)
         ops.attention(q, k, v, a, D ** -0.5)
-        self._linear(a.view(B * N, Cc), p + ".proj", out, res1=res)
+        self._linear(a.view(B * N, Cc), p + ".proj", out, res1=res, skinny=sk)
 
-    def _mlp(self, tag, x_ln16, p, out, res):
+    def _mlp(self, tag, x_ln16, p, out, res, skinny=False):
         M = x_ln16.shape[0]
         hdim = self.w[p + ".fc1"].npad
         h = self.buf(tag + ".mlp_h", (M, hdim), F16)
-        self._linear(x_ln16, p + ".fc1", h, act=1)
-        self._linear(h, p + ".fc2", out, res1=res)
+        self._linear(x_ln16, p + ".fc1", h, act=1, skinny=skinny)
+        self._linear(h, p + ".fc2", out, res1=res, skinny=skinny)
 
     # ------------------------------------------------------------------ encoder
     def _encode(self, img: torch.Tensor):
@@ -299,8 +304,17 @@ class Cut3rModel:
             cur.wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = fn(static_in)
+            # no garbage collection while the stream is capturing: a collected tensor / graph of a dead model would be
+            # released (hipFree, hipGraphExecDestroy) in the middle of the capture
+            gc_was_on = gc.isenabled()
+            gc.collect()
+            gc.disable()
+            try:
+                with torch.cuda.graph(graph):
+                    out = fn(static_in)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             ent = (graph, static_in, out)
             self._graphs[key] = ent
         graph, static_in, out = ent
@@ -340,7 +354,7 @@ class Cut3rModel:
 
         def kv_branch():          # depends only on y (the other stream's previous layer): norm_y -> projk|projv -> RoPE(k)
             self._ln(y, p + ".norm_y", out16=y16)
-            self._linear(y16, p + ".cross_attn.projkv", kv)
+            self._linear(y16, p + ".cross_attn.projkv", kv, skinny=(Ny == 1))
             if ypos is not None:
                 self._rope(k, ypos)
 
@@ -357,7 +371,7 @@ class Cut3rModel:
         self._self_attn(tag, ln16, B, Nx, heads, xpos, p + ".attn", out, x)
         self._ln(out, p + ".norm2", out16=ln16)
         q = self.buf(tag + ".q", (B, Nx, heads, D), F16)
-        self._linear(ln16, p + ".cross_attn.projq", q.view(B * Nx, Cc))
+        self._linear(ln16, p + ".cross_attn.projq", q.view(B * Nx, Cc), skinny=(Nx == 1))
         if xpos is not None:
             self._rope(q, xpos)
         if fork:
@@ -366,9 +380,9 @@ class Cut3rModel:
             kv_branch()
         a = self.buf(tag + ".cattn", (B, Nx, heads, D), F16)
         ops.attention(q, k, v, a, D ** -0.5)
-        self._linear(a.view(B * Nx, Cc), p + ".cross_attn.proj", out, res1=out)
+        self._linear(a.view(B * Nx, Cc), p + ".cross_attn.proj", out, res1=out, skinny=(Nx == 1))
         self._ln(out, p + ".norm3", out16=ln16)
-        self._mlp(tag, ln16, p + ".mlp", out, out)
+        self._mlp(tag, ln16, p + ".mlp", out, out, skinny=(Nx == 1))
         return out
 
     # ------------------------------------------------------------------ pose memory
@@ -377,7 +391,7 @@ class Cut3rModel:
         cfg = self.cfg
         D = cfg.dec_embed_dim
         x = self.buf("memr.x", (B, 2 * D), F32)
-        self._linear(gfeat16, "pose_retriever.proj_q", x[:, :D])
+        self._linear(gfeat16, "pose_retriever.proj_q", x[:, :D], skinny=True)
         x[:, D:] = self.masked_token
         a, b = x, self.buf("memr.x2", (B, 2 * D), F32)
         for i in range(2):
@@ -390,7 +404,7 @@ class Cut3rModel:
         cfg = self.cfg
         D = cfg.dec_embed_dim
         f = self.buf("memw.f", (B, 2 * D), F32)
-        self._linear(gfeat16, "pose_retriever.proj_q", f[:, :D])
+        self._linear(gfeat16, "pose_retriever.proj_q", f[:, :D], skinny=True)
         f[:, D:] = pose_out
         tmp = self.buf("memw.tmp", tuple(mem.shape), F32)
         self._dec_block("memw", "pose_retriever.write_blocks.0", mem, f, None, None, cfg.dec_num_heads, tmp, B)

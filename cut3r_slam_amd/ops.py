@@ -142,6 +142,11 @@ def linear(A, W, out, bias=None, act=0, res1=None, res2=None, tile=0):
     for r in (res1, res2):
         if r is not None:
             _req(r.shape == (M, N), "residual shape")
+    if tile == 16 and M > 64:           # skinny kernel: 64 rows per launch (row results do not depend on the chunking)
+        for m0 in range(0, M, 64):
+            sl = slice(m0, min(M, m0 + 64))
+            linear(A[sl], W, out[sl], bias, act, None if res1 is None else res1[sl], None if res2 is None else res2[sl], tile=16)
+        return out
     d = GemmDesc()
     _fill_common(d, A, W, out, bias, res1, res2, act, tile)
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, A.stride(0), W.stride(0), out.stride(0)

@@ -58,11 +58,14 @@ typedef struct cut3r_gemm_desc {
     int relu_in;          /* apply ReLU to A on load (ResidualConvUnit pre-activation) */
     int shuf;             /* > 0: ConvTranspose(k == stride == shuf) scatter; N = shuf*shuf*shuf_cout, ldc = Cout */
     int shuf_cout, shuf_Hin, shuf_Win;
-    int tile;             /* 0 = auto (cut3r_gemm_tile_for), 64, 128 or 256 */
+    int tile;             /* 0 = auto (cut3r_gemm_tile_for), 16 (M <= 64 skinny), 64, 128 or 256 */
     int stages;           /* 0 = default; LDS ring depth override (tuning): 2|3 for tile 128, 2|3|4 for tile 64 */
 } cut3r_gemm_desc;
 int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream);
-/* the tile the launcher picks for this problem when desc->tile == 0: 256 (256x256x64 ping-pong kernel), 128 or 64 */
+/* the tile the launcher picks for this problem when desc->tile == 0: 256 (256x256x64 ping-pong kernel), 128 or 64.
+ * tile 16 (M <= 64: skinny weight-streaming MFMA kernel) is never chosen automatically: its K-split changes the fp32
+ * summation order, so callers request it for operands whose row count is the batch (one row per tracking window) and
+ * keep every other GEMM on the tile kernels, whose rows are bit-identical across tile sizes and batch sizes. */
 int cut3r_gemm_tile_for(const cut3r_gemm_desc* d);
 
 /* skinny M<=64 path: Y[M,N] = act(X[M,K] (fp32, optional SiLU on load) * W[N,K]^T (fp16) + bias) (+res) */

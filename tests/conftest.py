@@ -16,3 +16,19 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_objects_between_tests(request):
+    """hipGraphs and their memory pools of a finished test are destroyed HERE, at a quiescent point, rather than whenever
+    the garbage collector happens to run inside a later test's capture or replay."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import gc
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()

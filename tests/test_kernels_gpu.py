@@ -43,7 +43,10 @@ def _report(name, got, ref, tol):
     (6, 64, 48, 0), (13, 144, 48, 64), (256, 4608, 1536, 0), (130, 8, 192, 0), (200, 132, 72, 128),
     # 256^2 ping-pong kernel: full tiles, ragged M / N / K (K tail inside a 64-deep tile), one K-tile, two K-tiles
     (3072, 1024, 1024, 256), (769, 768, 768, 256), (1000, 516, 200, 256), (300, 260, 64, 256), (257, 256, 128, 256),
-    (5, 12, 8, 256)])
+    (5, 12, 8, 256),
+    # skinny M <= 64 kernel (pose memory / pose MLP rows): K split over 4 and 8 waves, 1/2/4 row blocks, ragged N and K
+    (8, 1536, 1536, 16), (8, 1536, 6144, 16), (1, 4608, 1536, 16), (16, 6144, 1536, 16), (3, 20, 40, 16), (7, 3072, 768, 16), (12, 8, 3072, 16),
+    (24, 1536, 6144, 16), (33, 1536, 1536, 16), (64, 768, 3072, 16), (50, 36, 72, 16), (150, 1536, 1536, 16)])
 def test_gemm_bias_gelu_residual(M, N, K, tile):
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g).half()
@@ -81,6 +84,23 @@ def test_gemm256_race_screen(M, N, K):
             torch.cuda.synchronize()
             for o in outs:
                 assert torch.equal(o, ref), f"rep {rep}: {(o != ref).sum().item()} elements differ, max {(o - ref).abs().max().item()}"
+
+
+def test_skinny_gemm_rows_do_not_depend_on_the_batch():
+    """a row of the M <= 64 kernel must come out bit-identical whatever M is (window-batch invariance of the pose path)"""
+    g = torch.Generator().manual_seed(4)
+    K, N = 6144, 1536
+    A = torch.randn(40, K, generator=g).half().to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    A = torch.cat([A, A[:37] * 0.5], 0)                  # 77 rows: more than one 64-row launch
+    full = torch.empty(77, N, device=DEV)
+    ops.linear(A, W, full, b, 0, tile=16)
+    for m in (1, 8, 16, 17, 32, 65):
+        part = torch.empty(m, N, device=DEV)
+        ops.linear(A[:m].contiguous(), W, part, b, 0, tile=16)
+        torch.cuda.synchronize()
+        assert torch.equal(part, full[:m]), m
 
 
 def test_gemm_strided_output_and_inplace_residual():
