@@ -237,7 +237,7 @@ def main():
                             "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
                             "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n,
                             "algorithmic_bytes_per_launch": by / n, "second_kernel": other}
-    if rank == 0 and not args.no_cpu_baseline and not args.small:
+    if rank == 0 and world == 1 and emu <= 1 and not args.no_cpu_baseline and not args.small:
         log("cpu baseline (oracle on host cores)")
         cpu_base = cpu_baseline(cfg, sd, frames[:2].cpu(), frames_per_step)
         log("cpu baseline done")

@@ -271,9 +271,9 @@ def test_im2col_cast_colmean_upsample():
     _report("upsample2x", up.float(), refu, 1.5e-3)
 
 
-def test_output_activations():
+@pytest.mark.parametrize("P,Cin", [(1000, 128), (4099, 256), (777, 48), (130, 64)])
+def test_output_activations(P, Cin):
     g = torch.Generator().manual_seed(9)
-    P, Cin = 1000, 128
     x = torch.randn(P, Cin, generator=g).half()
     w = torch.randn(4, Cin, generator=g) * 0.05
     b = torch.randn(4, generator=g) * 0.1
