@@ -33,6 +33,16 @@ DEVINL int wave_sum_i(int v) {
     return v;
 }
 
+// RoPE rotation of one element: a*co + t in fp32, THEN rounded to the token type.  The empty asm keeps the fp32 value
+// live so the compiler cannot merge the FMA and the fp16 conversion into v_fma_mixlo_f16 (one rounding instead of two):
+// the stand-alone kernel and the GEMM-fused epilogue must round identically, and the reference (kernels.cu:50-53) computes
+// in float and converts on the store as well.
+DEVINL float rope_rot(float a, float co, float t) {
+    float r = fmaf(a, co, t);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 // exact GELU (nn.GELU default, erf form) -- src/croco/models/blocks.py:75 act_layer=nn.GELU
 DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -48,12 +48,25 @@ __global__ __launch_bounds__(256) void rope2d_kernel(T* __restrict__ tok, T* __r
         for (int e = 0; e < 4; e++) {
             const float co = cs[X][0][4 * c + e], si = cs[X][1][4 * c + e];
             const float uf = (float)u.v[e], vf = (float)v.v[e];
-            ou.v[e] = (T)(uf * co - vf * si);
-            ov.v[e] = (T)(vf * co + uf * si);
+            float t1 = vf * si, t2 = uf * si;               // the GEMM-fused form (gemm.hip rope_store4) repeats this exactly
+            asm volatile("" : "+v"(t1), "+v"(t2));
+            ou.v[e] = (T)rope_rot(uf, co, -t1);
+            ov.v[e] = (T)rope_rot(vf, co, t2);
         }
         *reinterpret_cast<Vec4<T>*>(pu) = ou;
         *reinterpret_cast<Vec4<T>*>(pv) = ov;
     }
+}
+
+// cos / sin of every (position, frequency) pair of a head dimension of 64, by the expressions of rope2d_kernel
+__global__ void rope2d_table_kernel(float* __restrict__ table, int pmin, int npos, float base, float fwd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npos * 16) return;
+    const int p = i >> 4, q = i & 15;
+    const float inv = fwd / powf(base, (float)q / 16.0f);
+    const float fr = (float)(long long)(pmin + p) * inv;
+    table[i] = cosf(fr);
+    table[npos * 16 + i] = sinf(fr);
 }
 
 // ------------------------------------------------------------------------------------------------- LayerNorm
@@ -462,6 +475,12 @@ static int launch_rope(void* tokens, void* tokens2, int dtype, const int64_t* po
                            base, fwd);
     else
         return CUT3R_ERR_ARG;
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_rope2d_table(float* table, int pmin, int npos, float base, float fwd, void* stream) {
+    if (!table || npos < 1) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(rope2d_table_kernel, dim3((npos * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, pmin, npos, base, fwd);
     return cut3r_check_launch();
 }
 

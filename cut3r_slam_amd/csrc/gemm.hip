@@ -36,6 +36,8 @@ struct GemmArgs {
     int shuf, shuf_cout, shuf_Hin, shuf_Win;
     int swz;          // 1: 1-D grid with the XCD-aware tile rasterisation
     int prio;         // 1: s_setprio(1) around the MFMA cluster
+    // fused 2-D RoPE (head dimension 64) on output columns < rope_cols
+    const long long* rope_pos; const float* rope_table; int rope_cols, rope_pmin, rope_npos;
 };
 
 DEVINL half8_t relu8(half8_t v) {
@@ -99,6 +101,33 @@ DEVINL void fused_store4(const GemmArgs& g, int z, const float* bias, int gm, in
     } else {
         *reinterpret_cast<f32x4*>((float*)g.C + (size_t)z * g.sC + orow_off) = v;
     }
+}
+
+// Fused 2-D RoPE of 4 consecutive output columns gn..gn+3 (< rope_cols) of row gm, head dimension 64: own / partner are
+// the accumulators of these columns and of the columns 16 further (lower half of a 32-wide (y|x) block) or 16 back (upper
+// half), read from the epilogue's LDS staging.  Same arithmetic as rope2d_kernel on the fp16-rounded projection.
+DEVINL void rope_store4(const GemmArgs& g, int z, const float* bias, int gm, int gn, f32x4 own, f32x4 partner) {
+    const int hl = gn & 63, X = hl >> 5, within = hl & 31;
+    const bool lower = within < 16;
+    const int j = within & 15;
+    const int pn = lower ? gn + 16 : gn - 16;
+    if (bias) {
+        own += *reinterpret_cast<const f32x4*>(bias + gn);
+        partner += *reinterpret_cast<const f32x4*>(bias + pn);
+    }
+    long long pv = g.rope_pos[(size_t)gm * 2 + X] - g.rope_pmin;
+    pv = pv < 0 ? 0 : (pv >= g.rope_npos ? g.rope_npos - 1 : pv);
+    const float* ct = g.rope_table + (size_t)pv * 16 + j;
+    const float* st = ct + (size_t)g.rope_npos * 16;
+    half4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float a = (float)(h16)own[e], b = (float)(h16)partner[e];
+        float t = b * st[e];
+        asm volatile("" : "+v"(t));                 // a separate multiply, as in rope2d_kernel (no re-contraction)
+        o[e] = (h16)rope_rot(a, ct[e], lower ? -t : t);
+    }
+    *reinterpret_cast<half4_t*>((h16*)g.C + (size_t)z * g.sC + (size_t)gm * g.ldc + gn) = o;
 }
 
 // XCD-aware rasterisation of a 1-D grid: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
@@ -295,7 +324,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     for (int r = tid / TPR; r < BM; r += RPP) {
         const int gm = m0 + r;
         if (gm >= M) break;
-        fused_store4(g, z, bias, gm, gn, *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
+        if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, v, *reinterpret_cast<const f32x4*>(cs + r * CPAD + (((gn & 31) < 16) ? c4 + 16 : c4 - 16)));
+        else fused_store4(g, z, bias, gm, gn, v);
     }
 }
 
@@ -512,7 +543,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) {
             for (int it = 0; it < 8; it++) {
                 const int rr = it * 4 + er;
                 const int gm = m0 + wr * 128 + mp * 32 + rr;
-                if (gm < M) fused_store4(g, z, bias, gm, gn, *reinterpret_cast<const f32x4*>(cs + rr * CP + ec));
+                if (gm < M) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec);
+                    if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, v, *reinterpret_cast<const f32x4*>(cs + rr * CP + (((gn & 31) < 16) ? ec + 16 : ec - 16)));
+                    else fused_store4(g, z, bias, gm, gn, v);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -633,6 +668,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ X, 
 
 }  // namespace
 
+static inline int batch_of(const cut3r_gemm_desc* d) { return d->batch > 0 ? d->batch : 1; }
+
 extern "C" int cut3r_gemm_tile_for(const cut3r_gemm_desc* d) {
     if (!d) return 0;
     if (d->tile != 0) return d->tile;
@@ -671,11 +708,19 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     g.shuf = d->shuf; g.shuf_cout = d->shuf_cout; g.shuf_Hin = d->shuf_Hin; g.shuf_Win = d->shuf_Win;
     g.swz = 0;
     g.prio = (d->stages == 12) ? 1 : 0;
+    g.rope_pos = (const long long*)d->rope_pos; g.rope_table = d->rope_table;
+    g.rope_cols = d->rope_pos ? d->rope_cols : 0; g.rope_pmin = d->rope_pmin; g.rope_npos = d->rope_npos;
+    if (g.rope_cols) {
+        // whole heads of 64 inside the N range and inside every tile (tile widths are multiples of 64), fp16 output only
+        if (!d->rope_table || d->rope_npos < 1 || (g.rope_cols & 63) || g.rope_cols > d->N || !d->out_f16 || d->act || d->res1 || d->res2 ||
+            d->shuf || d->conv_k == 3 || (d->N & 63) || batch_of(d) != 1)
+            return CUT3R_ERR_ARG;
+    }
     const int batch = d->batch > 0 ? d->batch : 1;
     hipStream_t s = (hipStream_t)stream;
     const int tile = cut3r_gemm_tile_for(d);
     if (tile == 16) {
-        if (d->M > 64 || d->conv_k == 3 || d->shuf || d->relu_in) return CUT3R_ERR_ARG;
+        if (d->M > 64 || d->conv_k == 3 || d->shuf || d->relu_in || g.rope_cols) return CUT3R_ERR_ARG;
         dim3 grid((d->N + 15) / 16, 1, batch);
         const int mb = (d->M + 15) / 16;            // 1..4 row blocks; K >= 2048 splits over 8 waves, else 4
 #define CUT3R_SKINNY(NWV, MBV) hipLaunchKernelGGL((gemm_skinny_kernel<NWV, MBV>), grid, dim3(64 * NWV), 0, s, g)

@@ -76,6 +76,7 @@ class Cut3rModel:
         # the state-side and image-side decoder blocks of a layer are independent (both read the previous layer's
         # pair, model.py:669-692): issue them on two streams so the captured graph has two parallel branches
         self.dual_stream = _os.environ.get("CUT3R_DUAL_STREAM", "1") != "0"
+        self.fused_rope = _os.environ.get("CUT3R_FUSED_ROPE", "1") != "0"      # RoPE in the q/k projection epilogue (D = 64)
         self.kv_branch = _os.environ.get("CUT3R_KV_BRANCH", "0") != "0"   # nested capture forks segfault in hipGraph capture_end (ROCm 7.2)
         self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "0") != "0"     # measured: no gain over the batched head
         self._side = None
@@ -223,11 +224,18 @@ class Cut3rModel:
         return t
 
     # ------------------------------------------------------------------ primitives
-    def _linear(self, x16, name, out, act=0, res1=None, res2=None, skinny=False):
+    def _linear(self, x16, name, out, act=0, res1=None, res2=None, skinny=False, rope=None):
         """skinny: the operand has ONE row per independent sequence (pose token of a tracking window): weight-streaming
-        kernel whose per-row result does not depend on how many windows are batched"""
+        kernel whose per-row result does not depend on how many windows are batched.
+        rope = (positions [B,N,2], cols): RoPE of the first `cols` output columns fused into the GEMM epilogue."""
         L = self.w[name]
-        return ops.linear(x16, L.w, out, L.b, act, res1, res2, tile=16 if skinny else 0)
+        if rope is not None:
+            rope = (rope[0], rope[1], self.cfg.rope_freq)
+        return ops.linear(x16, L.w, out, L.b, act, res1, res2, tile=16 if skinny else 0, rope=rope)
+
+    def _fuse_rope(self, pos, D, rows):
+        """the GEMM-fused RoPE covers head dimension 64 with one position row per GEMM row"""
+        return self.fused_rope and pos is not None and D == 64 and pos.is_contiguous() and pos.numel() == 2 * rows
 
     def _ln(self, x, name, out16=None, out32=None, mod=None):
         g, b = self.w[name]
@@ -242,10 +250,11 @@ class Cut3rModel:
         D = Cc // heads
         sk = N == 1
         qkv = self.buf(tag + ".qkv", (B * N, 3 * Cc), F16)
-        self._linear(x_ln16, p + ".qkv", qkv, skinny=sk)
+        fuse = (not sk) and self._fuse_rope(pos, D, B * N)
+        self._linear(x_ln16, p + ".qkv", qkv, skinny=sk, rope=(pos, 2 * Cc) if fuse else None)
         v5 = qkv.view(B, N, 3, heads, D)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
-        if pos is not None:
+        if pos is not None and not fuse:
             ops.rope_2d_qk(q, k, pos, self.cfg.rope_freq, 1.0)
         a = self.buf(tag + ".attn", (B, N, heads, D), F16)
         ops.attention(q, k, v, a, D ** -0.5)
@@ -354,8 +363,9 @@ class Cut3rModel:
 
         def kv_branch():          # depends only on y (the other stream's previous layer): norm_y -> projk|projv -> RoPE(k)
             self._ln(y, p + ".norm_y", out16=y16)
-            self._linear(y16, p + ".cross_attn.projkv", kv, skinny=(Ny == 1))
-            if ypos is not None:
+            fuse_k = Ny > 1 and self._fuse_rope(ypos, D, B * Ny)
+            self._linear(y16, p + ".cross_attn.projkv", kv, skinny=(Ny == 1), rope=(ypos, Cc) if fuse_k else None)
+            if ypos is not None and not fuse_k:
                 self._rope(k, ypos)
 
         fork = self.dual_stream and self.kv_branch and self.use_graphs and torch.cuda.is_current_stream_capturing()
@@ -371,8 +381,9 @@ class Cut3rModel:
         self._self_attn(tag, ln16, B, Nx, heads, xpos, p + ".attn", out, x)
         self._ln(out, p + ".norm2", out16=ln16)
         q = self.buf(tag + ".q", (B, Nx, heads, D), F16)
-        self._linear(ln16, p + ".cross_attn.projq", q.view(B * Nx, Cc), skinny=(Nx == 1))
-        if xpos is not None:
+        fuse_q = Nx > 1 and self._fuse_rope(xpos, D, B * Nx)
+        self._linear(ln16, p + ".cross_attn.projq", q.view(B * Nx, Cc), skinny=(Nx == 1), rope=(xpos, Cc) if fuse_q else None)
+        if xpos is not None and not fuse_q:
             self._rope(q, xpos)
         if fork:
             cur.wait_stream(side)

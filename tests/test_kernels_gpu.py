@@ -86,6 +86,28 @@ def test_gemm256_race_screen(M, N, K):
                 assert torch.equal(o, ref), f"rep {rep}: {(o != ref).sum().item()} elements differ, max {(o - ref).abs().max().item()}"
 
 
+@pytest.mark.parametrize("tile", [64, 128, 256])
+@pytest.mark.parametrize("M,N,cols", [(1538, 2304, 1536), (769, 768, 768), (1536, 1536, 768), (300, 128, 64)])
+def test_gemm_fused_rope_equals_gemm_then_rope_kernel(M, N, cols, tile):
+    """RoPE in the projection epilogue (head dimension 64) must reproduce the separate rope_2d kernel bit for bit:
+    q|k|v, q-only and k|v layouts, positions including the pose token's -1, ragged last row tile."""
+    K = 192
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).half().to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    pos = torch.randint(-1, 33, (M, 2), generator=g, dtype=torch.int64).to(DEV)
+    ref = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.linear(A, W, ref, b, 0, tile=tile)
+    heads = cols // 64
+    ops.rope_2d(ref.view(1, M, N // 64, 64)[:, :, :heads], pos.view(1, M, 2), 100.0, 1.0)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+    ops.linear(A, W, out, b, 0, tile=tile, rope=(pos, cols, 100.0))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref), f"{(out != ref).sum().item()} elements differ, max {(out.float() - ref.float()).abs().max().item()}"
+    assert not torch.equal(out[:, :cols], (A.float() @ W.float().t() + b).half()[:, :cols])      # RoPE did something
+
+
 def test_skinny_gemm_rows_do_not_depend_on_the_batch():
     """a row of the M <= 64 kernel must come out bit-identical whatever M is (window-batch invariance of the pose path)"""
     g = torch.Generator().manual_seed(4)
