@@ -201,37 +201,49 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(const float* __restrict__ 
     }
 }
 
-// backward counts: blockIdx.z = view v (camera of keyframe i = t0 + v), blockIdx.y = stored pointmap b < i
+// backward counts: blockIdx.y = stored pointmap b; the points are read ONCE and tested against the cameras of all the
+// window's keyframes i = t0 + v > b (the per-keyframe entry point streams every stored pointmap once per keyframe)
 __global__ __launch_bounds__(256) void win_bwd_kernel(const float* __restrict__ pms, int N, int grp, int grp_stride,
                                                       const float* __restrict__ w2c, Cam cam, int32_t* __restrict__ counts, int ldc,
                                                       WinArgs wa) {
-    __shared__ int32_t wsum[4];
-    __shared__ float m[12];
-    const int v = blockIdx.z, kfi = wa.t0 + v, b = blockIdx.y;
-    if (kfi < wa.first || b >= kfi) return;
+    __shared__ int32_t wsum[6][4];
+    __shared__ float m[6][12];
+    const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 12) m[tid] = w2c[12 * (size_t)kfi + tid];
+    if (tid < 12 * wa.V) m[tid / 12][tid % 12] = w2c[12 * (size_t)(wa.t0 + tid / 12) + tid % 12];
     __syncthreads();
     const int slot = grp > 0 ? (b / grp) * grp_stride + (b % grp) : b;
     const float* pm = pms + (size_t)slot * N * 3;
-    int c = 0;
+    int c[6] = {0, 0, 0, 0, 0, 0};
     const int nquad = N >> 2;
     for (int qd = blockIdx.x * 256 + tid; qd < nquad; qd += gridDim.x * 256) {
         const f32x4* p4 = reinterpret_cast<const f32x4*>(pm + (size_t)qd * 12);
         const f32x4 a = p4[0], bb = p4[1], cc = p4[2];
-        c += proj_valid(m, a[0], a[1], a[2], cam, false);
-        c += proj_valid(m, a[3], bb[0], bb[1], cam, false);
-        c += proj_valid(m, bb[2], bb[3], cc[0], cam, false);
-        c += proj_valid(m, cc[1], cc[2], cc[3], cam, false);
+#pragma unroll
+        for (int v = 0; v < 6; v++) {
+            if (v < wa.V) {
+                c[v] += proj_valid(m[v], a[0], a[1], a[2], cam, false);
+                c[v] += proj_valid(m[v], a[3], bb[0], bb[1], cam, false);
+                c[v] += proj_valid(m[v], bb[2], bb[3], cc[0], cam, false);
+                c[v] += proj_valid(m[v], cc[1], cc[2], cc[3], cam, false);
+            }
+        }
     }
     if (blockIdx.x == 0)
-        for (int p = (nquad << 2) + tid; p < N; p += 256) c += proj_valid(m, pm[3 * p], pm[3 * p + 1], pm[3 * p + 2], cam, false);
-    c = wave_sum_i(c);
-    if (lane == 0) wsum[wave] = c;
+        for (int p = (nquad << 2) + tid; p < N; p += 256)
+#pragma unroll
+            for (int v = 0; v < 6; v++)
+                if (v < wa.V) c[v] += proj_valid(m[v], pm[3 * p], pm[3 * p + 1], pm[3 * p + 2], cam, false);
+#pragma unroll
+    for (int v = 0; v < 6; v++) {
+        c[v] = wave_sum_i(c[v]);
+        if (lane == 0) wsum[v][wave] = c[v];
+    }
     __syncthreads();
-    if (tid == 0) {
-        const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (t) atomicAdd(&counts[(size_t)v * 2 * ldc + ldc + b], t);
+    if (tid < wa.V) {
+        const int kfi = wa.t0 + tid;
+        const int t = wsum[tid][0] + wsum[tid][1] + wsum[tid][2] + wsum[tid][3];
+        if (kfi >= wa.first && b < kfi && t) atomicAdd(&counts[(size_t)tid * 2 * ldc + ldc + b], t);
     }
 }
 
@@ -370,7 +382,7 @@ extern "C" int cut3r_window_update(const float* pts, const float* conf, int V, i
         if (gx < 1) gx = 1;
         if (gx > 64) gx = 64;
         if (last > 65535) return CUT3R_ERR_ARG;
-        hipLaunchKernelGGL(win_bwd_kernel, dim3(gx, last, V), dim3(256), 0, st, store, Nd, grp, grp_stride, w2c, camb, counts, ldc, wa);
+        hipLaunchKernelGGL(win_bwd_kernel, dim3(gx, last), dim3(256), 0, st, store, Nd, grp, grp_stride, w2c, camb, counts, ldc, wa);
     }
     return cut3r_check_launch();
 }
