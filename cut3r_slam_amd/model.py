@@ -78,7 +78,10 @@ class Cut3rModel:
         self.dual_stream = _os.environ.get("CUT3R_DUAL_STREAM", "1") != "0"
         self.fused_rope = _os.environ.get("CUT3R_FUSED_ROPE", "1") != "0"      # RoPE in the q/k projection epilogue (D = 64)
         self.kv_branch = _os.environ.get("CUT3R_KV_BRANCH", "0") != "0"   # nested capture forks segfault in hipGraph capture_end (ROCm 7.2)
-        self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "0") != "0"     # measured: no gain over the batched head
+        # DPT head of view i (all windows) on a third stream while the recurrent decoder works on view i+1: the decoder's
+        # mid-size kernels leave matrix and memory pipes idle that the head's large convolutions can use
+        self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "1") != "0"
+        self._head_stream = None
         self._side = None
         self._kv_side = {}
         self._head_side = None
@@ -585,6 +588,13 @@ class Cut3rModel:
         fork = self.dual_stream and self.use_graphs and torch.cuda.is_current_stream_capturing()
         if fork and self._side is None:
             self._side = torch.cuda.Stream()
+        head_fork = fork and self.head_overlap and cfg.head_type == "dpt"
+        head_pts = head_conf = None
+        if head_fork:
+            if self._head_stream is None:
+                self._head_stream = torch.cuda.Stream()
+            head_pts = torch.empty((Wn * V, H, W, 3), dtype=F32, device=dev)
+            head_conf = torch.empty((Wn * V, H, W), dtype=F32, device=dev)
         for i in range(V):
             for w in range(Wn):
                 ops.colmean(feat[w, i], g32[w])
@@ -627,6 +637,24 @@ class Cut3rModel:
             pose_tok16[:, i].copy_(dn16v[:, 0])
             self._mem_update(mem[cm], g16, dn32v[:, 0], mem[cm ^ 1], Wn)
             cm ^= 1
+            if head_fork:
+                # fork: this view's DPT head (batch = the Wn windows) runs beside the decoder of the next view
+                cur = torch.cuda.current_stream()
+                self._head_stream.wait_stream(cur)
+                with torch.cuda.stream(self._head_stream):
+                    for c0 in range(0, Wn, 8):
+                        c1 = min(Wn, c0 + 8)
+                        nb = c1 - c0
+                        tk = []
+                        for name, src, dim in (("f", feat16, E), ("t1", tok1, D), ("t2", tok2, D), ("t3", tok3, D)):
+                            t = self.buf("head.view." + name, (nb, N, dim), F16)
+                            t.copy_(src[c0:c1, i])
+                            tk.append(t.view(nb * N, dim))
+                        pv = self.buf("head.view.pts", (nb, H, W, 3), F32)
+                        cv = self.buf("head.view.conf", (nb, H, W), F32)
+                        self._dpt_pts("downstream_head.dpt_self", tk, nb, nh, nw, H, W, None, None, None, out=(pv, cv))
+                        head_pts.view(Wn, V, H, W, 3)[c0:c1, i].copy_(pv)
+                        head_conf.view(Wn, V, H, W)[c0:c1, i].copy_(cv)
             # the state ping-pong: make st[cs] hold the new state for the next view
             cs = 0 if new_state is st[0] else 1
             if return_taps:
@@ -645,7 +673,10 @@ class Cut3rModel:
         ops.postprocess_pose(praw[:, :7].contiguous(), pose)
         res: Dict[str, torch.Tensor] = {"camera_pose": pose}
         toks = [feat16.reshape(BV * N, E), tok1.view(BV * N, D), tok2.view(BV * N, D), tok3.view(BV * N, D)]
-        if cfg.head_type == "dpt":
+        if head_fork:
+            torch.cuda.current_stream().wait_stream(self._head_stream)          # join the head branch
+            res["pts3d_in_self_view"], res["conf_self"] = head_pts, head_conf
+        elif cfg.head_type == "dpt":
             # chunks of <= 8 views keep the implicit-GEMM grids (M/128 row tiles on grid.y) inside the 65535 limit
             pts = torch.empty((BV, H, W, 3), dtype=F32, device=dev)
             conf = torch.empty((BV, H, W), dtype=F32, device=dev)
