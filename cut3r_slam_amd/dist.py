@@ -72,6 +72,9 @@ class ShardedTracker:
         self._next_t0 = None            # first keyframe of the next window to be scheduled
         self._side = None
         self._pose_pinned = [None, None]
+        self._appended_upto = 0
+        self._enc_stream, self._ahead = None, None        # look-ahead encoder pass: (ranges, features, event)
+        self.encode_ahead = os.environ.get("CUT3R_ENC_AHEAD", "1") == "1"
         self.side_priority = int(os.environ.get("CUT3R_SIDE_PRIORITY", "0"))         # 0: measured best; -1 (high) starves the network pass once the host runs ahead
         self.stats = {"append_s": 0.0, "issue_s": 0.0, "issue_enc_s": 0.0, "replay_s": 0.0, "replay_wait_s": 0.0, "exchange_s": 0.0, "steps": 0}     # host wall-clock per phase
 
@@ -160,6 +163,16 @@ class ShardedTracker:
                 self.slam.tracker.t1 = ranges_all[-1][1]
         self.stats["replay_s"] += time.perf_counter() - tic
 
+    def _append_range(self, frames, t, n_frames, kf_every, win, intr, first_t0):
+        """register the keyframes among frames t..t+n_frames-1 (once: a look-ahead may already have done it)"""
+        slam, world, rank, wb = self.slam, self.world, self.rank, self.wb
+        for f in range(max(t, self._appended_upto), t + n_frames):
+            if f % kf_every == 0:
+                k = slam.keyframes.counter.value
+                owner = min(max((k - first_t0 - 1) // (win * wb), 0), world - 1) if k > first_t0 else 0
+                self.append_fn(k, frames[f:f + 1], f, intr, owner == rank)
+        self._appended_upto = max(self._appended_upto, t + n_frames)
+
     def step(self, frames, t, kf_every, win, intr):
         """Advance world*wb windows (= world*wb*win*kf_every frames).  Returns the new frame counter."""
         slam, world, rank, wb = self.slam, self.world, self.rank, self.wb
@@ -172,11 +185,7 @@ class ShardedTracker:
         #    every rank registers all of them, only the owner of a window ever encodes them
         n_frames = world * wb * win * kf_every
         tic0 = time.perf_counter()
-        for f in range(t, t + n_frames):
-            if f % kf_every == 0:
-                k = slam.keyframes.counter.value
-                owner = min(max((k - first_t0 - 1) // (win * wb), 0), world - 1) if k > first_t0 else 0
-                self.append_fn(k, frames[f:f + 1], f, intr, owner == rank)
+        self._append_range(frames, t, n_frames, kf_every, win, intr, first_t0)
         tic = time.perf_counter()
         self.stats["append_s"] += tic - tic0
         if self.infer_fn is not None:
@@ -187,10 +196,33 @@ class ShardedTracker:
                 self._replay(self._pending)
                 self._pending = None
         else:
-            # 2. encoder graph of this rank's new keyframes (one stream), asynchronous on the main stream
-            feats = self._encode(mine)
+            # 2. encoder features of this rank's windows: from the look-ahead pass issued during the previous step (its own
+            #    stream, beside that step's decoder), else encoded now on the main stream
+            if self._ahead is not None and self._ahead[0] == mine:
+                _, feats, ev_enc = self._ahead
+                torch.cuda.current_stream().wait_event(ev_enc)
+                feats.record_stream(torch.cuda.current_stream())
+            else:
+                feats = self._encode(mine)
+            self._ahead = None
             self.stats["issue_s"] += time.perf_counter() - tic
             self.stats["issue_enc_s"] += time.perf_counter() - tic
+            # 2b. look-ahead: register the next step's keyframes and start THEIR encoder pass on the encoder stream; it runs
+            #     beside this step's decoder (large efficient GEMMs filling the gaps of the decoder's mid-size kernels)
+            t_next = t + n_frames
+            if self.encode_ahead and self.pipelined and t_next + n_frames <= frames.shape[0] and feats.is_cuda:
+                nxt_first = ranges_all[-1][1] - 1
+                nxt_all = window_ranges(nxt_first, world * wb, win)
+                nxt_mine = nxt_all[rank * wb:(rank + 1) * wb]
+                self._append_range(frames, t_next, n_frames, kf_every, win, intr, nxt_first)
+                if self._enc_stream is None:
+                    self._enc_stream = torch.cuda.Stream()
+                self._enc_stream.wait_stream(torch.cuda.current_stream())      # the keyframe images were copied on this stream
+                with torch.cuda.stream(self._enc_stream):
+                    nf = self._encode(nxt_mine)
+                    ev_enc = torch.cuda.Event()
+                    ev_enc.record()
+                self._ahead = (nxt_mine, nf, ev_enc)
             # 3. replay of the previous step's chaining + graph update (side stream) while the encoder runs.  It is
             #    issued BEFORE the decoder graph on purpose: that graph has parallel branches on several hardware queues and
             #    anything queued behind it on a shared queue waits for the whole branch (measured: ~40 ms per step)

@@ -147,6 +147,43 @@ def test_window_batch_gives_the_same_trajectory_and_graph():
         np.testing.assert_array_equal(a, b)
 
 
+def test_pipelined_driver_equals_the_frame_by_frame_loop():
+    """dist.ShardedTracker (window batch 3, encoder look-ahead on its own stream, replay on the side stream behind the
+    encoder graph, decoder graph last) must leave the same keyframe poses, depths and ordered edge lists as feeding the
+    frames one by one through Cut3rSlam.run with the reference schedule."""
+    from cut3r_slam_amd import dist as cdist
+    kf_every, win, wb, steps = 2, 5, 3, 2
+    n = (7 + win * wb * steps + 1) * kf_every + 1
+    frames = _frames(n, seed=4).to(DEV)
+    intr = torch.tensor([40.0, 40.0, 23.5, 15.5])
+    cfgd = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 1, "kf_every": kf_every}, "frontend": {"iteration": 0}}}
+    # reference schedule: one frame at a time, one window at a time
+    ref = Cut3rSlam(_model(), cfgd, (H, W), buffer=64, device=DEV)
+    for t in range(n - 1):
+        ref.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+    # pipelined driver
+    slam = Cut3rSlam(_model(), cfgd, (H, W), buffer=64, device=DEV)
+    t = 0
+    while not slam.keyframes.is_initialized:
+        slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+        t += 1
+    runner = cdist.ShardedTracker(slam, 1, 0, wb=wb, pipelined=True)
+    assert frames.shape[0] >= runner.frames_needed(steps, kf_every, win)
+    for _ in range(steps):
+        t = runner.step(frames, t, kf_every, win, intr)
+    runner.flush()
+    torch.cuda.synchronize()
+    k = slam.tracker.t1
+    assert k == 6 + win * wb * steps and ref.tracker.t1 >= k
+    np.testing.assert_allclose(slam.keyframes.pose[:k].numpy(), ref.keyframes.pose[:k].numpy(), atol=1e-5)
+    np.testing.assert_allclose(slam.keyframes.depth[:k].cpu().numpy(), ref.keyframes.depth[:k].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    e_ref = [np.asarray(x) for x in ref.graph.edges_numpy()]
+    keep = (e_ref[0] < k) & (e_ref[1] < k)                    # the frame-by-frame loop may already have tracked one window more
+    e_got = slam.graph.edges_numpy()
+    np.testing.assert_array_equal(e_got[0], e_ref[0][keep])
+    np.testing.assert_array_equal(e_got[1], e_ref[1][keep])
+
+
 def test_sharded_overlap_counting_two_ranks_in_one_process():
     """Multi-GPU replay (dist.ShardedTracker): every rank chains and stores every window, the overlap counting of a window
     runs only on its owner and the owners' counts are summed before the decisions.  Two trackers play the two ranks here
