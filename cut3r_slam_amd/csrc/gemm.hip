@@ -682,7 +682,8 @@ extern "C" int cut3r_gemm_tile_for(const cut3r_gemm_desc* d) {
     const long long blocks256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
     // one workgroup per CU: a grid of 300 tiles costs two full rounds, so also require >= 85 % of the last round
     const long long rounds = (blocks256 + 255) / 256;
-    const bool fills = blocks256 * 100 >= rounds * 256 * 85;
+    static const long long fill_pct = [] { const char* e = getenv("CUT3R_GEMM_T256_FILL"); return e ? atoll(e) : 85LL; }();
+    const bool fills = blocks256 * 100 >= rounds * 256 * fill_pct;
     if (d->conv_k != 3 && !d->shuf && (d->N & 255) == 0 && blocks256 >= t256_min && fills) return 256;
     return (big_blocks >= 128) ? 128 : 64;
 }
