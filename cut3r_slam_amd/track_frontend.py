@@ -102,6 +102,34 @@ class TrackFrontend:
         pose_enc = torch.cat([p["camera_pose"] for p in preds], 0)         # [V,7] (t, q wxyz)
         return pts.contiguous(), conf.contiguous(), pose_enc
 
+    def predict(self, new_img, kf_img, kf_pose, kf_depth, kf_pointmap=None, outputs=None):
+        """track_frontend.py:102-162: pose / depth / stride-ds pointmap of a NON-keyframe `new_img` from a 2-view inference
+        [keyframe, new frame], chained to the keyframe by the log-depth scale and the keyframe pose (hi2.py:203 uses it to
+        densify the map between distant keyframes).  new_img, kf_img u8 [3,H,W]; kf_pose [7] c2w (t, q_xyzw); kf_depth
+        [H,W].  Returns (new_pose [7] host, new_depth [H,W], new_pointmap [h,w,3], new_conf [h,w]) -- the last three on the
+        GPU; new_conf is the raw confidence of view 0 as in the reference (:114,157).  kf_pointmap is only read by the
+        reference's disabled Umeyama branch."""
+        ds = self.downsample_ratio
+        if outputs is None:
+            outputs = self.infer(torch.stack([kf_img, new_img], 0).to(self.device))
+        pts, conf, pose_enc = outputs
+        _, H, W, _ = pts.shape
+        kf_depth = torch.as_tensor(kf_depth).to(self.device, torch.float32).contiguous()
+        lsum = torch.zeros(1, dtype=torch.float64, device=self.device)
+        ops.logdepth_sum(kf_depth, pts[0].contiguous(), lsum)
+        packed = torch.cat([pose_enc.detach().reshape(-1).double(), lsum]).cpu().numpy()
+        host, lsum = packed[:-1].astype(np.float32).reshape(2, 7), float(packed[-1])
+        poses = gh.pose_encoding_to_camera(host)
+        align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
+        prev_c2w = gh.pose_vec_to_matrix(np.asarray(torch.as_tensor(kf_pose).cpu(), np.float32)[None])[0]
+        pose = gh.chain_pose(gh.inv4(poses[0]), poses[1], prev_c2w[:3, :3], prev_c2w[:3, 3], align_s)
+        pm = torch.empty(H // ds, W // ds, 3, device=self.device)
+        cf = torch.empty(H // ds, W // ds, device=self.device)
+        depth = torch.empty(H, W, device=self.device)
+        ops.align_view(pts[1].contiguous(), conf[1].contiguous(), pose[:3, :4].reshape(-1), float(align_s), ds, pm, cf, depth)
+        new_pose = torch.from_numpy(gh.matrix_to_pose_vec(pose))
+        return new_pose, depth, pm, conf[0][::ds, ::ds].contiguous()
+
     def track(self, t0, t1, init=False, outputs=None):
         """track_frontend.py:166-262.  `outputs` = (pts, conf, pose_enc) lets callers (tests, the multi-GPU
         driver) supply precomputed network outputs."""

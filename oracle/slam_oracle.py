@@ -3,6 +3,7 @@ to check the product's HIP-backed tracker on identical network outputs.
 
   OracleOverlapBackend   counts from oracle/oracle_geom.c (pinned to the reference's cal_overlap_* outputs)
   track_window           /root/reference/hislam2/track_frontend.py:166-262 in torch-CPU fp32, line by line
+  predict                /root/reference/hislam2/track_frontend.py:102-162 (2-view relocalisation of a non-keyframe)
   RefGraph               /root/reference/hislam2/factor_graph.py:29-39,59-81,109-117,148-197 (ordered edge lists)
 """
 from __future__ import annotations
@@ -62,6 +63,26 @@ def pose_vec_to_matrix(pose):
     T[:, :3, :3] = R
     T[:, :3, 3] = pose[:, :3]
     return T
+
+
+def predict(pts3ds_self, conf_self, pose_enc, kf_pose, kf_depth, ds=2):
+    """/root/reference/hislam2/track_frontend.py:102-162 on the outputs of the 2-view inference [keyframe, new frame]
+    (torch CPU): returns (new_pose [7] c2w (t, q_xyzw), new_depth [H,W], new_pointmap [h,w,3], new_conf [h,w]).
+    Quirk kept: the returned confidence is the raw conf_self of view 0 (the keyframe), downsampled (:114,157)."""
+    poses = pose_encoding_to_camera(pose_enc)
+    depths = pts3ds_self[..., 2]
+    conf = conf_self[0]
+    log_scale = (torch.log(kf_depth) - torch.log(depths[0])).mean()
+    align_s = torch.exp(log_scale)
+    prev_c2w = pose_vec_to_matrix(kf_pose.unsqueeze(0))[0]
+    align_R, align_t = prev_c2w[:3, :3], prev_c2w[:3, 3]
+    pose = torch.inverse(poses[0]) @ poses[1]
+    pa = torch.eye(4)
+    pa[:3, :3] = align_R @ pose[:3, :3]
+    pa[:3, 3] = align_R @ (align_s * pose[:3, 3]) + align_t
+    pointmap = torch.einsum("ij,hwj->hwi", pa[:3, :3], align_s * pts3ds_self[1]) + pa[:3, 3]
+    quat = torch.from_numpy(Rotation.from_matrix(pa[:3, :3].numpy()).as_quat())
+    return torch.cat([pa[:3, 3], quat], dim=-1), align_s * depths[1], pointmap[::ds, ::ds], conf[::ds, ::ds]
 
 
 def track_window(state, t0, t1, pts3ds_self, conf_self, pose_enc, init, ds=2):

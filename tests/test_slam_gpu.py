@@ -147,6 +147,30 @@ def test_window_batch_gives_the_same_trajectory_and_graph():
         np.testing.assert_array_equal(a, b)
 
 
+def test_predict_matches_oracle_on_same_network_outputs():
+    """TrackFrontend.predict (track_frontend.py:102-162) against its CPU restatement on identical 2-view outputs"""
+    frames = _frames(8, seed=7)
+    intr = torch.tensor([40.0, 40.0, 23.5, 15.5])
+    model = _model()
+    cfgd = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 1, "kf_every": 2}, "frontend": {"iteration": 0}}}
+    slam = Cut3rSlam(model, cfgd, (H, W), buffer=16, device=DEV)
+    tr = slam.tracker
+    outs = tuple(t.clone() for t in tr.infer(torch.stack([frames[0], frames[3]], 0).to(DEV)))
+    g = torch.Generator().manual_seed(1)
+    kf_pose = torch.cat([torch.randn(3, generator=g) * 0.3, torch.nn.functional.normalize(torch.randn(4, generator=g), dim=0)])
+    kf_depth = outs[0][0, ..., 2].abs().cpu() * 1.7 + 0.05
+    new_pose, new_depth, new_pm, new_conf = tr.predict(frames[3], frames[0], kf_pose, kf_depth, outputs=outs)
+    ref_pose, ref_depth, ref_pm, ref_conf = SO.predict(outs[0].cpu(), outs[1].cpu(), outs[2].cpu(), kf_pose, kf_depth)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(new_pose.numpy(), ref_pose.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(new_depth.cpu().numpy(), ref_depth.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(new_pm.cpu().numpy(), ref_pm.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(new_conf.cpu().numpy(), ref_conf.numpy())
+    # and the inference path itself (no precomputed outputs) runs and agrees with it
+    p2, d2, m2, c2 = tr.predict(frames[3], frames[0], kf_pose, kf_depth)
+    np.testing.assert_allclose(p2.numpy(), new_pose.numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_pipelined_driver_equals_the_frame_by_frame_loop():
     """dist.ShardedTracker (window batch 3, encoder look-ahead on its own stream, replay on the side stream behind the
     encoder graph, decoder graph last) must leave the same keyframe poses, depths and ordered edge lists as feeding the
