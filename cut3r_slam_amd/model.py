@@ -77,13 +77,11 @@ class Cut3rModel:
         # pair, model.py:669-692): issue them on two streams so the captured graph has two parallel branches
         self.dual_stream = _os.environ.get("CUT3R_DUAL_STREAM", "1") != "0"
         self.fused_rope = _os.environ.get("CUT3R_FUSED_ROPE", "1") != "0"      # RoPE in the q/k projection epilogue (D = 64)
-        self.kv_branch = _os.environ.get("CUT3R_KV_BRANCH", "0") != "0"   # nested capture forks segfault in hipGraph capture_end (ROCm 7.2)
         # DPT head of view i (all windows) on a third stream while the recurrent decoder works on view i+1: the decoder's
         # mid-size kernels leave matrix and memory pipes idle that the head's large convolutions can use
         self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "1") != "0"
         self._head_stream = None
         self._side = None
-        self._kv_side = {}
         self._head_side = None
         self._prep(state_dict)
 
@@ -371,15 +369,6 @@ class Cut3rModel:
             if ypos is not None and not fuse_k:
                 self._rope(k, ypos)
 
-        fork = self.dual_stream and self.kv_branch and self.use_graphs and torch.cuda.is_current_stream_capturing()
-        if fork:
-            cur = torch.cuda.current_stream()
-            side = self._kv_side.get(tag)
-            if side is None:
-                side = self._kv_side[tag] = torch.cuda.Stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                kv_branch()
         self._ln(x, p + ".norm1", out16=ln16)
         self._self_attn(tag, ln16, B, Nx, heads, xpos, p + ".attn", out, x)
         self._ln(out, p + ".norm2", out16=ln16)
@@ -388,10 +377,7 @@ class Cut3rModel:
         self._linear(ln16, p + ".cross_attn.projq", q.view(B * Nx, Cc), skinny=(Nx == 1), rope=(xpos, Cc) if fuse_q else None)
         if xpos is not None and not fuse_q:
             self._rope(q, xpos)
-        if fork:
-            cur.wait_stream(side)
-        else:
-            kv_branch()
+        kv_branch()      # (forking this onto its own capture stream was tried: nested forks crash hipGraph capture_end on ROCm 7.2)
         a = self.buf(tag + ".cattn", (B, Nx, heads, D), F16)
         ops.attention(q, k, v, a, D ** -0.5)
         self._linear(a.view(B * Nx, Cc), p + ".cross_attn.proj", out, res1=out, skinny=(Nx == 1))
