@@ -6,6 +6,7 @@ All functions validate shapes/dtypes/strides on the host BEFORE launching (a fau
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -109,7 +110,7 @@ def layernorm(x, gamma, beta, eps=1e-6, out16=None, out32=None, mod_scale=None, 
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-GEMM_STAGES = 0     # tuning override (0 = kernel default)
+GEMM_STAGES = int(os.environ.get("CUT3R_GEMM_STAGES", "0"))     # tuning override (0 = kernel default)
 
 
 def _fill_common(d, A, Bw, out, bias, res1, res2, act, tile):
