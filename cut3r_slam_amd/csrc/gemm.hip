@@ -164,7 +164,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     constexpr int NL = A_CH + B_CH;
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     constexpr int CPAD = BN + 4;
-    constexpr int EPI_BYTES = BM * CPAD * 4;
+    // the epilogue stages the tile through LDS in EPI_PASSES row bands so that it never needs more LDS than the ring
+    constexpr int EPI_PASSES = (BM * CPAD * 4 > NSTAGE * STAGE_BYTES && (BM % 32) == 0) ? 2 : 1;
+    constexpr int EPI_ROWS = BM / EPI_PASSES;
+    constexpr int EPI_BYTES = EPI_ROWS * CPAD * 4;
     constexpr int LDS_BYTES = (NSTAGE * STAGE_BYTES > EPI_BYTES) ? NSTAGE * STAGE_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
@@ -301,32 +304,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     }
     __syncthreads();
 
-    // ---- epilogue: accumulators -> LDS (fp32) -> coalesced fused store
+    // ---- epilogue: accumulators -> LDS (fp32) -> coalesced fused store, one row band per pass
     float* cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                int r = wm * WM + i * 16 + fq * 4 + e;
-                int c = wn * WN + j * 16 + fr;
-                cs[r * CPAD + c] = acc[i][j][e];
-            }
-    __syncthreads();
-
     const float* bias = g.bias ? g.bias + (size_t)z * g.sBias : nullptr;
     constexpr int TPR = BN / 4;               // threads per output row (4 columns each)
     constexpr int RPP = NTHR / TPR;           // rows per pass
     const int c4 = (tid % TPR) * 4;
     const int gn = n0 + c4;
-    if (gn >= N) return;
-    for (int r = tid / TPR; r < BM; r += RPP) {
-        const int gm = m0 + r;
-        if (gm >= M) break;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
-        if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, v, *reinterpret_cast<const f32x4*>(cs + r * CPAD + (((gn & 31) < 16) ? c4 + 16 : c4 - 16)));
-        else fused_store4(g, z, bias, gm, gn, v);
+#pragma unroll
+    for (int p = 0; p < EPI_PASSES; p++) {
+        if (p > 0) __syncthreads();           // the previous band has been read
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int r = wm * WM + i * 16 + fq * 4 + e - p * EPI_ROWS;
+                    const int c = wn * WN + j * 16 + fr;
+                    if (EPI_PASSES == 1 || (r >= 0 && r < EPI_ROWS)) cs[r * CPAD + c] = acc[i][j][e];
+                }
+        __syncthreads();
+        if (gn < N) {
+            for (int r = tid / TPR; r < EPI_ROWS; r += RPP) {
+                const int gm = m0 + p * EPI_ROWS + r;
+                if (gm >= M) break;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
+                if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, v, *reinterpret_cast<const f32x4*>(cs + r * CPAD + (((gn & 31) < 16) ? c4 + 16 : c4 - 16)));
+                else fused_store4(g, z, bias, gm, gn, v);
+            }
+        }
     }
 }
 
@@ -685,6 +692,12 @@ extern "C" int cut3r_gemm_tile_for(const cut3r_gemm_desc* d) {
     static const long long fill_pct = [] { const char* e = getenv("CUT3R_GEMM_T256_FILL"); return e ? atoll(e) : 85LL; }();
     const bool fills = blocks256 * 100 >= rounds * 256 * fill_pct;
     if (d->conv_k != 3 && !d->shuf && (d->N & 255) == 0 && blocks256 >= t256_min && fills) return 256;
+    // 192 x 128 (48 x 64 per wave: fewer LDS reads and L2->LDS bytes per FLOP than 128^2, still two workgroups per CU):
+    // alone +19 % on the M~6k x 1536 decoder projections and +9 % on the DPT 3x3 convolutions, but inside the tracking
+    // step (3-5 kernels in flight, idle CUs are taken by other streams) the gain is within noise (+0.5 %), so it stays an
+    // explicit choice (tile = 192128, CUT3R_GEMM_T192_MIN_M) rather than the default
+    static const long long t192_min = [] { const char* e = getenv("CUT3R_GEMM_T192_MIN_M"); return e ? atoll(e) : (1LL << 60); }();
+    if (!d->shuf && d->M >= t192_min && big_blocks >= 128) return 192128;
     return (big_blocks >= 128) ? 128 : 64;
 }
 
@@ -747,6 +760,10 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         else if (d->stages == 10) hipLaunchKernelGGL((gemm_kernel<128, 128, 3, 4, 2>), grid, dim3(512), 0, s, g);
         else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<128, 128, 2>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
+    } else if (tile == 192128) {       // 192 x 128, 8 waves (48 x 64 per wave), 80 KB LDS: two workgroups per CU
+        dim3 grid(((d->N + 127) / 128) * ((d->M + 191) / 192), 1, batch);
+        g.swz = 1;
+        hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
     } else if (tile == 256128) {
         dim3 grid((d->N + 127) / 128, (d->M + 255) / 256, batch);
         hipLaunchKernelGGL((gemm_kernel<256, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);

@@ -58,7 +58,7 @@ typedef struct cut3r_gemm_desc {
     int relu_in;          /* apply ReLU to A on load (ResidualConvUnit pre-activation) */
     int shuf;             /* > 0: ConvTranspose(k == stride == shuf) scatter; N = shuf*shuf*shuf_cout, ldc = Cout */
     int shuf_cout, shuf_Hin, shuf_Win;
-    int tile;             /* 0 = auto (cut3r_gemm_tile_for), 16 (M <= 64 skinny), 64, 128 or 256 */
+    int tile;             /* 0 = auto (cut3r_gemm_tile_for), 16 (M <= 64 skinny), 64, 128, 192128 (192 x 128) or 256 */
     int stages;           /* 0 = default; LDS ring depth override (tuning): 2|3 for tile 128, 2|3|4 for tile 64 */
     /* fused 2-D RoPE on the first rope_cols output columns (head dimension 64 only; fp16 output, no activation/residual):
      * what curope.rope_2d does to q / k right after the projection (croco/models/blocks.py:126-127, dust3r/blocks.py

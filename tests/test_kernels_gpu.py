@@ -44,6 +44,8 @@ def _report(name, got, ref, tol):
     # 256^2 ping-pong kernel: full tiles, ragged M / N / K (K tail inside a 64-deep tile), one K-tile, two K-tiles
     (3072, 1024, 1024, 256), (769, 768, 768, 256), (1000, 516, 200, 256), (300, 260, 64, 256), (257, 256, 128, 256),
     (5, 12, 8, 256),
+    # 192 x 128 tile (two-band epilogue): full tiles, ragged M / N / K
+    (6152, 768, 768, 192128), (385, 260, 200, 192128), (191, 128, 64, 192128), (193, 132, 72, 192128),
     # skinny M <= 64 kernel (pose memory / pose MLP rows): K split over 4 and 8 waves, 1/2/4 row blocks, ragged N and K
     (8, 1536, 1536, 16), (8, 1536, 6144, 16), (1, 4608, 1536, 16), (16, 6144, 1536, 16), (3, 20, 40, 16), (7, 3072, 768, 16), (12, 8, 3072, 16),
     (24, 1536, 6144, 16), (33, 1536, 1536, 16), (64, 768, 3072, 16), (50, 36, 72, 16), (150, 1536, 1536, 16)])
@@ -86,7 +88,7 @@ def test_gemm256_race_screen(M, N, K):
                 assert torch.equal(o, ref), f"rep {rep}: {(o != ref).sum().item()} elements differ, max {(o - ref).abs().max().item()}"
 
 
-@pytest.mark.parametrize("tile", [64, 128, 256])
+@pytest.mark.parametrize("tile", [64, 128, 256, 192128])
 @pytest.mark.parametrize("M,N,cols", [(1538, 2304, 1536), (769, 768, 768), (1536, 1536, 768), (300, 128, 64)])
 def test_gemm_fused_rope_equals_gemm_then_rope_kernel(M, N, cols, tile):
     """RoPE in the projection epilogue (head dimension 64) must reproduce the separate rope_2d kernel bit for bit:
