@@ -84,3 +84,12 @@ def test_save_trajectory_format(tmp_path):
     assert rows[1].split()[0] == "10.0000" and len(rows[1].split()[1].split(".")[1]) == 7
     np.testing.assert_allclose(np.load(out / "intrinsics.npy"), [256.0, 339.0, 255.8, 191.7])
     assert traj.shape == (5, 8)
+
+
+def test_demo_config_loader_inherits_and_cli_defaults(tmp_path):
+    import demo
+    (tmp_path / "base.yaml").write_text("Tracking:\n  motion_filter:\n    thresh: 2.4\n    skip_blur: false\n  frontend:\n    frontend_nms: 1\n")
+    (tmp_path / "child.yaml").write_text("inherit_from: base.yaml\nTracking:\n  motion_filter:\n    thresh: 0.9\n")
+    cfg = demo.load_config(str(tmp_path / "child.yaml"))
+    assert cfg["Tracking"]["motion_filter"] == {"thresh": 0.9, "skip_blur": False}
+    assert cfg["Tracking"]["frontend"]["frontend_nms"] == 1
