@@ -593,8 +593,13 @@ class Cut3rModel:
                 a3[:, 0] = self._mem_inquire(g16, mem[cm], Wn)
             ops.linear_batched(feat16[:, i], w_de, a3[:, 1:], b_de)                                   # decoder_embed
             s_a, s_b = st[cs], st[cs ^ 1]
+            # after the window's last view the recurrent state and the pose memory are never read again (the next window
+            # re-initialises both, model.py:819-822): their final updates are skipped unless the caller asked for them
+            dead_tail = (i == V - 1) and not return_taps
             for l in range(Ld):
-                if fork:
+                if dead_tail and l == Ld - 1:
+                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn)
+                elif fork:
                     cur = torch.cuda.current_stream()
                     self._side.wait_stream(cur)
                     with torch.cuda.stream(self._side):
@@ -612,7 +617,8 @@ class Cut3rModel:
                     for w in range(Wn):
                         ops.cast_f16(av[w, 1:], tk[w, i])
             # final norms (model.py:694-697): new state = dec_norm_state(state), img = dec_norm(img)
-            self._ln(s_a, "dec_norm_state", out32=s_b)
+            if not dead_tail:
+                self._ln(s_a, "dec_norm_state", out32=s_b)
             new_state = s_b
             self._ln(a, "dec_norm", out16=dn16, out32=dn32)
             dn16v, dn32v = dn16.view(Wn, N + 1, D), dn32.view(Wn, N + 1, D)
@@ -621,8 +627,9 @@ class Cut3rModel:
                 tok3_32[:, i].copy_(dn32v[:, 1:])
             pose_tok[:, i].copy_(dn32v[:, 0])
             pose_tok16[:, i].copy_(dn16v[:, 0])
-            self._mem_update(mem[cm], g16, dn32v[:, 0], mem[cm ^ 1], Wn)
-            cm ^= 1
+            if not dead_tail:
+                self._mem_update(mem[cm], g16, dn32v[:, 0], mem[cm ^ 1], Wn)
+                cm ^= 1
             if head_fork:
                 # fork: this view's DPT head (batch = the Wn windows) runs beside the decoder of the next view
                 cur = torch.cuda.current_stream()
