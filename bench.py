@@ -115,17 +115,20 @@ def main():
     emu = int(os.environ.get("CUT3R_EMULATE_WORLD", "0"))     # debug: rank 0 of an `emu`-GPU job on ONE GPU (replay load only)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CUT3R_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = 0                 # functional run: all ranks share GPU 0
     dist_on = world > 1 or os.environ.get("CUT3R_FORCE_DIST") == "1"     # the env flag rehearses the RCCL path with one rank
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if dist_on:
         import torch.distributed as dist
+        backend = os.environ.get("CUT3R_DIST_BACKEND", "nccl")       # "gloo": functional multi-rank run with every rank on ONE GPU
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29577")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+            dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": torch.device(dev)} if backend == "nccl" else {}))
         else:
-            dist.init_process_group("nccl", device_id=torch.device(dev))
+            dist.init_process_group(backend, **({"device_id": torch.device(dev)} if backend == "nccl" else {}))
 
     from cut3r_slam_amd.config import production_config, tiny_config
     from cut3r_slam_amd.model import Cut3rModel
@@ -242,6 +245,13 @@ def main():
         cpu_base = cpu_baseline(cfg, sd, frames[:2].cpu(), frames_per_step)
         log("cpu baseline done")
 
+    dump = os.environ.get("CUT3R_DUMP_STATE")
+    if dump:                               # tests: the replicated result of every rank
+        import numpy as np
+        k = slam.tracker.t1
+        ii, jj, age = slam.graph.edges_numpy()
+        np.savez(f"{dump}.rank{rank}.npz", pose=slam.keyframes.pose[:k].numpy(), depth_sum=slam.keyframes.depth[:k].double().sum(dim=(1, 2)).cpu().numpy(),
+                 w2c=slam.keyframes.w2c[:k].cpu().numpy(), ii=ii, jj=jj, k=k)
     if rank == 0:
         out = {
             "metric": "frames/sec (ViT pointmap + covisibility-graph tracking step) on 640x480" + (f" [DEBUG: rank 0 of an emulated {emu}-GPU job]" if emu > 1 else ""), "value": round(value, 2),

@@ -43,12 +43,12 @@ def all_gather_outputs(outs: Sequence[torch.Tensor], world: int, force_collectiv
     res = []
     for t in outs:
         t = t.contiguous()
-        if t.is_cuda:
+        if t.is_cuda and dist.get_backend() == "nccl":
             buf = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
             dist.all_gather_into_tensor(buf.view(-1), t.view(-1))       # one RCCL all-gather per tensor
         else:
             parts = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(parts, t)                                   # gloo (CPU tests)
+            dist.all_gather(parts, t)                                   # gloo (CPU tests; functional multi-rank runs on one GPU)
             buf = torch.stack(parts, 0)
         res.append(buf.reshape((world * t.shape[0],) + tuple(t.shape[1:])))
     return res
