@@ -93,3 +93,26 @@ def test_demo_config_loader_inherits_and_cli_defaults(tmp_path):
     cfg = demo.load_config(str(tmp_path / "child.yaml"))
     assert cfg["Tracking"]["motion_filter"] == {"thresh": 0.9, "skip_blur": False}
     assert cfg["Tracking"]["frontend"]["frontend_nms"] == 1
+
+
+def test_ate_recovers_a_known_similarity_and_noise_level(tmp_path):
+    from scipy.spatial.transform import Rotation
+    from cut3r_slam_amd import eval_ate as E
+    rng = np.random.default_rng(3)
+    n = 200
+    stamps = np.arange(n) * 0.1
+    gt_p = np.cumsum(rng.normal(size=(n, 3)) * 0.05, axis=0)
+    R = Rotation.from_rotvec([0.3, -0.8, 0.5]).as_matrix()
+    s, t = 2.7, np.array([1.0, -2.0, 0.5])
+    noise = rng.normal(size=(n, 3)) * 0.01
+    est_p = ((gt_p - t) @ R) / s + noise                      # gt = s R est + t up to noise
+    quat = np.tile([0, 0, 0, 1.0], (n, 1))
+    gt = np.concatenate([stamps[:, None], gt_p, quat], 1)
+    est = np.concatenate([stamps[:, None] + 0.002, est_p, quat], 1)[::2]     # every other frame, slightly shifted stamps
+    (tmp_path / "gt.txt").write_text("# tum\n" + "\n".join(" ".join(f"{v:.9f}" for v in r) for r in gt))
+    (tmp_path / "est.txt").write_text("\n".join(" ".join(f"{v:.9f}" for v in r) for r in est))
+    res = E.ate_rmse(E.load_tum(str(tmp_path / "est.txt")), E.load_tum(str(tmp_path / "gt.txt")))
+    assert res["n"] == n // 2 and abs(res["scale"] - s) < 0.02
+    assert 0.6 * s * 0.01 * np.sqrt(3) < res["rmse"] < 1.2 * s * 0.01 * np.sqrt(3)      # residual = scaled noise
+    exact = E.ate_rmse(np.concatenate([stamps[:, None], ((gt_p - t) @ R) / s, quat], 1), gt)
+    assert exact["rmse"] < 1e-9
