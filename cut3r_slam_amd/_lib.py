@@ -49,6 +49,7 @@ SIGNATURES = {
     "cut3r_im2col_patch": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "cut3r_cast_f32_f16": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "cut3r_colmean": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "cut3r_colmean_batched": [c_void_p, c_int, c_ll, c_int, c_int, c_int, c_void_p, c_ll, c_void_p],
     "cut3r_upsample2x_nhwc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "cut3r_dpt_final": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "cut3r_postprocess_pts": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],

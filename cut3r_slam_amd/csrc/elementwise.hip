@@ -222,8 +222,11 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, 
 
 // column mean: each block owns 64 columns; its 4 waves split the rows (stride 4) with 4 independent accumulators per
 // thread for memory-level parallelism; partials are combined through LDS in fixed order (deterministic).
-__global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ x, int ldx, int M, int C, float* __restrict__ y) {
+__global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ x, int ldx, int M, int C, float* __restrict__ y,
+                                                      long long sx, long long sy) {
     __shared__ float part[16][64];
+    x += (size_t)blockIdx.y * sx;          // blockIdx.y: independent matrices (one per tracking window)
+    y += (size_t)blockIdx.y * sy;
     const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;      // 4 row groups per block
     const int c = blockIdx.x * 64 + col;
     // 4 independent accumulators per thread (ILP), rows strided by 16
@@ -532,7 +535,14 @@ extern "C" int cut3r_cast_f32_f16(const float* x, int ldx, void* y, int ldy, int
 
 extern "C" int cut3r_colmean(const float* x, int ldx, int M, int C, float* y, void* stream) {
     if (!x || !y || M <= 0 || C <= 0) return CUT3R_ERR_ARG;
-    hipLaunchKernelGGL(colmean_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, y);
+    hipLaunchKernelGGL(colmean_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, y, 0LL, 0LL);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_colmean_batched(const float* x, int B, long long stride_x, int ldx, int M, int C, float* y, long long stride_y,
+                                     void* stream) {
+    if (!x || !y || B <= 0 || B > 65535 || M <= 0 || C <= 0) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(colmean_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, y, stride_x, stride_y);
     return cut3r_check_launch();
 }
 

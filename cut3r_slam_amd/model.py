@@ -582,8 +582,7 @@ class Cut3rModel:
             head_pts = torch.empty((Wn * V, H, W, 3), dtype=F32, device=dev)
             head_conf = torch.empty((Wn * V, H, W), dtype=F32, device=dev)
         for i in range(V):
-            for w in range(Wn):
-                ops.colmean(feat[w, i], g32[w])
+            ops.colmean_batched(feat[:, i], g32)                 # global feature of view i, every window, one launch
             ops.cast_f16(g32, g16)
             a, b = im[0], im[1]
             a3 = a.view(Wn, N + 1, D)
@@ -613,9 +612,7 @@ class Cut3rModel:
                 a, b = b, a
                 if l + 1 == h1 or l + 1 == h2:
                     tk = tok1 if l + 1 == h1 else tok2
-                    av = a.view(Wn, N + 1, D)
-                    for w in range(Wn):
-                        ops.cast_f16(av[w, 1:], tk[w, i])
+                    tk[:, i].copy_(a.view(Wn, N + 1, D)[:, 1:])      # fp32 -> fp16 (round to nearest even), one strided copy
             # final norms (model.py:694-697): new state = dec_norm_state(state), img = dec_norm(img)
             if not dead_tail:
                 self._ln(s_a, "dec_norm_state", out32=s_b)

@@ -307,6 +307,17 @@ def colmean(x, out):
     return out
 
 
+def colmean_batched(x, out):
+    """x fp32 [B,M,C] (any batch / row stride, unit inner stride) -> out fp32 [B,C]: per-matrix column means, one launch"""
+    _cuda(x, out)
+    _req(x.dtype == F32 and x.dim() == 3 and x.stride(2) == 1 and out.dtype == F32 and out.shape == (x.shape[0], x.shape[2]) and out.stride(1) == 1,
+         "colmean_batched")
+    lib = _lib.load()
+    check(lib.cut3r_colmean_batched(_p(x), x.shape[0], x.stride(0), x.stride(1), x.shape[1], x.shape[2], _p(out), out.stride(0), _stream()),
+          "cut3r_colmean_batched")
+    return out
+
+
 def upsample2x(x, out):
     _cuda(x, out)
     B, H, W, Cc = x.shape

@@ -100,6 +100,8 @@ int cut3r_im2col_patch(const void* img, int u8, int B, int C, int H, int W, int 
 int cut3r_cast_f32_f16(const float* x, int ldx, void* y, int ldy, int M, int C, void* stream);
 /* column mean over rows: y[c] = mean_m x[m,c]  (model.py:732 `_get_img_level_feat`) ; x fp32 [M,C] */
 int cut3r_colmean(const float* x, int ldx, int M, int C, float* y, void* stream);
+/* B independent matrices (element strides stride_x / stride_y between them) in one launch; same summation order */
+int cut3r_colmean_batched(const float* x, int B, long long stride_x, int ldx, int M, int C, float* y, long long stride_y, void* stream);
 
 /* ---- DPT head helpers (NHWC fp16 activations) ------------------------------------------------------------------ */
 /* bilinear x2 upsample, align_corners=True (dpt_block.py:215-221, :262-268): in [B,H,W,C] -> out [B,2H,2W,C] */
