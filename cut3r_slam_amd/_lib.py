@@ -39,6 +39,8 @@ SIGNATURES = {
                         c_void_p],
     "cut3r_layernorm": [c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                         c_void_p, c_void_p, c_void_p],
+    "cut3r_layernorm_dual": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int,
+                             c_int, c_void_p],
     "cut3r_gemm_f16": [C.POINTER(GemmDesc), c_void_p],
     "cut3r_gemm_tile_for": [C.POINTER(GemmDesc)],
     "cut3r_rope2d_table": [c_void_p, c_int, c_int, c_float, c_float, c_void_p],

@@ -76,6 +76,7 @@ class Cut3rModel:
         # the state-side and image-side decoder blocks of a layer are independent (both read the previous layer's
         # pair, model.py:669-692): issue them on two streams so the captured graph has two parallel branches
         self.dual_stream = _os.environ.get("CUT3R_DUAL_STREAM", "1") != "0"
+        self.dual_ln = _os.environ.get("CUT3R_DUAL_LN", "1") != "0"            # shared-statistics LayerNorm of the decoder inputs
         self.fused_rope = _os.environ.get("CUT3R_FUSED_ROPE", "1") != "0"      # RoPE in the q/k projection epilogue (D = 64)
         # DPT head of view i (all windows) on a third stream while the recurrent decoder works on view i+1: the decoder's
         # mid-size kernels leave matrix and memory pipes idle that the head's large convolutions can use
@@ -350,9 +351,10 @@ class Cut3rModel:
         return feat, pos, im_shape
 
     # ------------------------------------------------------------------ decoder block
-    def _dec_block(self, tag, p, x, y, xpos, ypos, heads, out, B=1):
+    def _dec_block(self, tag, p, x, y, xpos, ypos, heads, out, B=1, pre_ln=False):
         """x fp32 [B*Nx,C], y fp32 [B*Ny,C] -> out fp32 [B*Nx,C]   (dust3r/blocks.py:292-297).  B = independent
-        sequences (tracking windows batched through the decoder)."""
+        sequences (tracking windows batched through the decoder).  pre_ln: norm1(x) and norm_y(y) are already in this
+        block's `.ln16` / `.y16` buffers (`_dual_norms`)."""
         Cc = x.shape[1]
         Nx, Ny = x.shape[0] // B, y.shape[0] // B
         D = Cc // heads
@@ -363,13 +365,15 @@ class Cut3rModel:
         k, v = kv4[:, :, 0], kv4[:, :, 1]
 
         def kv_branch():          # depends only on y (the other stream's previous layer): norm_y -> projk|projv -> RoPE(k)
-            self._ln(y, p + ".norm_y", out16=y16)
+            if not pre_ln:
+                self._ln(y, p + ".norm_y", out16=y16)
             fuse_k = Ny > 1 and self._fuse_rope(ypos, D, B * Ny)
             self._linear(y16, p + ".cross_attn.projkv", kv, skinny=(Ny == 1), rope=(ypos, Cc) if fuse_k else None)
             if ypos is not None and not fuse_k:
                 self._rope(k, ypos)
 
-        self._ln(x, p + ".norm1", out16=ln16)
+        if not pre_ln:
+            self._ln(x, p + ".norm1", out16=ln16)
         self._self_attn(tag, ln16, B, Nx, heads, xpos, p + ".attn", out, x)
         self._ln(out, p + ".norm2", out16=ln16)
         q = self.buf(tag + ".q", (B, Nx, heads, D), F16)
@@ -384,6 +388,17 @@ class Cut3rModel:
         self._ln(out, p + ".norm3", out16=ln16)
         self._mlp(tag, ln16, p + ".mlp", out, out, skinny=(Nx == 1))
         return out
+
+    def _dual_norms(self, l, a, s_a):
+        """The four input norms of decoder layer l in two launches: the image tokens `a` feed norm1 of the image block and
+        norm_y of the state block, the state tokens `s_a` feed norm1 of the state block and norm_y of the image block; each
+        tensor is read once and its row statistics are shared (identical outputs to four separate LayerNorms)."""
+        pi, ps = f"dec_blocks.{l}", f"dec_blocks_state.{l}"
+        Ci = a.shape[1]
+        ops.layernorm_dual(a, *self.w[pi + ".norm1"], self.buf("deci.ln16", (a.shape[0], Ci), F16),
+                           *self.w[ps + ".norm_y"], self.buf("decs.y16", (a.shape[0], Ci), F16), self.cfg.ln_eps)
+        ops.layernorm_dual(s_a, *self.w[ps + ".norm1"], self.buf("decs.ln16", (s_a.shape[0], Ci), F16),
+                           *self.w[pi + ".norm_y"], self.buf("deci.y16", (s_a.shape[0], Ci), F16), self.cfg.ln_eps)
 
     # ------------------------------------------------------------------ pose memory
     def _mem_inquire(self, gfeat16, mem, B=1):
@@ -598,16 +613,22 @@ class Cut3rModel:
             for l in range(Ld):
                 if dead_tail and l == Ld - 1:
                     self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn)
-                elif fork:
+                    s_a, s_b = s_b, s_a
+                    a, b = b, a
+                    continue
+                pre = self.dual_ln and D in (768, 1024, 1536)
+                if pre:
+                    self._dual_norms(l, a, s_a)
+                if fork:
                     cur = torch.cuda.current_stream()
                     self._side.wait_stream(cur)
                     with torch.cuda.stream(self._side):
-                        self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn)
-                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn)
+                        self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre)
+                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre)
                     cur.wait_stream(self._side)
                 else:
-                    self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn)
-                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn)
+                    self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre)
+                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre)
                 s_a, s_b = s_b, s_a
                 a, b = b, a
                 if l + 1 == h1 or l + 1 == h2:

@@ -109,6 +109,20 @@ def layernorm(x, gamma, beta, eps=1e-6, out16=None, out32=None, mod_scale=None, 
                               _p(mod_scale), _p(mod_shift), _stream()), "cut3r_layernorm")
 
 
+def layernorm_dual(x, g1, b1, out1, g2, b2, out2, eps=1e-6):
+    """out1 = LN(x; g1, b1), out2 = LN(x; g2, b2), both fp16, one pass over x (C in {768, 1024, 1536})"""
+    _cuda(x, g1, b1, out1, g2, b2, out2)
+    M, Cc = x.shape
+    _req(x.dtype == F32 and x.stride(1) == 1 and Cc in (768, 1024, 1536), "x fp32 [M,C], C in {768,1024,1536}")
+    for o in (out1, out2):
+        _req(o.dtype == F16 and o.shape == (M, Cc) and o.stride(1) == 1, "outputs fp16 [M,C]")
+    for t in (g1, b1, g2, b2):
+        _req(t.dtype == F32 and t.numel() == Cc and t.is_contiguous(), "gamma/beta fp32 [C]")
+    lib = _lib.load()
+    check(lib.cut3r_layernorm_dual(_p(x), x.stride(0), _p(g1), _p(b1), _p(out1), out1.stride(0), _p(g2), _p(b2), _p(out2), out2.stride(0),
+                                   float(eps), M, Cc, _stream()), "cut3r_layernorm_dual")
+
+
 # ------------------------------------------------------------------------------------------------ GEMM
 GEMM_STAGES = int(os.environ.get("CUT3R_GEMM_STAGES", "0"))     # tuning override (0 = kernel default)
 

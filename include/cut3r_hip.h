@@ -36,6 +36,10 @@ int cut3r_rope2d_qk(void* q, void* k, int dtype, const int64_t* positions, int B
 int cut3r_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int M, int C,
                     void* y16, int ld16, float* y32, int ld32, const float* mod_scale, const float* mod_shift,
                     void* stream);
+/* one tensor, two affine parameter sets, two fp16 outputs (shared row statistics): norm1 of one decoder block and norm_y of
+ * the other act on the same tokens (dust3r/blocks.py:292-297).  C in {768, 1024, 1536}. */
+int cut3r_layernorm_dual(const float* x, int ldx, const float* g1, const float* b1, void* y1, int ld1, const float* g2,
+                         const float* b2, void* y2, int ld2, float eps, int M, int C, void* stream);
 
 /* ---- GEMM family ---------------------------------------------------------------------------------------------
  * replaces nn.Linear / nn.Conv2d / nn.ConvTranspose2d(+bias)(+GELU|ReLU)(+residual) in the ViT and DPT stacks

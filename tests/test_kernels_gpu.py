@@ -265,6 +265,20 @@ def test_layernorm_and_adaln(M, C):
     _report("adaLN", o32, ref * (1 + sc) + sh, 5e-6)
 
 
+@pytest.mark.parametrize("M,C", [(769, 768), (130, 1024), (5, 1536)])
+def test_layernorm_dual_equals_two_layernorms(M, C):
+    g = torch.Generator().manual_seed(C + M)
+    x = (torch.randn(M, C, generator=g) * 3 + 0.5).to(DEV)
+    prm = [torch.randn(C, generator=g).to(DEV) for _ in range(4)]
+    ref1, ref2 = torch.empty(M, C, dtype=torch.float16, device=DEV), torch.empty(M, C, dtype=torch.float16, device=DEV)
+    ops.layernorm(x, prm[0], prm[1], 1e-6, ref1, None)
+    ops.layernorm(x, prm[2], prm[3], 1e-6, ref2, None)
+    o1, o2 = torch.zeros_like(ref1), torch.zeros_like(ref2)
+    ops.layernorm_dual(x, prm[0], prm[1], o1, prm[2], prm[3], o2, 1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, ref1) and torch.equal(o2, ref2)
+
+
 def test_im2col_cast_colmean_upsample():
     g = torch.Generator().manual_seed(5)
     img = torch.randn(2, 3, 32, 48, generator=g)
