@@ -28,6 +28,7 @@ class GemmDesc(C.Structure):
         ("shuf", c_int), ("shuf_cout", c_int), ("shuf_Hin", c_int), ("shuf_Win", c_int),
         ("tile", c_int), ("stages", c_int),
         ("rope_pos", c_void_p), ("rope_table", c_void_p), ("rope_cols", c_int), ("rope_pmin", c_int), ("rope_npos", c_int),
+        ("rope_d", c_int),
     ]
 
 
@@ -43,7 +44,7 @@ SIGNATURES = {
                              c_int, c_void_p],
     "cut3r_gemm_f16": [C.POINTER(GemmDesc), c_void_p],
     "cut3r_gemm_tile_for": [C.POINTER(GemmDesc)],
-    "cut3r_rope2d_table": [c_void_p, c_int, c_int, c_float, c_float, c_void_p],
+    "cut3r_rope2d_table": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p],
     "cut3r_gemv_f16w": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                         c_void_p, c_int, c_int, c_void_p],
     "cut3r_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

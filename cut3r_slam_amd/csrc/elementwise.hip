@@ -58,15 +58,15 @@ __global__ __launch_bounds__(256) void rope2d_kernel(T* __restrict__ tok, T* __r
     }
 }
 
-// cos / sin of every (position, frequency) pair of a head dimension of 64, by the expressions of rope2d_kernel
-__global__ void rope2d_table_kernel(float* __restrict__ table, int pmin, int npos, float base, float fwd) {
+// cos / sin of every (position, frequency) pair for a quarter head dimension Q, by the expressions of rope2d_kernel
+__global__ void rope2d_table_kernel(float* __restrict__ table, int pmin, int npos, int Q, float base, float fwd) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npos * 16) return;
-    const int p = i >> 4, q = i & 15;
-    const float inv = fwd / powf(base, (float)q / 16.0f);
+    if (i >= npos * Q) return;
+    const int p = i / Q, q = i - p * Q;
+    const float inv = fwd / powf(base, (float)q / (float)Q);
     const float fr = (float)(long long)(pmin + p) * inv;
     table[i] = cosf(fr);
-    table[npos * 16 + i] = sinf(fr);
+    table[npos * Q + i] = sinf(fr);
 }
 
 // ------------------------------------------------------------------------------------------------- LayerNorm
@@ -525,9 +525,9 @@ static int launch_rope(void* tokens, void* tokens2, int dtype, const int64_t* po
     return cut3r_check_launch();
 }
 
-extern "C" int cut3r_rope2d_table(float* table, int pmin, int npos, float base, float fwd, void* stream) {
-    if (!table || npos < 1) return CUT3R_ERR_ARG;
-    hipLaunchKernelGGL(rope2d_table_kernel, dim3((npos * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, pmin, npos, base, fwd);
+extern "C" int cut3r_rope2d_table(float* table, int pmin, int npos, int Q, float base, float fwd, void* stream) {
+    if (!table || npos < 1 || Q < 1 || Q > 64) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(rope2d_table_kernel, dim3((npos * Q + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, pmin, npos, Q, base, fwd);
     return cut3r_check_launch();
 }
 

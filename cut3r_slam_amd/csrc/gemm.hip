@@ -36,8 +36,8 @@ struct GemmArgs {
     int shuf, shuf_cout, shuf_Hin, shuf_Win;
     int swz;          // 1: 1-D grid with the XCD-aware tile rasterisation
     int prio;         // 1: s_setprio(1) around the MFMA cluster
-    // fused 2-D RoPE (head dimension 64) on output columns < rope_cols
-    const long long* rope_pos; const float* rope_table; int rope_cols, rope_pmin, rope_npos;
+    // fused 2-D RoPE (head dimension rope_d = 64 or 48) on output columns < rope_cols
+    const long long* rope_pos; const float* rope_table; int rope_cols, rope_pmin, rope_npos, rope_d;
 };
 
 DEVINL half8_t relu8(half8_t v) {
@@ -103,22 +103,26 @@ DEVINL void fused_store4(const GemmArgs& g, int z, const float* bias, int gm, in
     }
 }
 
-// Fused 2-D RoPE of 4 consecutive output columns gn..gn+3 (< rope_cols) of row gm, head dimension 64: own / partner are
-// the accumulators of these columns and of the columns 16 further (lower half of a 32-wide (y|x) block) or 16 back (upper
-// half), read from the epilogue's LDS staging.  Same arithmetic as rope2d_kernel on the fp16-rounded projection.
-DEVINL void rope_store4(const GemmArgs& g, int z, const float* bias, int gm, int gn, f32x4 own, f32x4 partner) {
-    const int hl = gn & 63, X = hl >> 5, within = hl & 31;
-    const bool lower = within < 16;
-    const int j = within & 15;
-    const int pn = lower ? gn + 16 : gn - 16;
+// Fused 2-D RoPE of 4 consecutive output columns gn..gn+3 (< rope_cols) of row gm, head dimension D = 64 or 48 (quarter
+// Q = D/4): a head is [y-block | x-block] of D/2 columns, inside a block column j < Q pairs with column j + Q.  `cs_row` is
+// this row of the epilogue's LDS staging (raw accumulators), c4 the tile-local column of gn; the partner values come from
+// c4 +- Q (tiles start on head boundaries).  Same arithmetic as rope2d_kernel on the fp16-rounded projection.
+DEVINL void rope_store4(const GemmArgs& g, int z, const float* bias, int gm, int gn, const float* cs_row, int c4) {
+    const int D = g.rope_d, Q = D >> 2, half = D >> 1;
+    const int hl = gn % D, X = hl / half, within = hl - X * half;
+    const bool lower = within < Q;
+    const int j = lower ? within : within - Q;
+    const int po = lower ? Q : -Q;
+    f32x4 own = *reinterpret_cast<const f32x4*>(cs_row + c4);
+    f32x4 partner = *reinterpret_cast<const f32x4*>(cs_row + c4 + po);
     if (bias) {
         own += *reinterpret_cast<const f32x4*>(bias + gn);
-        partner += *reinterpret_cast<const f32x4*>(bias + pn);
+        partner += *reinterpret_cast<const f32x4*>(bias + gn + po);
     }
     long long pv = g.rope_pos[(size_t)gm * 2 + X] - g.rope_pmin;
     pv = pv < 0 ? 0 : (pv >= g.rope_npos ? g.rope_npos - 1 : pv);
-    const float* ct = g.rope_table + (size_t)pv * 16 + j;
-    const float* st = ct + (size_t)g.rope_npos * 16;
+    const float* ct = g.rope_table + (size_t)pv * Q + j;
+    const float* st = ct + (size_t)g.rope_npos * Q;
     half4_t o;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -325,12 +329,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
                     if (EPI_PASSES == 1 || (r >= 0 && r < EPI_ROWS)) cs[r * CPAD + c] = acc[i][j][e];
                 }
         __syncthreads();
-        if (gn < N) {
+        if (gn < N && tid < RPP * TPR) {          // (TPR need not divide the block: 128x192 has 48 threads per row)
             for (int r = tid / TPR; r < EPI_ROWS; r += RPP) {
                 const int gm = m0 + p * EPI_ROWS + r;
                 if (gm >= M) break;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
-                if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, v, *reinterpret_cast<const f32x4*>(cs + r * CPAD + (((gn & 31) < 16) ? c4 + 16 : c4 - 16)));
+                if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, cs + r * CPAD, c4);
                 else fused_store4(g, z, bias, gm, gn, v);
             }
         }
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) {
                 const int gm = m0 + wr * 128 + mp * 32 + rr;
                 if (gm < M) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec);
-                    if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, v, *reinterpret_cast<const f32x4*>(cs + rr * CP + (((gn & 31) < 16) ? ec + 16 : ec - 16)));
+                    if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, cs + rr * CP, ec);
                     else fused_store4(g, z, bias, gm, gn, v);
                 }
             }
@@ -680,6 +684,7 @@ static inline int batch_of(const cut3r_gemm_desc* d) { return d->batch > 0 ? d->
 extern "C" int cut3r_gemm_tile_for(const cut3r_gemm_desc* d) {
     if (!d) return 0;
     if (d->tile != 0) return d->tile;
+    if (d->rope_pos && d->rope_cols && d->rope_d == 48) return 128192;      // the only tile whose width is a multiple of 48
     const int batch = d->batch > 0 ? d->batch : 1;
     const long long big_blocks = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
     // measured (tools/bench_gemm256.py, tools/bench_gemm.py): the 256^2 ping-pong kernel wins once its grid fills the
@@ -724,11 +729,15 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     g.prio = (d->stages == 12) ? 1 : 0;
     g.rope_pos = (const long long*)d->rope_pos; g.rope_table = d->rope_table;
     g.rope_cols = d->rope_pos ? d->rope_cols : 0; g.rope_pmin = d->rope_pmin; g.rope_npos = d->rope_npos;
+    g.rope_d = d->rope_d ? d->rope_d : 64;
     if (g.rope_cols) {
-        // whole heads of 64 inside the N range and inside every tile (tile widths are multiples of 64), fp16 output only
-        if (!d->rope_table || d->rope_npos < 1 || (g.rope_cols & 63) || g.rope_cols > d->N || !d->out_f16 || d->act || d->res1 || d->res2 ||
-            d->shuf || d->conv_k == 3 || (d->N & 63) || batch_of(d) != 1)
+        // whole heads inside the N range and inside every tile (tile widths 64/128/256 hold 64-wide heads, 192 holds both
+        // 64- and 48-wide heads), fp16 output only
+        if (!d->rope_table || d->rope_npos < 1 || (g.rope_d != 64 && g.rope_d != 48) || (g.rope_cols % g.rope_d) || g.rope_cols > d->N ||
+            !d->out_f16 || d->act || d->res1 || d->res2 || d->shuf || d->conv_k == 3 || (d->N % g.rope_d) || batch_of(d) != 1)
             return CUT3R_ERR_ARG;
+        if (g.rope_d == 48 && cut3r_gemm_tile_for(d) != 128192) return CUT3R_ERR_ARG;     // 48-wide heads need the 192-column tile
+        if (g.rope_d == 64 && (d->N & 63)) return CUT3R_ERR_ARG;
     }
     const int batch = d->batch > 0 ? d->batch : 1;
     hipStream_t s = (hipStream_t)stream;
@@ -760,6 +769,10 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         else if (d->stages == 10) hipLaunchKernelGGL((gemm_kernel<128, 128, 3, 4, 2>), grid, dim3(512), 0, s, g);
         else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<128, 128, 2>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
+    } else if (tile == 128192) {       // 128 x 192 (four 48-wide or three 64-wide heads per tile), 8 waves (32 x 96 per wave), 80 KB LDS
+        dim3 grid(((d->N + 191) / 192) * ((d->M + 127) / 128), 1, batch);
+        g.swz = 1;
+        hipLaunchKernelGGL((gemm_kernel<128, 192, 2, 4, 2>), grid, dim3(512), 0, s, g);
     } else if (tile == 192128) {       // 192 x 128, 8 waves (48 x 64 per wave), 80 KB LDS: two workgroups per CU
         dim3 grid(((d->N + 127) / 128) * ((d->M + 191) / 192), 1, batch);
         g.swz = 1;

@@ -77,7 +77,10 @@ class Cut3rModel:
         # pair, model.py:669-692): issue them on two streams so the captured graph has two parallel branches
         self.dual_stream = _os.environ.get("CUT3R_DUAL_STREAM", "1") != "0"
         self.dual_ln = _os.environ.get("CUT3R_DUAL_LN", "1") != "0"            # shared-statistics LayerNorm of the decoder inputs
-        self.fused_rope = _os.environ.get("CUT3R_FUSED_ROPE", "1") != "0"      # RoPE in the q/k projection epilogue (D = 64)
+        # RoPE in the q/k projection epilogue: 0 off (default), 1 heads of 64, 2 also heads of 48.  Bit-identical to the
+        # stand-alone kernel; +1 % when the decoder ran alone, -2.5 % now that encoder / head kernels fill its gaps (the
+        # heavier epilogue lengthens every projection on the critical path, the small RoPE kernel overlaps for free)
+        self.fused_rope = int(_os.environ.get("CUT3R_FUSED_ROPE", "0"))      # RoPE in the q/k projection epilogue (D = 64)
         # DPT head of view i (all windows) on a third stream while the recurrent decoder works on view i+1: the decoder's
         # mid-size kernels leave matrix and memory pipes idle that the head's large convolutions can use
         self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "1") != "0"
@@ -232,12 +235,13 @@ class Cut3rModel:
         rope = (positions [B,N,2], cols): RoPE of the first `cols` output columns fused into the GEMM epilogue."""
         L = self.w[name]
         if rope is not None:
-            rope = (rope[0], rope[1], self.cfg.rope_freq)
+            rope = (rope[0], rope[1], self.cfg.rope_freq, rope[2])
         return ops.linear(x16, L.w, out, L.b, act, res1, res2, tile=16 if skinny else 0, rope=rope)
 
     def _fuse_rope(self, pos, D, rows):
         """the GEMM-fused RoPE covers head dimension 64 with one position row per GEMM row"""
-        return self.fused_rope and pos is not None and D == 64 and pos.is_contiguous() and pos.numel() == 2 * rows
+        dims = (64, 48) if self.fused_rope == 2 else (64,)
+        return self.fused_rope and pos is not None and D in dims and pos.is_contiguous() and pos.numel() == 2 * rows
 
     def _ln(self, x, name, out16=None, out32=None, mod=None):
         g, b = self.w[name]
@@ -253,7 +257,7 @@ class Cut3rModel:
         sk = N == 1
         qkv = self.buf(tag + ".qkv", (B * N, 3 * Cc), F16)
         fuse = (not sk) and self._fuse_rope(pos, D, B * N)
-        self._linear(x_ln16, p + ".qkv", qkv, skinny=sk, rope=(pos, 2 * Cc) if fuse else None)
+        self._linear(x_ln16, p + ".qkv", qkv, skinny=sk, rope=(pos, 2 * Cc, D) if fuse else None)
         v5 = qkv.view(B, N, 3, heads, D)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
         if pos is not None and not fuse:
@@ -368,7 +372,7 @@ class Cut3rModel:
             if not pre_ln:
                 self._ln(y, p + ".norm_y", out16=y16)
             fuse_k = Ny > 1 and self._fuse_rope(ypos, D, B * Ny)
-            self._linear(y16, p + ".cross_attn.projkv", kv, skinny=(Ny == 1), rope=(ypos, Cc) if fuse_k else None)
+            self._linear(y16, p + ".cross_attn.projkv", kv, skinny=(Ny == 1), rope=(ypos, Cc, D) if fuse_k else None)
             if ypos is not None and not fuse_k:
                 self._rope(k, ypos)
 
@@ -378,7 +382,7 @@ class Cut3rModel:
         self._ln(out, p + ".norm2", out16=ln16)
         q = self.buf(tag + ".q", (B, Nx, heads, D), F16)
         fuse_q = Nx > 1 and self._fuse_rope(xpos, D, B * Nx)
-        self._linear(ln16, p + ".cross_attn.projq", q.view(B * Nx, Cc), skinny=(Nx == 1), rope=(xpos, Cc) if fuse_q else None)
+        self._linear(ln16, p + ".cross_attn.projq", q.view(B * Nx, Cc), skinny=(Nx == 1), rope=(xpos, Cc, D) if fuse_q else None)
         if xpos is not None and not fuse_q:
             self._rope(q, xpos)
         kv_branch()      # (forking this onto its own capture stream was tried: nested forks crash hipGraph capture_end on ROCm 7.2)

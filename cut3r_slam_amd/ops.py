@@ -147,21 +147,22 @@ _ROPE_TABLES = {}
 ROPE_PMIN, ROPE_NPOS = -1, 258        # positions -1 (pose token) .. 256
 
 
-def rope_table(device, base, fwd=1.0):
-    """cos|sin table [2, ROPE_NPOS, 16] of the head-dimension-64 RoPE angles (cut3r_rope2d_table), cached per device"""
-    key = (str(device), float(base), float(fwd))
+def rope_table(device, base, fwd=1.0, head_dim=64):
+    """cos|sin table [2, ROPE_NPOS, head_dim/4] of the RoPE angles (cut3r_rope2d_table), cached per device"""
+    key = (str(device), float(base), float(fwd), int(head_dim))
     t = _ROPE_TABLES.get(key)
     if t is None:
-        t = torch.empty(2, ROPE_NPOS, 16, dtype=F32, device=device)
+        t = torch.empty(2, ROPE_NPOS, head_dim // 4, dtype=F32, device=device)
         lib = _lib.load()
-        check(lib.cut3r_rope2d_table(_p(t), ROPE_PMIN, ROPE_NPOS, float(base), float(fwd), _stream()), "cut3r_rope2d_table")
+        check(lib.cut3r_rope2d_table(_p(t), ROPE_PMIN, ROPE_NPOS, head_dim // 4, float(base), float(fwd), _stream()), "cut3r_rope2d_table")
         _ROPE_TABLES[key] = t
     return t
 
 
 def linear(A, W, out, bias=None, act=0, res1=None, res2=None, tile=0, rope=None):
     """out[M,N] = act(A[M,K] @ W[N,K]^T + bias) (+res1)(+res2).  A,W fp16; out fp16|fp32 (any row stride).
-    rope = (positions int64 [M,2] contiguous, cols, base): 2-D RoPE (head dimension 64) fused on the first `cols` columns."""
+    rope = (positions int64 [M,2] contiguous, cols, base[, head_dim = 64 | 48]): 2-D RoPE fused on the first `cols` columns
+    (48-wide heads use the 128 x 192 tile)."""
     _cuda(A, W, out, bias, res1, res2)
     _req(A.dtype == F16 and W.dtype == F16 and A.dim() == 2 and W.dim() == 2, "A,W must be 2-D fp16")
     M, K = A.shape
@@ -175,10 +176,11 @@ def linear(A, W, out, bias=None, act=0, res1=None, res2=None, tile=0, rope=None)
         if r is not None:
             _req(r.shape == (M, N), "residual shape")
     if rope is not None:
-        pos, cols, base = rope
+        pos, cols, base = rope[:3]
+        hd = rope[3] if len(rope) > 3 else 64
         _req(pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() == 2 * M and pos.is_cuda, "rope positions int64 [M,2]")
-        _req(out.dtype == F16 and act == 0 and res1 is None and res2 is None and cols % 64 == 0 and 0 < cols <= N and N % 64 == 0 and tile != 16,
-             "fused rope: fp16 output, no activation / residual, whole heads of 64")
+        _req(out.dtype == F16 and act == 0 and res1 is None and res2 is None and hd in (48, 64) and cols % hd == 0 and 0 < cols <= N
+             and N % hd == 0 and tile != 16, "fused rope: fp16 output, no activation / residual, whole heads of 64 or 48")
     if tile == 16 and M > 64:           # skinny kernel: 64 rows per launch (row results do not depend on the chunking)
         for m0 in range(0, M, 64):
             sl = slice(m0, min(M, m0 + 64))
@@ -188,8 +190,9 @@ def linear(A, W, out, bias=None, act=0, res1=None, res2=None, tile=0, rope=None)
     _fill_common(d, A, W, out, bias, res1, res2, act, tile)
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, A.stride(0), W.stride(0), out.stride(0)
     if rope is not None:
-        tab = rope_table(out.device, base)
+        tab = rope_table(out.device, base, 1.0, hd)
         d.rope_pos, d.rope_table, d.rope_cols, d.rope_pmin, d.rope_npos = pos.data_ptr(), tab.data_ptr(), int(cols), ROPE_PMIN, ROPE_NPOS
+        d.rope_d = hd
     lib = _lib.load()
     check(lib.cut3r_gemm_f16(C.byref(d), _stream()), f"cut3r_gemm_f16 M={M} N={N} K={K}")
     return out

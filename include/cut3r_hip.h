@@ -62,7 +62,7 @@ typedef struct cut3r_gemm_desc {
     int relu_in;          /* apply ReLU to A on load (ResidualConvUnit pre-activation) */
     int shuf;             /* > 0: ConvTranspose(k == stride == shuf) scatter; N = shuf*shuf*shuf_cout, ldc = Cout */
     int shuf_cout, shuf_Hin, shuf_Win;
-    int tile;             /* 0 = auto (cut3r_gemm_tile_for), 16 (M <= 64 skinny), 64, 128, 192128 (192 x 128) or 256 */
+    int tile;             /* 0 = auto (cut3r_gemm_tile_for), 16 (M <= 64 skinny), 64, 128, 192128 (192 x 128), 128192 (128 x 192) or 256 */
     int stages;           /* 0 = default; LDS ring depth override (tuning): 2|3 for tile 128, 2|3|4 for tile 64 */
     /* fused 2-D RoPE on the first rope_cols output columns (head dimension 64 only; fp16 output, no activation/residual):
      * what curope.rope_2d does to q / k right after the projection (croco/models/blocks.py:126-127, dust3r/blocks.py
@@ -71,11 +71,12 @@ typedef struct cut3r_gemm_desc {
     const void* rope_pos;
     const float* rope_table;
     int rope_cols, rope_pmin, rope_npos;
+    int rope_d;           /* head dimension of the fused RoPE: 64 (default when 0) or 48 (forces the 128 x 192 tile) */
 } cut3r_gemm_desc;
 int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream);
-/* table[0][p][q] = cos((pmin+p) * fwd / base^(q/16)), table[1][p][q] = sin(...), q < 16, p < npos: the angles of
- * cut3r_rope2d for head dimension 64, evaluated by the same device functions (fp32 [2][npos][16]) */
-int cut3r_rope2d_table(float* table, int pmin, int npos, float base, float fwd, void* stream);
+/* table[0][p][q] = cos((pmin+p) * fwd / base^(q/Q)), table[1][p][q] = sin(...), q < Q = head_dim/4, p < npos: the angles
+ * of cut3r_rope2d, evaluated by the same device functions (fp32 [2][npos][Q]) */
+int cut3r_rope2d_table(float* table, int pmin, int npos, int Q, float base, float fwd, void* stream);
 /* the tile the launcher picks for this problem when desc->tile == 0: 256 (256x256x64 ping-pong kernel), 128 or 64.
  * tile 16 (M <= 64: skinny weight-streaming MFMA kernel) is never chosen automatically: its K-split changes the fp32
  * summation order, so callers request it for operands whose row count is the batch (one row per tracking window) and

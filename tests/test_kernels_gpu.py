@@ -46,6 +46,7 @@ def _report(name, got, ref, tol):
     (5, 12, 8, 256),
     # 192 x 128 tile (two-band epilogue): full tiles, ragged M / N / K
     (6152, 768, 768, 192128), (385, 260, 200, 192128), (191, 128, 64, 192128), (193, 132, 72, 192128),
+    (3076, 768, 768, 128192), (260, 388, 200, 128192), (129, 196, 72, 128192),
     # skinny M <= 64 kernel (pose memory / pose MLP rows): K split over 4 and 8 waves, 1/2/4 row blocks, ragged N and K
     (8, 1536, 1536, 16), (8, 1536, 6144, 16), (1, 4608, 1536, 16), (16, 6144, 1536, 16), (3, 20, 40, 16), (7, 3072, 768, 16), (12, 8, 3072, 16),
     (24, 1536, 6144, 16), (33, 1536, 1536, 16), (64, 768, 3072, 16), (50, 36, 72, 16), (150, 1536, 1536, 16)])
@@ -88,11 +89,14 @@ def test_gemm256_race_screen(M, N, K):
                 assert torch.equal(o, ref), f"rep {rep}: {(o != ref).sum().item()} elements differ, max {(o - ref).abs().max().item()}"
 
 
-@pytest.mark.parametrize("tile", [64, 128, 256, 192128])
-@pytest.mark.parametrize("M,N,cols", [(1538, 2304, 1536), (769, 768, 768), (1536, 1536, 768), (300, 128, 64)])
-def test_gemm_fused_rope_equals_gemm_then_rope_kernel(M, N, cols, tile):
-    """RoPE in the projection epilogue (head dimension 64) must reproduce the separate rope_2d kernel bit for bit:
-    q|k|v, q-only and k|v layouts, positions including the pose token's -1, ragged last row tile."""
+@pytest.mark.parametrize("M,N,cols,hd,tile", [
+    (1538, 2304, 1536, 64, 64), (1538, 2304, 1536, 64, 128), (1538, 2304, 1536, 64, 256), (1538, 2304, 1536, 64, 192128),
+    (769, 768, 768, 64, 128), (1536, 1536, 768, 64, 256), (300, 128, 64, 64, 64), (300, 192, 128, 64, 128192),
+    # 48-wide heads (state side): only the 128 x 192 tile holds whole heads; auto (0) must pick it
+    (1536, 2304, 1536, 48, 0), (768, 768, 768, 48, 128192), (1537, 1536, 768, 48, 0), (300, 192, 96, 48, 0), (70, 240, 240, 48, 0)])
+def test_gemm_fused_rope_equals_gemm_then_rope_kernel(M, N, cols, hd, tile):
+    """RoPE in the projection epilogue (head dimension 64 or 48) must reproduce the separate rope_2d kernel bit for bit:
+    q|k|v, q-only and k|v layouts, positions including the pose token's -1, ragged last row / column tiles."""
     K = 192
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(M, K, generator=g).half().to(DEV)
@@ -100,11 +104,11 @@ def test_gemm_fused_rope_equals_gemm_then_rope_kernel(M, N, cols, tile):
     b = torch.randn(N, generator=g).to(DEV)
     pos = torch.randint(-1, 33, (M, 2), generator=g, dtype=torch.int64).to(DEV)
     ref = torch.empty(M, N, dtype=torch.float16, device=DEV)
-    ops.linear(A, W, ref, b, 0, tile=tile)
-    heads = cols // 64
-    ops.rope_2d(ref.view(1, M, N // 64, 64)[:, :, :heads], pos.view(1, M, 2), 100.0, 1.0)
+    ops.linear(A, W, ref, b, 0, tile=tile if tile else 128)
+    heads = cols // hd
+    ops.rope_2d(ref.view(1, M, N // hd, hd)[:, :, :heads], pos.view(1, M, 2), 100.0, 1.0)
     out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
-    ops.linear(A, W, out, b, 0, tile=tile, rope=(pos, cols, 100.0))
+    ops.linear(A, W, out, b, 0, tile=tile, rope=(pos, cols, 100.0, hd))
     torch.cuda.synchronize()
     assert torch.equal(out, ref), f"{(out != ref).sum().item()} elements differ, max {(out.float() - ref.float()).abs().max().item()}"
     assert not torch.equal(out[:, :cols], (A.float() @ W.float().t() + b).half()[:, :cols])      # RoPE did something
