@@ -14,6 +14,7 @@
 //     writes) and consumed column-wise by the hardware transposing read ds_read_b64_tr_b16 (two per k-step), rows padded
 //     so that the 4-row x 16-column blocks of a 32-lane half fall on disjoint banks.
 //   * register prefetch of the next K/V tile overlaps the global loads with the MFMAs of the current tile.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/cut3r_hip.h"
 
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
 template <int D>
 int launch_attn(const AttnArgs& a, int B, int H, hipStream_t s) {
     const long long blocks128 = (long long)B * H * ((a.Nq + 127) / 128);
-    if (blocks128 >= 384 || D >= 128) {
+    static const long long nw4_min = [] { const char* e = getenv("CUT3R_ATTN_NW4_MIN"); return e ? atoll(e) : 384LL; }();
+    if (blocks128 >= nw4_min || D >= 128) {
         dim3 grid((a.Nq + 127) / 128, H, B);
         hipLaunchKernelGGL((attn_kernel<D, 4>), grid, dim3(256), 0, s, a);
     } else {
