@@ -128,7 +128,9 @@ class ShardedTracker:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         return counts
 
-    def _replay(self, pending):
+    def _replay(self, pending, defer=False):
+        """chain + store every window of `pending`; returns the deferred host-only decisions (multi-rank with defer) or None"""
+        fin = None
         ranges_all, gathered, ev = pending
         V = self.views
         tic = time.perf_counter()
@@ -159,9 +161,10 @@ class ShardedTracker:
                     # the O(#keyframes) overlap counting of a window runs on its owner only; one small all-reduce per step
                     mask = [self.rank * self.wb <= j < (self.rank + 1) * self.wb for j in range(len(ranges_all))]
                     exch = self._exchange_counts
-                self.slam.tracker.track_many(ranges_all, outs, count_mask=mask, exchange=exch)
+                fin = self.slam.tracker.track_many(ranges_all, outs, count_mask=mask, exchange=exch, defer_decisions=defer)
                 self.slam.tracker.t1 = ranges_all[-1][1]
         self.stats["replay_s"] += time.perf_counter() - tic
+        return fin
 
     def _append_range(self, frames, t, n_frames, kf_every, win, intr, first_t0):
         """register the keyframes among frames t..t+n_frames-1 (once: a look-ahead may already have done it)"""
@@ -226,13 +229,18 @@ class ShardedTracker:
             # 3. replay of the previous step's chaining + graph update (side stream) while the encoder runs.  It is
             #    issued BEFORE the decoder graph on purpose: that graph has parallel branches on several hardware queues and
             #    anything queued behind it on a shared queue waits for the whole branch (measured: ~40 ms per step)
+            fin = None
             if self._pending is not None:
-                self._replay(self._pending)
+                fin = self._replay(self._pending, defer=True)
                 self._pending = None
             # 4'. recurrent decoder + heads graph
             tic = time.perf_counter()
             outs = self._decode(feats)
             self.stats["issue_s"] += time.perf_counter() - tic
+            if fin is not None:      # multi-rank: the host-only graph decisions of the replayed step, now that the GPU has its work
+                tic = time.perf_counter()
+                fin()
+                self.stats["replay_s"] += time.perf_counter() - tic
         # 4. one exchange over xGMI (private copies when world == 1)
         tic = time.perf_counter()
         if self.emulate_gather:      # debug (bench CUT3R_EMULATE_WORLD): this rank's outputs stand in for every other rank's

@@ -159,7 +159,7 @@ class TrackFrontend:
         ev.record()
         return ev
 
-    def track_many(self, ranges, outputs, init=False, first_event=None, count_mask=None, exchange=None):
+    def track_many(self, ranges, outputs, init=False, first_event=None, count_mask=None, exchange=None, defer_decisions=False):
         """The sequential part of tracking for consecutive windows `ranges` = [(t0, t1), ...] with their network outputs
         [(pts [V,H,W,3], conf [V,H,W], pose_enc [V,7] device or host), ...]: log-depth scale + pose chaining
         (track_frontend.py:193-245), keyframe store update and covisibility-graph update (:246-261).
@@ -171,7 +171,9 @@ class TrackFrontend:
         Multi-GPU (`count_mask`, `exchange`): the O(#keyframes) overlap counting of a window is done only where
         count_mask[k] is true (by the rank that owns the window; every rank still chains and stores every window, so the
         stores stay replicated); `exchange(int32 tensor [n_windows, 6, 2, L])` then sums the owners' counts over the ranks
-        (one small all-reduce per call) and the decisions of all windows are taken afterwards, in order."""
+        (one small all-reduce per call) and the decisions of all windows are taken afterwards, in order.  With
+        `defer_decisions` that host-only last part is returned as a callable instead of being run, so the caller can launch
+        device work first."""
         kf, graph, ds = self.keyframes, self.graph, self.downsample_ratio
         deferred = [] if exchange is not None else None     # (t0, t1, groups, centres) per window, decisions after the exchange
         L = ((ranges[-1][1] + 63) // 64) * 64
@@ -274,13 +276,19 @@ class TrackFrontend:
             self._decide(*pending)
         if deferred is not None:
             total = exchange(all_counts).numpy()
-            for k, (t0, t1, groups, centres, npix) in enumerate(deferred):
-                done = {}
-                for (a, b) in groups:
-                    if t0 + b - 1 >= 3:
-                        for tk, cf, cb in graph.window_tickets(t0 + a, t0 + b, centres, total[k, a:b], npix, h * w):
-                            done[tk["idx"]] = (tk, cf.copy(), cb.copy())
-                self._decide(t0, t1, init, done)
+
+            def finish():
+                for k, (t0, t1, groups, centres, npix) in enumerate(deferred):
+                    done = {}
+                    for (a, b) in groups:
+                        if t0 + b - 1 >= 3:
+                            for tk, cf, cb in graph.window_tickets(t0 + a, t0 + b, centres, total[k, a:b], npix, h * w):
+                                done[tk["idx"]] = (tk, cf.copy(), cb.copy())
+                    self._decide(t0, t1, init, done)
+            if defer_decisions:
+                return finish
+            finish()
+        return None
 
     def track_batch(self, ranges):
         """several consecutive 6-keyframe windows: ONE batched decoder/head inference, then the reference's sequential
