@@ -58,6 +58,8 @@ SIGNATURES = {
     "cut3r_postprocess_pts": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "cut3r_postprocess_pose": [c_void_p, c_int, c_void_p, c_void_p],
     "cut3r_patch_overlap": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "cut3r_patch_overlap_chain": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, C.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p],
     "cut3r_overlap_fwd": [c_void_p, c_int, C.POINTER(c_float), c_float, c_void_p, c_int, c_float, c_float, c_float, c_float,
                           c_int, c_int, c_int, c_void_p, c_void_p],
     "cut3r_overlap_bwd": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_int, c_int,

@@ -305,6 +305,64 @@ __global__ __launch_bounds__(256) void count_gt_kernel(const unsigned int* __res
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
 }
 
+// ---- chained keyframe decisions (a whole look-ahead batch of candidates, no host round trip per candidate)
+// simmax with the row operand chosen ON THE DEVICE: set `*state` + 1 of the normalised feature sets (set 0 = the last keyframe
+// before the batch, set 1 + i = candidate i).
+__global__ __launch_bounds__(64) void simmax_chain_kernel(const float* __restrict__ sets, size_t set_stride, const int32_t* __restrict__ state,
+                                                          int cand, int Nv, int C, unsigned int* __restrict__ rowmax_bits) {
+    const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5;
+    const int rt = blockIdx.y, ct = blockIdx.x;
+    const int ra = min(rt * 32 + r, Nv - 1), rb = min(ct * 32 + r, Nv - 1);
+    const float* f0 = sets + (size_t)(state[0] + 1) * set_stride;
+    const float* f1 = sets + (size_t)(cand + 1) * set_stride;
+    const float* pa = f0 + (size_t)ra * C + 4 * hh;
+    const float* pb = f1 + (size_t)rb * C + 4 * hh;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    for (int j = 0; j < C; j += 8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pa + j);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pb + j);
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    }
+    const bool colok = (ct * 32 + r) < Nv;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        float v = colok ? acc[i] : 0.f;
+        v = fmaxf(v, 0.f);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (r == 0 && row < Nv) atomicMax(&rowmax_bits[row], __float_as_uint(v));
+    }
+}
+
+// one workgroup: count the rows above the similarity threshold, take the keyframe decision of candidate `cand` exactly as the
+// host does (ratio = fp32 count / fp32 rows, widened to double, compared with the double threshold: motion_filter.py:124 on
+// `matched.mean().item()`), advance the device-side "last keyframe" and clear the row maxima for the next candidate.
+__global__ __launch_bounds__(256) void chain_decide_kernel(unsigned int* __restrict__ rowmax_bits, int Nv, float thr_sim, double thr_ratio,
+                                                           int cand, int forced, int32_t* __restrict__ state, int32_t* __restrict__ counts,
+                                                           int32_t* __restrict__ decisions) {
+    __shared__ int part[4];
+    int c = 0;
+    for (int i = threadIdx.x; i < Nv; i += 256) {
+        c += __uint_as_float(rowmax_bits[i]) > thr_sim;
+        rowmax_bits[i] = 0u;
+    }
+    c = wave_sum_i(c);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = part[0] + part[1] + part[2] + part[3];
+        const float ratio = (float)total / (float)Nv;
+        const int take = forced || ((double)ratio < thr_ratio);
+        counts[cand] = total;
+        decisions[cand] = take;
+        if (take) state[0] = cand;
+    }
+}
+
 inline int grid_for(size_t total, int block = 256) {
     size_t g = (total + block - 1) / block;
     if (g > 8192) g = 8192;
@@ -421,5 +479,29 @@ extern "C" int cut3r_patch_overlap(const float* feat0, const float* feat1, int N
     const int T = (Nv + 31) / 32;
     hipLaunchKernelGGL(simmax_kernel, dim3(T, T), dim3(64), 0, s, n0, n1, Nv, C, rmax);
     hipLaunchKernelGGL(count_gt_kernel, dim3(grid_for((size_t)Nv)), dim3(256), 0, s, rmax, Nv, thr, count);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_patch_overlap_chain(const float* feat_last, const float* feats, int B, int N, int C, float thr_sim, double thr_ratio,
+                                         const int32_t* forced_host, void* ws, int32_t* state, int32_t* counts, int32_t* decisions,
+                                         void* stream) {
+    if (!feat_last || !feats || !ws || !state || !counts || !decisions || B < 1 || N < 2 || C <= 0 || (C & 7)) return CUT3R_ERR_ARG;
+    if (((uintptr_t)feat_last | (uintptr_t)feats | (uintptr_t)ws) & 15) return CUT3R_ERR_ARG;
+    const int Nv = N - 1;
+    hipStream_t s = (hipStream_t)stream;
+    float* sets = (float*)ws;                                  // [B+1][Nv][C] normalised rows 1..
+    const size_t set_stride = (size_t)Nv * C;
+    unsigned int* rmax = (unsigned int*)(sets + (size_t)(B + 1) * set_stride);
+    if (hipMemsetAsync(rmax, 0, sizeof(unsigned int) * Nv, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    if (hipMemsetAsync(state, 0xff, sizeof(int32_t), s) != hipSuccess) return CUT3R_ERR_LAUNCH;           // -1: the keyframe before the batch
+    hipLaunchKernelGGL(rownorm_kernel, dim3((Nv + 3) / 4), dim3(256), 0, s, feat_last, Nv, C, sets);
+    for (int i = 0; i < B; i++)
+        hipLaunchKernelGGL(rownorm_kernel, dim3((Nv + 3) / 4), dim3(256), 0, s, feats + (size_t)i * N * C, Nv, C, sets + (size_t)(i + 1) * set_stride);
+    const int T = (Nv + 31) / 32;
+    for (int i = 0; i < B; i++) {
+        const int forced = forced_host ? (forced_host[i] != 0) : 0;
+        if (!forced) hipLaunchKernelGGL(simmax_chain_kernel, dim3(T, T), dim3(64), 0, s, sets, set_stride, state, i, Nv, C, rmax);
+        hipLaunchKernelGGL(chain_decide_kernel, dim3(1), dim3(256), 0, s, rmax, Nv, thr_sim, thr_ratio, i, forced, state, counts, decisions);
+    }
     return cut3r_check_launch();
 }

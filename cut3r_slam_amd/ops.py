@@ -384,6 +384,23 @@ def patch_overlap_count(feat0, feat1, thr, ws, count):
     check(lib.cut3r_patch_overlap(_p(feat0), _p(feat1), N, Cc, float(thr), _p(ws), _p(count), _stream()), "cut3r_patch_overlap")
 
 
+def patch_overlap_chain(feat_last, feats, thr_sim, thr_ratio, forced, ws, state, counts, decisions):
+    """Keyframe decisions of B consecutive tested frames on the device (motion_filter.py:98-124 without a host round trip per
+    frame): feat_last [N,C], feats [B,N,C] fp32; forced: list of B bools (always-keyframe frames) or None;
+    state int32[1], counts / decisions int32[B] on the device."""
+    _cuda(feat_last, feats, ws, state, counts, decisions)
+    B, N, Cc = feats.shape
+    _req(feats.dtype == F32 and feat_last.dtype == F32 and feat_last.shape == (N, Cc) and feats.is_contiguous() and feat_last.is_contiguous(),
+         "features fp32 [B,N,C] / [N,C]")
+    _req(ws.dtype == F32 and ws.numel() >= (B + 1) * (N - 1) * Cc + (N - 1), "workspace of (B+1)*(N-1)*C + N-1 floats")
+    _req(state.dtype == torch.int32 and counts.dtype == torch.int32 and decisions.dtype == torch.int32 and counts.numel() >= B and decisions.numel() >= B,
+         "state / counts / decisions int32")
+    arr = (C.c_int32 * B)(*[1 if f else 0 for f in forced]) if forced is not None else None
+    lib = _lib.load()
+    check(lib.cut3r_patch_overlap_chain(_p(feat_last), _p(feats), B, N, Cc, float(thr_sim), float(thr_ratio), arr, _p(ws), _p(state), _p(counts),
+                                        _p(decisions), _stream()), "cut3r_patch_overlap_chain")
+
+
 def overlap_fwd(pm, w2c, K4, W, H, counts, P12=None, s_align=1.0, clamp_z=True):
     """counts[b] = #points of pm (optionally mapped p <- P*(s*p) first) that land inside camera b's W x H image."""
     _cuda(pm, w2c, counts)

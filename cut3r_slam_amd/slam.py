@@ -59,6 +59,36 @@ class Cut3rSlam:
                 self.freeze_counter += 1
         return viz_idx, submap_idx, lc_did
 
+    @torch.no_grad()
+    def run_buffered(self, frames_u8, intrinsics, t_start=0, lookahead=16, mark_tail=True, on_frame=None):
+        """Buffered-stream driver: the same per-frame `run()` sequence as demo_s.py:151-160 over frames_u8 [n,3,H,W] (time
+        stamps t_start..), but in overlap mode the next `lookahead` tested frames (every `skip`-th, plus the always-kept
+        second-last / last frame when mark_tail) go through the encoder as ONE batch and their keyframe decisions are taken
+        on the device (MotionFilter.prefetch) -- identical keyframes and features, latency lookahead*skip frames."""
+        n = frames_u8.shape[0]
+        f = self.filterx
+        overlap_mode = not (f.kf_every > 0)
+        chunk = max(1, int(lookahead)) * max(1, int(f.skip))
+        for c0 in range(0, n, chunk):
+            c1 = min(n, c0 + chunk)
+            if overlap_mode:
+                idx, forced = [], []
+                for i in range(c0, c1):
+                    t = t_start + i
+                    tail = mark_tail and i >= n - 2
+                    if t % f.skip == 0 or tail or (self.keyframes.counter.value == 0 and i == c0):
+                        idx.append(i)
+                        forced.append(tail)
+                if idx:
+                    sel = frames_u8[idx[0]:idx[-1] + 1:f.skip] if (not any(forced) and len(idx) > 1 and idx[-1] - idx[0] == f.skip * (len(idx) - 1)) \
+                        else frames_u8[torch.as_tensor(idx, device=frames_u8.device)]
+                    f.prefetch(sel, [t_start + i for i in idx], forced)
+            for i in range(c0, c1):
+                out = self.run(t_start + i, frames_u8[i:i + 1], intrinsics, frames_u8[i:i + 1], intrinsics,
+                               second_last_frame=mark_tail and i == n - 2, last_frame=mark_tail and i == n - 1)
+                if on_frame is not None:
+                    on_frame(t_start + i, out)
+
     def trajectory(self):
         """(tstamps [t], poses [t,7] c2w (t, q_xyzw)) of the tracked keyframes (demo_s.py:97-100)."""
         t = self.keyframes.counter.value - 1

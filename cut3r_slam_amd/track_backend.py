@@ -215,9 +215,10 @@ class TrackBackend:
             self.lc_initialized = True
             stored = pm_lc
         else:
+            # later loops keep the lc submap as aligned by its matched transform (track_backend.py:566-575 rebinds
+            # pointmaps_lc to pointmaps_lc_aligned[-1] before appending it)
             stored, updates = self.loop_closure(pm_lc, idx_matched, idx_current)
-            stored = pm_lc if stored.dim() == 3 else stored
         self.closed_loop["idx_current"].append(idx_current)
         self.closed_loop["idx_matched"].append(idx_matched)
-        self.closed_loop["pointmaps_lc"].append(pm_lc)
+        self.closed_loop["pointmaps_lc"].append(stored)
         return True, updates

@@ -128,6 +128,17 @@ int cut3r_postprocess_pose(const float* raw, int B, float* out, void* stream);
  * zeroed by the call.  ws: 16-B aligned fp32 workspace of 2*(N-1)*C + (N-1) elements. */
 int cut3r_patch_overlap(const float* feat0, const float* feat1, int N, int C, float thr, void* ws, int32_t* count,
                         void* stream);
+/* The keyframe decisions of a whole look-ahead batch with no host round trip per candidate: replaces the decision loop of
+ * MotionFilter.kfFilter (hislam2/motion_filter.py:98-124) over B consecutive tested frames whose encoder features
+ * feats fp32 [B,N,C] are already resident.  Candidate i is compared with the LAST KEYFRAME SO FAR -- feat_last [N,C] until
+ * a candidate is taken, then that candidate (kept in *state on the device: -1 | index) -- with the arithmetic of
+ * cut3r_patch_overlap (bit-identical counts), and is taken when (double)(float(count)/float(N-1)) < thr_ratio, or
+ * unconditionally when forced_host[i] != 0 (first / second-last / last frame, :87-96; forced_host may be NULL).
+ * counts, decisions: int32 [B] (device); state: int32 [1] (device).
+ * ws: 16-B aligned fp32 workspace of (B+1)*(N-1)*C + (N-1) elements. */
+int cut3r_patch_overlap_chain(const float* feat_last, const float* feats, int B, int N, int C, float thr_sim, double thr_ratio,
+                              const int32_t* forced_host, void* ws, int32_t* state, int32_t* counts, int32_t* decisions,
+                              void* stream);
 
 /* ---- covisibility graph geometry ------------------------------------------------------------------------------------
  * replaces FactorGraph.cal_overlap_batch / cal_overlap_bi (hislam2/factor_graph.py:255-315).

@@ -47,13 +47,58 @@ def rope2d(tokens: torch.Tensor, pos: torch.Tensor, base: float = 100.0, f0: flo
     return out.to(tokens.dtype)
 
 
+# ------------------------------------------------------------------------------------------------ operand precision
+# The reference runs its matmuls/convolutions in TF32 on NVIDIA (src/croco/models/croco.py:13 `allow_tf32 = True`): operands
+# rounded to a 10-bit mantissa, fp32 accumulation.  `matmul_precision("tf32")` emulates that on the CPU (operands of every
+# Linear / Conv / attention product rounded to 10 mantissa bits, round-to-nearest-even, products and sums in fp32), and
+# "fp16" rounds them to IEEE half (what the MI355X path feeds its MFMAs).  Default "fp32" = exact fp32, the pinned mode.
+_PRECISION = ["fp32"]
+
+
+class matmul_precision:
+    def __init__(self, mode: str):
+        assert mode in ("fp32", "tf32", "fp16"), mode
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _PRECISION[0]
+        _PRECISION[0] = self.mode
+
+    def __exit__(self, *exc):
+        _PRECISION[0] = self.prev
+
+
+def round_tf32(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> nearest value with a 10-bit mantissa (ties to even), exponent range of fp32"""
+    i = x.contiguous().view(torch.int32)
+    lsb = (i >> 13) & 1
+    i = (i + 0x0FFF + lsb) & ~0x1FFF
+    return i.view(torch.float32)
+
+
+def _r(x):
+    m = _PRECISION[0]
+    if m == "fp32" or x is None:
+        return x
+    if m == "tf32":
+        return round_tf32(x.float())
+    return x.to(torch.float16).float()
+
+
+def _sdpa(q, k, v, scale):
+    if _PRECISION[0] == "fp32":
+        return F.scaled_dot_product_attention(q, k, v, scale=scale)
+    s = torch.softmax((_r(q) @ _r(k).transpose(-1, -2)) * scale, dim=-1)
+    return _r(s) @ _r(v)
+
+
 # ------------------------------------------------------------------------------------------------ blocks
 def _ln(x, sd, p, eps=1e-6):
     return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps)
 
 
 def _lin(x, sd, p):
-    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+    return F.linear(_r(x), _r(sd[p + ".weight"]), sd.get(p + ".bias"))
 
 
 def _mlp(x, sd, p):
@@ -72,7 +117,7 @@ def _self_attn(x, pos, sd, p, heads, rope: bool, fp16_qk: bool):
         else:            # dust3r/blocks.py:114-121 (decoder): fp32 throughout
             q = rope2d(q, pos)
             k = rope2d(k, pos)
-    o = F.scaled_dot_product_attention(q, k, v, scale=d ** -0.5)
+    o = _sdpa(q, k, v, d ** -0.5)
     return _lin(o.transpose(1, 2).reshape(B, N, C), sd, p + ".proj")
 
 
@@ -88,7 +133,7 @@ def _cross_attn(xq, y, qpos, kpos, sd, p, heads, rope: bool):
             q = rope2d(q, qpos)
         if kpos is not None:
             k = rope2d(k, kpos)
-    o = F.scaled_dot_product_attention(q, k, v, scale=d ** -0.5)
+    o = _sdpa(q, k, v, d ** -0.5)
     return _lin(o.transpose(1, 2).reshape(B, Nq, C), sd, p + ".proj")
 
 
@@ -124,7 +169,7 @@ def encode_image(cfg, sd, img):
     """img [B,3,H,W] float (already normalised) -> (feat [B,N,E], pos [B,N,2] int64)."""
     B, _, H, W = img.shape
     P = cfg.patch_size
-    x = F.conv2d(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=P)
+    x = F.conv2d(_r(img), _r(sd["patch_embed.proj.weight"]), sd["patch_embed.proj.bias"], stride=P)
     x = x.flatten(2).transpose(1, 2)
     pos = patch_positions(B, H // P, W // P)
     for i in range(cfg.enc_depth):
@@ -154,7 +199,7 @@ def postprocess_pose(out):
 
 
 def _conv(x, sd, p, **kw):
-    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), **kw)
+    return F.conv2d(_r(x), _r(sd[p + ".weight"]), sd.get(p + ".bias"), **kw)
 
 
 def _rcu(x, sd, p):
@@ -177,8 +222,8 @@ def dpt_adapter(cfg, sd, p, toks: List[torch.Tensor], H, W):
     nh, nw = H // P, W // P
     L = [t.transpose(1, 2).reshape(t.shape[0], t.shape[2], nh, nw) for t in toks]
     a = p + ".act_postprocess"
-    l0 = F.conv_transpose2d(_conv(L[0], sd, a + ".0.0"), sd[a + ".0.1.weight"], sd[a + ".0.1.bias"], stride=4)
-    l1 = F.conv_transpose2d(_conv(L[1], sd, a + ".1.0"), sd[a + ".1.1.weight"], sd[a + ".1.1.bias"], stride=2)
+    l0 = F.conv_transpose2d(_r(_conv(L[0], sd, a + ".0.0")), _r(sd[a + ".0.1.weight"]), sd[a + ".0.1.bias"], stride=4)
+    l1 = F.conv_transpose2d(_r(_conv(L[1], sd, a + ".1.0")), _r(sd[a + ".1.1.weight"]), sd[a + ".1.1.bias"], stride=2)
     l2 = _conv(L[2], sd, a + ".2.0")
     l3 = _conv(_conv(L[3], sd, a + ".3.0"), sd, a + ".3.1", stride=2, padding=1)
     L = [l0, l1, l2, l3]

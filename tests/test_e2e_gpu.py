@@ -1,0 +1,168 @@
+"""GPU: END-TO-END trajectory parity -- frames in, keyframe trajectory out -- of the HIP tracking loop (`Cut3rSlam.run`,
+everything through the C ABI) against the CPU restatement of the reference loop (oracle/slam_run.py: fp32 network, fp32
+geometry) on the SAME seeded stream and weights.  This is the second half of the BASELINE metric: the reference's run
+scripts score `traj_kf.txt` with `evo_ape tum ... -vas` (scripts/run_scannet.py:34-36) = Sim(3)-aligned ATE-RMSE.
+
+What is asserted (medium config: production head widths at 64x96, >= 7 tracking windows, path length ~3 m):
+  * keyframe selection: identical time stamps (fixed cadence AND overlap mode, whose decisions come from the features);
+  * graph topology: identical edge lists, except edges whose deciding overlap ratio sits within +-0.02 of the 0.3 threshold in
+    the oracle (listed; a TF32 run of the oracle flips the same kind of edges against its own fp32 run);
+  * ATE-RMSE(GPU, CPU fp32) <= 1 mm (BASELINE target) on the smooth 2.9 m fixed-cadence stream, <= 1 mm per metre on the
+    13.7 m slideshow stream, and in both cases <= 2.5 x ATE-RMSE(CPU TF32-emulated, CPU fp32): the fp16-operand MFMA path
+    deviates from exact fp32 no more than the reference's own TF32 arithmetic does.
+Parity status: the network, overlap counts and edge bookkeeping of the oracle are pinned to reference fixtures; the
+composition of the tracker drivers is read-faithful, unpinned (they hard-code 'cuda' in the reference).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cut3r_slam_amd import synth  # noqa: E402
+from cut3r_slam_amd.eval_ate import ate_rmse  # noqa: E402
+from cut3r_slam_amd.model import Cut3rModel  # noqa: E402
+from cut3r_slam_amd.slam import Cut3rSlam  # noqa: E402
+from oracle import slam_run as SR  # noqa: E402
+
+DEV = "cuda:0"
+H, W = 64, 96
+INTR = np.array([80.0, 80.0, 47.5, 31.5], np.float32)
+NEAR = 0.02                     # half-width of the "near the 0.3 overlap threshold" band used to explain edge differences
+
+
+def _gpu_run(cfg, sd, frames, mf, buffered=False, window_batch=1):
+    model = Cut3rModel(cfg, sd, DEV, minimal=True)
+    conf = {"Tracking": {"motion_filter": dict(mf), "frontend": {"iteration": 0, "window_batch": window_batch}}}
+    slam = Cut3rSlam(model, conf, (H, W), buffer=frames.shape[0] + 8, device=DEV)
+    intr = torch.from_numpy(INTR)
+    fr = frames.to(DEV)
+    n = fr.shape[0]
+    if buffered:
+        slam.run_buffered(fr, intr, lookahead=6)
+    else:
+        for t in range(n):
+            slam.run(t, fr[t:t + 1], intr, fr[t:t + 1], intr, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+    torch.cuda.synchronize()
+    ts, poses = slam.trajectory()
+    return slam, np.concatenate([ts.reshape(-1, 1).astype(np.float64), poses.astype(np.float64)], 1)
+
+
+def _path_length(traj):
+    return float(np.linalg.norm(np.diff(traj[:, 1:4], axis=0), axis=1).sum())
+
+
+def _explain_edge_differences(edges_a, edges_b, so):
+    """every edge in the symmetric difference must be decided by a ratio within NEAR of 0.3 in the oracle"""
+    unexplained, near = [], []
+    for (i, j) in sorted(set(edges_a) ^ set(edges_b)):
+        r = so.graph.ratios.get((max(i, j), min(i, j)))
+        ok = r is not None and any(v is not None and abs(v - 0.3) <= NEAR for v in r)
+        (near if ok else unexplained).append(((i, j), r))
+    return near, unexplained
+
+
+def _compare(tag, slam, traj_gpu, so_fp32, so_tf32, ate_limit=1e-3):
+    traj_ref, traj_tf = so_fp32.trajectory(), so_tf32.trajectory()
+    assert np.array_equal(traj_gpu[:, 0], traj_ref[:, 0]), f"{tag}: keyframe time stamps differ\n{traj_gpu[:, 0]}\n{traj_ref[:, 0]}"
+    assert len(so_fp32.windows) >= 7 and slam.tracker.t1 == so_fp32.t1
+    path = _path_length(traj_ref)
+    ate = ate_rmse(traj_gpu, traj_ref, 0.01, True)
+    ate_tf = ate_rmse(traj_tf, traj_ref, 0.01, True) if np.array_equal(traj_tf[:, 0], traj_ref[:, 0]) else None
+    ii, jj, _ = slam.graph.edges_numpy()
+    e_gpu, e_ref = list(zip(ii.tolist(), jj.tolist())), list(zip(so_fp32.graph.ii, so_fp32.graph.jj))
+    near, unexplained = _explain_edge_differences(e_gpu, e_ref, so_fp32)
+    first_div = next((k for k, (a, b) in enumerate(zip(e_gpu, e_ref)) if a != b), None)
+    pos_err = np.abs(traj_gpu[:, 1:4] - traj_ref[:, 1:4]).max()
+    print(f"[e2e {tag}] keyframes {len(traj_ref)} windows {len(so_fp32.windows)} path {path:.3f} m | ATE-RMSE GPU vs CPU-fp32 "
+          f"{ate['rmse'] * 1e3:.3f} mm (scale {ate['scale']:.6f}, max {ate['max'] * 1e3:.3f} mm, unaligned max |dt| {pos_err * 1e3:.3f} mm) | "
+          f"CPU-tf32 vs CPU-fp32 {ate_tf['rmse'] * 1e3 if ate_tf else float('nan'):.3f} mm | edges {len(e_gpu)} vs {len(e_ref)}, "
+          f"first divergent edge {first_div}, near-threshold differences {near}")
+    assert not unexplained, f"{tag}: edge differences not explained by a near-threshold overlap ratio: {unexplained}"
+    assert len(near) <= 0.02 * len(e_ref) + 2
+    assert path >= 1.0
+    assert ate["rmse"] <= ate_limit(path) if callable(ate_limit) else ate["rmse"] <= ate_limit, ate
+    if ate_tf is not None:
+        assert ate["rmse"] <= 2.5 * ate_tf["rmse"] + 5e-5, (ate, ate_tf)
+    return ate, ate_tf
+
+
+def test_fixed_cadence_stream_trajectory_matches_cpu_path():
+    cfg = synth.medium_config()
+    sd = synth.tracking_state_dict(cfg, 11)
+    mf = {"thresh": 0.9, "skip": 1, "kf_every": 2}
+    frames = synth.pan_stream(70, H, W, pool=5, num=2, den=1, seed=0)
+    so32 = SR.run_stream(cfg, sd, frames, INTR, mf, precision="fp32")
+    sotf = SR.run_stream(cfg, sd, frames, INTR, mf, precision="tf32")
+    slam, traj = _gpu_run(cfg, sd, frames, mf)
+    _compare("kf_every=2", slam, traj, so32, sotf)
+
+
+def test_overlap_mode_stream_trajectory_matches_cpu_path_and_buffered_driver_is_identical():
+    cfg = synth.medium_config()
+    sd = synth.tracking_state_dict(cfg, 11)
+    mf = {"thresh": 0.9, "skip": 2, "kf_every": -1}
+    frames = synth.slideshow_stream(150, H, W, hold=4, seed=3)
+    so32 = SR.run_stream(cfg, sd, frames, INTR, mf, precision="fp32")
+    sotf = SR.run_stream(cfg, sd, frames, INTR, mf, precision="tf32")
+    # the decisions are content driven: some tested frames are kept, some are not
+    kept = {int(t) for t in so32.trajectory()[:, 0]}
+    tested = [t for t, _ in so32.ratios]
+    assert 0.3 < len(kept & set(tested)) / len(tested) < 0.7
+    slam, traj = _gpu_run(cfg, sd, frames, mf)
+    # ratios of the HIP filter vs the oracle's on every tested frame: both far from the 0.9 decision threshold
+    # (unrelated textures make the random-weight network jump ~0.35 m per keyframe: a 13.7 m path, on which the reference's
+    #  own TF32 arithmetic already deviates 3.2 mm from exact fp32 -- the bound here is 1 mm per metre of path)
+    _compare("overlap skip=2", slam, traj, so32, sotf, ate_limit=lambda path: 1e-3 * path)
+    # buffered driver (batched look-ahead encode + on-device decision chain): bit-identical to the frame-by-frame loop
+    slam_b, traj_b = _gpu_run(cfg, sd, frames, mf, buffered=True)
+    assert np.array_equal(traj, traj_b)
+    assert slam_b.filterx.stats["encoded"] <= 2 and slam_b.filterx.stats["cache_hits"] >= len(tested) - 2
+    for a, b in zip(slam.graph.edges_numpy(), slam_b.graph.edges_numpy()):
+        assert np.array_equal(a, b)
+    k = slam.tracker.t1
+    assert torch.equal(slam.keyframes.featI[:k], slam_b.keyframes.featI[:k])
+    assert torch.equal(slam.keyframes.depth[:k], slam_b.keyframes.depth[:k])
+
+
+def test_overlap_decisions_at_production_encoder_shape_match_oracle_on_same_features():
+    """384x512, ViT-L encoder (24 x 1024/16): the keyframe decisions of the batched look-ahead path == decisions taken by the
+    fp64 oracle ratio (oracle/geom.py) on the SAME (HIP) features, and == the sequential kfFilter path."""
+    from cut3r_slam_amd.config import production_config
+    from oracle import geom as G
+    cfg = production_config()
+    sd = synth.tracking_state_dict(cfg, 0, enc_residual_gain=0.1)
+    model = Cut3rModel(cfg, sd, DEV, minimal=True)
+    Hp, Wp = 384, 512
+    frames = synth.slideshow_stream(61, Hp, Wp, hold=10, seed=1, device=DEV)
+    conf = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "kf_every": -1}, "frontend": {"iteration": 0}}}
+    intr = torch.tensor([300.0, 300.0, 255.5, 191.5])
+    slam = Cut3rSlam(model, conf, (Hp, Wp), buffer=32, device=DEV)
+    f = slam.filterx
+    idx = list(range(0, 61, 5))
+    f.prefetch(frames[0:61:5], idx, None)
+    ahead = {t: (feat.clone(), took, cnt) for t, (feat, took, cnt, _) in f._ahead.items()}
+    # sequential reference decisions on the same features, fp64 ratio
+    last, ref = None, {}
+    for t in idx:
+        feat = ahead[t][0].cpu().numpy()
+        if last is None:
+            ref[t], last = True, feat
+            continue
+        ratio, _ = G.patch_overlap_ratio(last, feat)
+        ref[t] = ratio < 0.9
+        assert abs(ratio - ahead[t][2] / (feat.shape[0] - 1)) < 2e-3, (t, ratio, ahead[t][2])
+        if ref[t]:
+            last = feat
+    assert {t: a[1] for t, a in ahead.items()} == ref
+    assert sum(ref.values()) == 7                                   # one keyframe per texture
+    # the plain per-frame filter takes the same decisions with bit-identical features
+    slam2 = Cut3rSlam(model, conf, (Hp, Wp), buffer=32, device=DEV)
+    took = {}
+    for t in range(61):
+        took[t] = slam2.filterx.kfFilter(t, frames[t:t + 1], intrinsics=intr)
+    assert {t: took[t] for t in idx} == ref
+    k = slam2.keyframes.counter.value
+    assert k == 7
+    for i, t in enumerate([t for t in idx if ref[t]]):
+        assert torch.equal(slam2.keyframes.featI[i], ahead[t][0])
