@@ -1,22 +1,35 @@
 #!/usr/bin/env python3
-"""Throughput of the CUT3R-SLAM tracking hot path on MI355X (BASELINE.json metric: frames/s on 640x480 input).
+"""Throughput + trajectory parity of the CUT3R-SLAM tracking hot path on MI355X (BASELINE.json metric: frames/s on 640x480
+input; ATE-RMSE vs the reference path).
 
-Workload (BASELINE configs[1], "Replica room0 640x480: ViT pointmap + factor-graph step, tracking only, GS off"):
-synthetic 640x480 stream -> tracking resolution 384x512 (demo_s.py:69-73), production-shape network (ViT-L encoder,
-768-d dual decoder, DPT head; seeded random weights -- no checkpoint exists), fixed keyframe cadence kf_every=10
-(hislam2/motion_filter.py:83,109,124).  One STEP = one steady-state tracking window = 50 input frames:
-5 keyframe-filter encoder passes + one 6-view window inference + chaining/alignment + covisibility-graph update
-of the 5 new keyframes (hislam2/hi2.py:101-133 without the GS mapper).  Frames are resident in HBM before the
-timed region.  value = frames processed by all ranks / max-over-ranks time.
+Headline `value` (BASELINE configs[1], "Replica room0 640x480: ViT pointmap + factor-graph step, tracking only, GS off"):
+synthetic 640x480 stream -> tracking resolution 384x512 (demo_s.py:69-73), production-shape network (ViT-L encoder, 768-d
+dual decoder, DPT head; seeded random weights -- no checkpoint exists), BUFFERED FIXED-CADENCE mode: kf_every=10
+(hislam2/motion_filter.py:83,109,124; SURVEY 8(d) names it the throughput schedule because its keyframes do not depend on
+feature numerics), `--window-batch` (default 8) tracking windows pushed through the decoder together.  One STEP =
+window_batch steady-state windows = window_batch*50 frames: each new keyframe through the encoder once, 6-view recurrent
+decoder + DPT head per window, chaining/alignment + covisibility-graph update per keyframe (hislam2/hi2.py:101-133 without
+the GS mapper).  Frames are resident in HBM before the timed region.  value = frames of all ranks / max-over-ranks time.
 
-N > 1 (one process per GPU, torch.distributed/RCCL): windows are sharded across ranks (every window re-initialises
-the recurrent state, src/dust3r/model.py:819-822, so windows are independent network evaluations); each step every
-rank infers ONE window, the three consumed outputs are all-gathered over xGMI and the cheap sequential chaining +
-graph update of all N windows runs replicated.  Per-GPU work is fixed => "scaling": "weak".
+Beside it, in the same JSON line (rank 0, N = 1):
+  operating_points   the reference's own schedules on the same network: fixed cadence with ONE window at a time
+                     (window_batch=1), and the maintained configs' OVERLAP mode (kf_every=-1, skip=5, thresh=0.9,
+                     config/scannet_config.yaml:20-25): encoder + patch-overlap test every 5th frame, one window at a time,
+                     through Cut3rSlam.run -- frame by frame, and with the batched look-ahead of the buffered driver
+  trajectory_parity  the metric's second half: Cut3rSlam on HIP vs the CPU restatement of the reference loop
+                     (oracle/slam_run.py) on the same seeded stream and weights, medium config, both keyframe modes:
+                     Sim(3)-aligned ATE-RMSE (evo_ape -vas semantics), keyframe agreement, edge-list equality
+  roofline           dominant MFMA GEMM kernel (+ the other large-tile GEMM and the attention kernels), HIP-event timed
+  cpu_baseline       the oracle timed on the host cores on a bounded sample of the same loop
+
+N > 1 (one process per GPU, torch.distributed/RCCL): windows are sharded across ranks (every window re-initialises the
+recurrent state, src/dust3r/model.py:819-822); the consumed outputs are all-gathered over xGMI and the cheap sequential
+chaining + graph update runs replicated.  Per-GPU work is fixed => "scaling": "weak".
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,6 +38,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+H, W, KF_EVERY, WIN = 384, 512, 10, 5
+PEAK_F16 = 2500.0          # TFLOP/s dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def synth_frames(n, H, W, device, seed=0):
@@ -40,50 +56,63 @@ def synth_frames(n, H, W, device, seed=0):
     return frames
 
 
-class GemmProbe:
-    """HIP-event timing of every launch of the two large-tile GEMM kernels (128^2 and 256^2) on the launch stream."""
+class KernelProbe:
+    """HIP-event timing, on the launch stream, of every launch of the large-tile GEMM kernels and of the fused attention
+    kernels (the C-ABI entry points are wrapped; events bracket live launches of an eager pass, never a graph replay)."""
 
-    KERNELS = {128: "gemm_kernel<128,128,2,4,2> (v_mfma_f32_16x16x32_f16, 8 waves, 2 workgroups/CU)",
-               256: "gemm256_kernel (256x256x64, v_mfma_f32_16x16x32_f16, 8 waves ping-pong, 1 workgroup/CU)"}
+    GEMM = {128: "gemm_kernel<128,128,2,4,2> (v_mfma_f32_16x16x32_f16, 8 waves, 2 workgroups/CU)",
+            256: "gemm256_kernel (256x256x64, v_mfma_f32_16x16x32_f16, 8 waves ping-pong, 1 workgroup/CU)"}
 
     def __init__(self):
-        self.ev = {128: [], 256: []}
-        self.flops = {128: 0.0, 256: 0.0}
-        self.bytes = {128: 0.0, 256: 0.0}
+        self.rec = {}          # key -> [events, flops, bytes]
+
+    def _add(self, key, s, e, flops, nbytes):
+        r = self.rec.setdefault(key, [[], 0.0, 0.0])
+        r[0].append((s, e))
+        r[1] += flops
+        r[2] += nbytes
 
     def install(self):
         from cut3r_slam_amd import _lib
         lib = _lib.load()
-        raw = lib.cut3r_gemm_f16
+        raw_gemm, raw_attn = lib.cut3r_gemm_f16, lib.cut3r_attention_f16
         probe = self
 
-        def wrapped(dref, stream):
+        def gemm(dref, stream):
             d = dref._obj
             tile = lib.cut3r_gemm_tile_for(dref)
-            if tile in (128, 256):
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                rc = raw(dref, stream)
-                e.record()
-                probe.ev[tile].append((s, e))
-                nb = max(d.batch, 1)
-                probe.flops[tile] += 2.0 * d.M * d.N * d.K * nb
-                a_bytes = d.M * d.Cin * 2 if d.conv_k == 3 else d.M * d.K * 2        # a conv input is read once
-                probe.bytes[tile] += nb * (a_bytes + d.N * d.K * 2 + d.M * d.N * (2 if d.out_f16 else 4)
-                                           + (d.M * d.N * (2 if d.res1_f16 else 4) if d.res1 else 0))
-                return rc
-            return raw(dref, stream)
+            if tile not in (128, 256):
+                return raw_gemm(dref, stream)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = raw_gemm(dref, stream)
+            e.record()
+            nb = max(d.batch, 1)
+            a_bytes = d.M * d.Cin * 2 if d.conv_k == 3 else d.M * d.K * 2        # a conv input is read once
+            probe._add(("gemm", tile), s, e, 2.0 * d.M * d.N * d.K * nb,
+                       nb * (a_bytes + d.N * d.K * 2 + d.M * d.N * (2 if d.out_f16 else 4) + (d.M * d.N * (2 if d.res1_f16 else 4) if d.res1 else 0)))
+            return rc
 
-        self._lib, self._raw = lib, raw
-        lib.cut3r_gemm_f16 = wrapped
+        def attn(q, k, v, o, B, Hh, Nq, Nk, D, *rest):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = raw_attn(q, k, v, o, B, Hh, Nq, Nk, D, *rest)
+            e.record()
+            if Nq >= 128 and Nk >= 128:
+                probe._add(("attn", D, "enc" if B * Nq >= 8 * 768 and D == 64 and Hh == 16 else "dec"), s, e, 4.0 * B * Hh * Nq * Nk * D,
+                           2.0 * B * Hh * D * (2 * Nq + 2 * Nk))
+            return rc
+
+        self._lib, self._raw = lib, (raw_gemm, raw_attn)
+        lib.cut3r_gemm_f16, lib.cut3r_attention_f16 = gemm, attn
 
     def remove(self):
-        self._lib.cut3r_gemm_f16 = self._raw
+        self._lib.cut3r_gemm_f16, self._lib.cut3r_attention_f16 = self._raw
 
     def result(self):
-        """{tile: (launches, total ms, flops, algorithmic bytes)}"""
+        """{key: (launches, total ms, flops, algorithmic bytes)}"""
         torch.cuda.synchronize()
-        return {t: (len(ev), sum(s.elapsed_time(e) for s, e in ev), self.flops[t], self.bytes[t]) for t, ev in self.ev.items()}
+        return {k: (len(ev), sum(s.elapsed_time(e) for s, e in ev), fl, by) for k, (ev, fl, by) in self.rec.items()}
 
 
 def log(msg):
@@ -99,6 +128,195 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def git_sha():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
+def traffic_from_profile(tile, launches_in_run):
+    """HBM-side bytes per launch of the dominant GEMM from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of this same command, tools/pmc_traffic.py).  NOT measured in this run: emitted with its provenance,
+    and dropped (null) when the profile belongs to another kernel build."""
+    for rnd in ("r02", "r01"):
+        pj = os.path.join(ROOT, "profiles", rnd, f"pmc_traffic_gemm{tile}.json")
+        if os.path.isfile(pj):
+            j = json.load(open(pj))
+            return {"bytes_per_launch": j.get("traffic_bytes_per_launch"), "source": os.path.relpath(pj, ROOT),
+                    "profile_launches": j.get("launches"), "profile_git_sha": j.get("git_sha"), "run_launches": launches_in_run,
+                    "note": "separate rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE); not measured in this run"}
+    return None
+
+
+# ------------------------------------------------------------------------------------------------------------------ legs
+def fixed_cadence_leg(model, slam_cls, cdist, dev, wb, steps, warmup, world=1, rank=0, dist_on=False, emu=0, probe_steps=0, barrier=None):
+    """buffered fixed-cadence schedule (kf_every=10) through the pipelined ShardedTracker; returns dict of results"""
+    total_steps = warmup + steps
+    n_kf = 7 + WIN * wb * world * (total_steps + probe_steps) + 2
+    config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": KF_EVERY},
+                           "frontend": {"iteration": 0, "window_batch": 1}}}
+    slam = slam_cls(model, config, (H, W), buffer=n_kf + 8, device=dev)
+    intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])  # calib/replica.txt scaled
+    runner = cdist.ShardedTracker(slam, world, rank, wb=wb, pipelined=os.environ.get("CUT3R_PIPELINE", "1") == "1", force_collective=dist_on)
+    runner.emulate_gather = emu > 1
+    frames = synth_frames(runner.frames_needed(total_steps + probe_steps, KF_EVERY, WIN), H, W, dev, seed=0)
+    t = 0
+    while not slam.keyframes.is_initialized:          # prologue (untimed): the 6-keyframe initialisation window
+        slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+        t += 1
+    torch.cuda.synchronize()
+    for _ in range(warmup):
+        t = runner.step(frames, t, KF_EVERY, WIN, intr)
+    runner.flush()
+    barrier()
+    for k in runner.stats:
+        runner.stats[k] = 0
+    tic = time.perf_counter()
+    for _ in range(steps):
+        t = runner.step(frames, t, KF_EVERY, WIN, intr)
+    runner.flush()                       # the timed region holds exactly K network passes and K replays
+    barrier()
+    elapsed = time.perf_counter() - tic
+    return {"elapsed": elapsed, "slam": slam, "runner": runner, "frames": frames, "t": t, "intr": intr,
+            "frames_per_step": KF_EVERY * WIN * wb}
+
+
+def overlap_mode_leg(model, slam_cls, dev, n_frames=800, lookahead=16, plain_frames=200):
+    """the maintained configs' schedule (kf_every=-1, skip=5, thresh=0.9; one 6-view window at a time) through
+    Cut3rSlam.run on a content-driven stream (cut3r_slam_amd.synth.slideshow_stream: one keyframe per 10 frames)"""
+    from cut3r_slam_amd import synth
+    config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": -1},
+                           "frontend": {"iteration": 0, "window_batch": 1}}}
+    intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])
+    out = {"config": "kf_every=-1, skip=5, thresh=0.9, window_batch=1 (config/scannet_config.yaml:20-25)"}
+    warm = 160                          # initialisation window + first steady windows: graph captures, workspaces
+    frames = synth.slideshow_stream(warm + max(n_frames, plain_frames), H, W, hold=10, seed=0, device=dev)
+    for name, n, kw in (("buffered_lookahead", n_frames, {"lookahead": lookahead}), ("frame_by_frame", plain_frames, None)):
+        slam = slam_cls(model, config, (H, W), buffer=(warm + n) // 10 + 16, device=dev)
+        if kw is None:
+            for t in range(warm):
+                slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+        else:
+            slam.run_buffered(frames[:warm], intr, mark_tail=False, **kw)
+        torch.cuda.synchronize()
+        k0, w0 = slam.keyframes.counter.value, slam.tracker.t1
+        tic = time.perf_counter()
+        if kw is None:
+            for t in range(warm, warm + n):
+                slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+        else:
+            slam.run_buffered(frames[warm:warm + n], intr, t_start=warm, mark_tail=False, **kw)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - tic
+        out[name] = {"frames_per_s": round(n / el, 1), "frames": n, "keyframes": slam.keyframes.counter.value - k0,
+                     "tested_frames": n // 5, "windows": (slam.tracker.t1 - w0) // 5, "ms_per_frame": round(1e3 * el / n, 3)}
+        if kw is not None:
+            out[name]["lookahead_tested_frames"] = lookahead
+            out[name]["latency_frames"] = lookahead * 5
+    return out
+
+
+def trajectory_parity_leg(dev):
+    """GPU path vs CPU restatement of the reference loop on the same seeded stream + weights (medium config, both keyframe
+    modes): ATE-RMSE with Sim(3) alignment, keyframe agreement, edge lists.  tests/test_e2e_gpu.py asserts the same."""
+    from cut3r_slam_amd import synth
+    from cut3r_slam_amd.eval_ate import ate_rmse
+    from cut3r_slam_amd.model import Cut3rModel
+    from cut3r_slam_amd.slam import Cut3rSlam
+    from oracle import slam_run as SR
+    Hm, Wm = 64, 96
+    intr = np.array([80.0, 80.0, 47.5, 31.5], np.float32)
+    cfg = synth.medium_config()
+    sd = synth.tracking_state_dict(cfg, 11)
+    model = Cut3rModel(cfg, sd, dev, minimal=True)
+    res = {"config": "medium (enc 256/3/4, dec 192/4/3 + 4 state heads, DPT head) at 64x96; oracle/slam_run.py fp32 on the host",
+           "alignment": "Sim(3) Umeyama, RMSE of translation residuals (evo_ape tum -vas, scripts/run_scannet.py:34-36)"}
+    for tag, mf, frames in (("fixed_cadence_kf_every_2", {"thresh": 0.9, "skip": 1, "kf_every": 2}, synth.pan_stream(70, Hm, Wm, 5, 2, 1, 0)),
+                            ("overlap_mode_skip_2", {"thresh": 0.9, "skip": 2, "kf_every": -1}, synth.slideshow_stream(150, Hm, Wm, 4, 3))):
+        so = SR.run_stream(cfg, sd, frames, intr, mf, precision="fp32")
+        sotf = SR.run_stream(cfg, sd, frames, intr, mf, precision="tf32")
+        conf = {"Tracking": {"motion_filter": dict(mf), "frontend": {"iteration": 0}}}
+        slam = Cut3rSlam(model, conf, (Hm, Wm), buffer=frames.shape[0] + 8, device=dev)
+        fr = frames.to(dev)
+        n = fr.shape[0]
+        it = torch.from_numpy(intr)
+        for t in range(n):
+            slam.run(t, fr[t:t + 1], it, fr[t:t + 1], it, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+        torch.cuda.synchronize()
+        ts, poses = slam.trajectory()
+        tg = np.concatenate([ts.reshape(-1, 1).astype(np.float64), poses.astype(np.float64)], 1)
+        tr, ttf = so.trajectory(), sotf.trajectory()
+        kf_gpu, kf_ref = set(tg[:, 0].tolist()), set(tr[:, 0].tolist())
+        ii, jj, _ = slam.graph.edges_numpy()
+        e_gpu, e_ref = list(zip(ii.tolist(), jj.tolist())), list(zip(so.graph.ii, so.graph.jj))
+        first_div = next((k for k, (a, b) in enumerate(zip(e_gpu, e_ref)) if a != b), None)
+        if first_div is None and len(e_gpu) != len(e_ref):
+            first_div = min(len(e_gpu), len(e_ref))
+        diff = sorted(set(e_gpu) ^ set(e_ref))
+        a = ate_rmse(tg, tr, 0.01, True)
+        atf = ate_rmse(ttf, tr, 0.01, True)
+        res[tag] = {"keyframes": len(tr), "windows": len(so.windows), "path_length_m": round(float(np.linalg.norm(np.diff(tr[:, 1:4], axis=0), axis=1).sum()), 4),
+                    "ate_rmse_m": a["rmse"], "ate_max_m": a["max"], "sim3_scale": a["scale"],
+                    "ate_rmse_m_cpu_tf32_vs_cpu_fp32": atf["rmse"],
+                    "keyframe_agreement": len(kf_gpu & kf_ref) / max(1, len(kf_gpu | kf_ref)),
+                    "edges_gpu": len(e_gpu), "edges_cpu": len(e_ref), "edge_lists_equal": e_gpu == e_ref, "first_divergent_edge": first_div,
+                    "differing_edges": [[int(i), int(j), so.graph.ratios.get((max(i, j), min(i, j)))] for i, j in diff[:8]]}
+    return res
+
+
+def cpu_baseline(cfg, sd, imgs_u8, frames_per_window=50):
+    """Oracle (kind 'port') timed on the host cores on a BOUNDED sample of the tracking loop at 384x512: one keyframe-filter
+    encode + patch-overlap test, one 2-view window through the network (the model cost is linear in views: extrapolated to
+    5 encodes + 6 views), the window alignment of 6 views and 50 covisibility-graph updates at the real map sizes."""
+    from oracle import cut3r_oracle as O
+    from oracle import slam_oracle as SO
+    from oracle import slam_run as SR
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    x = O.normalize(imgs_u8)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        f0, _ = O.encode_image(cfg, sd, x[:1])
+        t_enc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        SR.patch_overlap_ratio_f32(f0[0], f0[0].roll(1, 0))
+        t_ovl = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        preds = O.forward_views(cfg, sd, x[:2], minimal=True)
+        t_win2 = time.perf_counter() - t0
+    t_dec_view = max(t_win2 - 2 * t_enc, 0.0) / 2
+    # chaining of a 6-view window + 50 graph updates on maps of the real size (network outputs of the sample, repeated)
+    pts = torch.cat([preds[i % 2]["pts3d_in_self_view"] for i in range(6)], 0).abs() + 0.5
+    conf = torch.cat([preds[i % 2]["conf_self"] for i in range(6)], 0)
+    enc = torch.cat([preds[i % 2]["camera_pose"] for i in range(6)], 0)
+    nkf = 64
+    st = {"pose": torch.zeros(nkf, 7), "depth": torch.ones(nkf, H, W), "submap_ds": torch.ones(nkf // 5 + 1, 6, H // 2, W // 2, 3),
+          "conf_ds": torch.zeros(nkf // 5 + 1, 6, H // 2, W // 2)}
+    st["pose"][:, 6] = 1
+    t0 = time.perf_counter()
+    full = SO.track_window(st, 0, 6, pts, conf, enc, True)
+    t_align = time.perf_counter() - t0
+    graph = SR.RefGraph()
+    g = np.random.default_rng(0)
+    c2w = np.tile(np.eye(4, dtype=np.float32), (60, 1, 1))
+    c2w[:, :3, 3] = g.normal(0, 0.7, (60, 3)).astype(np.float32)
+    pm_all = np.ascontiguousarray(np.broadcast_to(full[0][2][::2, ::2].numpy()[None], (60, H // 2, W // 2, 3)))
+    cur_pm = full[1][2].numpy()
+    K4 = np.array([256.0, 203.3, 255.8, 191.7], np.float32)
+    t0 = time.perf_counter()
+    for i in range(10, 60):
+        graph.add(i, c2w[:i], pm_all[:i], c2w[i], cur_pm, K4)
+    t_graph = (time.perf_counter() - t0) / 50
+    window_s = 5 * (t_enc + t_ovl) + 6 * t_dec_view + t_align + 5 * t_graph
+    return {"value": round(frames_per_window / window_s, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "stage_ms": {"kf_filter_encode": round(1e3 * t_enc, 1), "patch_overlap": round(1e3 * t_ovl, 1), "decoder_heads_per_view": round(1e3 * t_dec_view, 1),
+                         "window_alignment_6_views": round(1e3 * t_align, 1), "graph_update_per_keyframe_avg_35_prev": round(1e3 * t_graph, 1)},
+            "sample": f"oracle fp32 at 384x512: 1 encode_image ({t_enc:.2f} s) + patch-overlap test + one 2-view window ({t_win2:.2f} s) + "
+                      f"alignment of 6 views + 50 graph updates (10..59 previous keyframes); composed into a 50-frame window = 5 (encode + test) + "
+                      "6 decoder/head views + 1 alignment + 5 graph updates"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +324,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-operating-points", action="store_true")
+    ap.add_argument("--no-trajectory-parity", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: tiny network (NOT a valid benchmark line)")
     ap.add_argument("--window-batch", type=int, default=8, help="tracking windows pushed through the decoder together "
                     "(buffered-stream throughput mode; 1 = the reference's one-window-at-a-time schedule)")
@@ -120,6 +340,7 @@ def main():
     dist_on = world > 1 or os.environ.get("CUT3R_FORCE_DIST") == "1"     # the env flag rehearses the RCCL path with one rank
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    dist = None
     if dist_on:
         import torch.distributed as dist
         backend = os.environ.get("CUT3R_DIST_BACKEND", "nccl")       # "gloo": functional multi-rank run with every rank on ONE GPU
@@ -133,48 +354,21 @@ def main():
     from cut3r_slam_amd.config import production_config, tiny_config
     from cut3r_slam_amd.model import Cut3rModel
     from cut3r_slam_amd.slam import Cut3rSlam
-    from cut3r_slam_amd.weights import synth_state_dict
+    from cut3r_slam_amd import synth
     from cut3r_slam_amd import dist as cdist
 
-    H, W, KF_EVERY, WIN = 384, 512, 10, 5
     WB = max(1, args.window_batch)
     cfg = tiny_config("dpt") if args.small else production_config()
     t0 = time.time()
     torch.set_num_threads(host_cores())
-    sd = synth_state_dict(cfg, seed=0)
+    # random init through the reference key schema; the encoder's residual branches are damped so that patch features stay
+    # content dependent (the overlap-mode keyframe test needs that; cut3r_slam_amd/synth.py) -- no effect on the arithmetic
+    sd = synth.tracking_state_dict(cfg, seed=0, enc_residual_gain=0.1)
     log(f"weights synthesised in {time.time() - t0:.1f}s")
     model = Cut3rModel(cfg, sd, dev, minimal=True)
     torch.cuda.synchronize()
     t_build = time.time() - t0
     log(f"model resident in HBM after {t_build:.1f}s")
-
-    if emu > 1:
-        world = emu                                # after the process-group decisions above: no collective is created
-    frames_per_step = KF_EVERY * WIN * WB          # per rank: one step = WB windows, pushed through the network together
-    total_steps = args.warmup + args.steps
-    probe_steps = 0 if (args.no_roofline or dist_on) else args.steps      # second, instrumented pass
-    n_kf = 7 + WIN * WB * world * (total_steps + probe_steps) + 2
-    config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": KF_EVERY},
-                           "frontend": {"iteration": 0, "window_batch": 1}}}
-    slam = Cut3rSlam(model, config, (H, W), buffer=n_kf + 8, device=dev)
-    intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])  # calib/replica.txt scaled
-    # rank r owns windows [r*WB, (r+1)*WB) of every step; chaining + graph update of step s overlap the network pass of step s+1
-    runner = cdist.ShardedTracker(slam, world, rank, wb=WB, pipelined=os.environ.get("CUT3R_PIPELINE", "1") == "1",
-                                  force_collective=dist_on)
-    runner.emulate_gather = emu > 1
-    frames = synth_frames(runner.frames_needed(total_steps + probe_steps, KF_EVERY, WIN), H, W, dev, seed=0)
-
-    # prologue (untimed): the 6-keyframe initialisation window
-    log(f"{frames.shape[0]} synthetic frames resident; running the initialisation window")
-    t = 0
-    while not slam.keyframes.is_initialized:
-        slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
-        t += 1
-    torch.cuda.synchronize()
-    log("initialised; warmup")
-
-    def one_step(t):
-        return runner.step(frames, t, KF_EVERY, WIN, intr)
 
     def barrier():
         torch.cuda.synchronize()
@@ -182,19 +376,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        t = one_step(t)
-    runner.flush()
-    barrier()
-    log("timed region")
-    for k in runner.stats:
-        runner.stats[k] = 0
-    tic = time.perf_counter()
-    for _ in range(args.steps):
-        t = one_step(t)
-    runner.flush()                       # the timed region holds exactly K network passes and K replays
-    barrier()
-    elapsed = time.perf_counter() - tic
+    if emu > 1:
+        world = emu                                # after the process-group decisions above: no collective is created
+    single = rank == 0 and world == 1 and emu <= 1 and not dist_on
+    probe_steps = args.steps if (single and not args.no_roofline) else 0
+    log("fixed-cadence leg: initialisation window, warmup, timed region")
+    leg = fixed_cadence_leg(model, Cut3rSlam, cdist, dev, WB, args.steps, args.warmup, world, rank, dist_on, emu, probe_steps, barrier)
+    elapsed, slam, runner, frames, t, intr = (leg[k] for k in ("elapsed", "slam", "runner", "frames", "t", "intr"))
+    frames_per_step = leg["frames_per_step"]
     if dist_on:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -207,92 +396,89 @@ def main():
         f"window update {1e3 * TIMING['sync2_s'] / max(1, TIMING['windows']):.2f}")
     log("host wall-clock per step [ms]: " + ", ".join(f"{k[:-2]} {1e3 * v / max(1, runner.stats['steps']):.2f}" for k, v in runner.stats.items() if k != "steps"))
 
-    roofline, cpu_base = None, None
-    if rank == 0 and not args.no_roofline and not dist_on:
-        # second, instrumented pass over the same number of steps: HIP events around every launch of the dominant
-        # kernel (tile-128 MFMA GEMM: encoder linears + DPT convolutions) on the launch stream
-        need = frames_per_step * args.steps
-        if t + need + 1 <= frames.shape[0]:
-            probe = GemmProbe()
-            probe.install()
-            model.use_graphs = False      # events must bracket live launches, not a graph replay
-            for _ in range(args.steps):
-                t = one_step(t)
-            runner.flush()
-            res = probe.result()
-            probe.remove()
-            model.use_graphs = True
-            dom = max(res, key=lambda tk: res[tk][1])          # the kernel with the largest total time in this workload
-            n, ms, fl, by = res[dom]
-            if n:
-                ach = fl / (ms * 1e-3) / 1e12
-                traffic = None
-                pj = os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_gemm{dom}.json")
-                if os.path.isfile(pj):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/pmc_traffic.py)
-                    traffic = json.load(open(pj)).get("traffic_bytes_per_launch")
-                other = {}
-                for tk, (n2, ms2, fl2, by2) in res.items():
-                    if tk != dom and n2:
-                        other = {"kernel": GemmProbe.KERNELS[tk], "launches": n2, "avg_launch_us": round(ms2 * 1e3 / n2, 2),
-                                 "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2), "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / 2500.0, 4),
-                                 "share_of_large_gemm_time": round(ms2 / (ms + ms2), 3)}
-                roofline = {"bound": "mfma", "kernel": GemmProbe.KERNELS[dom], "achieved": round(ach, 2),
-                            "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
-                            "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n,
-                            "algorithmic_bytes_per_launch": by / n, "second_kernel": other}
-    if rank == 0 and world == 1 and emu <= 1 and not args.no_cpu_baseline and not args.small:
-        log("cpu baseline (oracle on host cores)")
-        cpu_base = cpu_baseline(cfg, sd, frames[:2].cpu(), frames_per_step)
-        log("cpu baseline done")
-
     dump = os.environ.get("CUT3R_DUMP_STATE")
     if dump:                               # tests: the replicated result of every rank
-        import numpy as np
         k = slam.tracker.t1
         ii, jj, age = slam.graph.edges_numpy()
         np.savez(f"{dump}.rank{rank}.npz", pose=slam.keyframes.pose[:k].numpy(), depth_sum=slam.keyframes.depth[:k].double().sum(dim=(1, 2)).cpu().numpy(),
                  w2c=slam.keyframes.w2c[:k].cpu().numpy(), ii=ii, jj=jj, k=k)
+
+    roofline, cpu_base, op_points, traj = None, None, None, None
+    if probe_steps:
+        # second, instrumented pass over the same number of steps: HIP events around every launch of the large-tile GEMM
+        # and attention kernels on the launch stream
+        need = frames_per_step * args.steps
+        if t + need + 1 <= frames.shape[0]:
+            probe = KernelProbe()
+            probe.install()
+            model.use_graphs = False      # events must bracket live launches, not a graph replay
+            for _ in range(args.steps):
+                t = runner.step(frames, t, KF_EVERY, WIN, intr)
+            runner.flush()
+            res = probe.result()
+            probe.remove()
+            model.use_graphs = True
+            gem = {k[1]: v for k, v in res.items() if k[0] == "gemm" and v[0]}
+            if gem:
+                dom = max(gem, key=lambda tk: gem[tk][1])          # the GEMM kernel with the largest total time in this workload
+                n, ms, fl, by = gem[dom]
+                ach = fl / (ms * 1e-3) / 1e12
+                tot_ms = sum(v[1] for v in gem.values())
+                others = []
+                for tk, (n2, ms2, fl2, by2) in gem.items():
+                    if tk != dom:
+                        others.append({"kernel": KernelProbe.GEMM[tk], "bound": "mfma", "launches": n2, "avg_launch_us": round(ms2 * 1e3 / n2, 2),
+                                       "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2), "peak": PEAK_F16, "unit": "TFLOP/s",
+                                       "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / PEAK_F16, 4), "share_of_large_gemm_time": round(ms2 / tot_ms, 3)})
+                for k, (n2, ms2, fl2, by2) in sorted((k, v) for k, v in res.items() if k[0] == "attn" and v[0]):
+                    others.append({"kernel": f"attn_kernel<{k[1]},4> ({'encoder self-attention [B,16,768,64]' if k[2] == 'enc' else 'decoder self/cross attention'})",
+                                   "bound": "mfma", "launches": n2, "avg_launch_us": round(ms2 * 1e3 / n2, 2), "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2),
+                                   "peak": PEAK_F16, "unit": "TFLOP/s", "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / PEAK_F16, 4), "flops_per_launch": fl2 / n2})
+                roofline = {"bound": "mfma", "kernel": KernelProbe.GEMM[dom], "achieved": round(ach, 2), "peak": PEAK_F16, "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK_F16, 4), "traffic": None, "traffic_from_profile": traffic_from_profile(dom, n),
+                            "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n,
+                            "algorithmic_bytes_per_launch": by / n, "share_of_large_gemm_time": round(ms / tot_ms, 3),
+                            "second_kernel": others[0] if others else None, "other_kernels": others}
+    if single and not args.small and not args.no_operating_points:
+        log("operating points: fixed cadence with one window at a time")
+        del leg, runner, slam
+        op_points = {}
+        l1 = fixed_cadence_leg(model, Cut3rSlam, cdist, dev, 1, 16, 4, barrier=barrier)
+        op_points["fixed_cadence_window_batch_1"] = {
+            "config": "kf_every=10, window_batch=1: the reference's one-window-at-a-time schedule (50 frames of buffering)",
+            "frames_per_s": round(16 * l1["frames_per_step"] / l1["elapsed"], 1), "ms_per_window": round(1e3 * l1["elapsed"] / 16, 3), "windows": 16}
+        del l1
+        log("operating points: overlap mode (kf_every=-1, skip=5, thresh=0.9)")
+        op_points["overlap_mode"] = overlap_mode_leg(model, Cut3rSlam, dev)
+    if single and not args.no_trajectory_parity:
+        log("trajectory parity leg (medium config, GPU vs CPU oracle)")
+        traj = trajectory_parity_leg(dev)
+    if single and not args.no_cpu_baseline and not args.small:
+        log("cpu baseline (oracle on host cores)")
+        cpu_base = cpu_baseline(cfg, sd, frames[:2].cpu())
+        log("cpu baseline done")
+
     if rank == 0:
         out = {
             "metric": "frames/sec (ViT pointmap + covisibility-graph tracking step) on 640x480" + (f" [DEBUG: rank 0 of an emulated {emu}-GPU job]" if emu > 1 else ""), "value": round(value, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"Replica-shaped 640x480 stream -> 384x512 tracking res; kf_every=10; step = {WB} window(s) "
-                                   f"= {frames_per_step} frames: each new keyframe through the ViT-L encoder once (batched), "
+            "config": {"workload": f"BUFFERED FIXED-CADENCE mode: Replica-shaped 640x480 stream -> 384x512 tracking res; kf_every=10; step = {WB} window(s) "
+                                   f"= {frames_per_step} frames ({frames_per_step} frames of buffering): each new keyframe through the ViT-L encoder once (batched), "
                                    "6-view recurrent decoder + DPT head per window (windows batched through the decoder), "
                                    "log-depth/pose chaining + covisibility-graph update per keyframe; "
-                                   "ViT-L/24 enc, 768/12 dual decoder, DPT head, random init; GS backend off"
+                                   "ViT-L/24 enc, 768/12 dual decoder, DPT head, random init; GS backend off; the reference's own "
+                                   "schedules (one window at a time; overlap mode) are in `operating_points`"
                                    + (" [DEBUG --small]" if args.small else ""),
                        "frames_per_step": frames_per_step, "window_views": 6, "window_batch": WB, "parallelism": f"window-sharded x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu_base, "build_s": round(t_build, 1),
+            "roofline": roofline, "cpu_baseline": cpu_base, "operating_points": op_points, "trajectory_parity": traj,
+            "ate_rmse_m": (traj or {}).get("fixed_cadence_kf_every_2", {}).get("ate_rmse_m"),
+            "build_s": round(t_build, 1), "git_sha": git_sha(),
         }
         print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()
-
-
-def cpu_baseline(cfg, sd, imgs_u8, frames_per_step):
-    """Oracle (kind 'port') timed on the host cores on a BOUNDED sample: one keyframe-filter encode + one 2-view window
-    at 384x512, extrapolated to a step (5 encodes + 6 views; the model cost is linear in views)."""
-    from oracle import cut3r_oracle as O
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    x = O.normalize(imgs_u8)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        O.encode_image(cfg, sd, x[:1])
-        t_enc = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        O.forward_views(cfg, sd, x[:2], minimal=True)
-        t_win2 = time.perf_counter() - t0
-    # same algorithmic work as the GPU path per 50-frame window: 5 new keyframes encoded once + 6 views decoded
-    # (the 2-view sample contains 2 encodes + 2 decodes; the model cost is linear in views)
-    t_dec_view = max(t_win2 - 2 * t_enc, 0.0) / 2
-    window_s = 5 * t_enc + 6 * t_dec_view
-    return {"value": round(50.0 / window_s, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/cut3r_oracle.py fp32: 1 encode_image ({t_enc:.2f} s) + one 2-view window ({t_win2:.2f} s) at "
-                      f"384x512, extrapolated to a 50-frame window = 5 encodes + 6 decoder/head views"}
 
 
 if __name__ == "__main__":
