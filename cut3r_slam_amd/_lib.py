@@ -32,6 +32,11 @@ class GemmDesc(C.Structure):
     ]
 
 
+class LcTerm(C.Structure):
+    """mirror of `cut3r_lc_term` (include/cut3r_hip.h)"""
+    _fields_ = [("a", c_void_p), ("c", c_void_p), ("mask", c_void_p), ("ia", c_int), ("ic", c_int), ("w", c_float), ("pad", c_int)]
+
+
 # name -> argtypes ; every function returns int (0 ok / 1 bad argument / 2 launch failure)
 SIGNATURES = {
     "cut3r_abi_version": [],
@@ -82,6 +87,8 @@ SIGNATURES = {
     "cut3r_lc_workspace_floats": [c_int, c_int],
     "cut3r_lc_optimize": [c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_float,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "cut3r_lc_optimize_terms": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p],
     "cut3r_transform_submaps": [c_void_p, c_void_p, c_int, c_ll, c_void_p],
     "cut3r_corr_index_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "cut3r_corr_index_backward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

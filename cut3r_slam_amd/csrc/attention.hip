@@ -29,8 +29,16 @@ struct AttnArgs {
     float scale_log2;
 };
 
+// Occupancy: the natural allocation of the D <= 64 instances is 190 registers = 2 waves per SIMD, which leaves the matrix pipe
+// idle whenever both waves are in their softmax; bounding them to 3 waves per SIMD (136 registers, no scratch) lets a third
+// workgroup's MFMAs run under it.
+//
+// A key count of the form 64 m + 1 (the decoder's image tokens: 768 patches + the pose token, src/dust3r/model.py:666-667)
+// would need an almost empty 13th key tile.  Instead key 0 is folded in before the loop -- it initialises the online softmax
+// (running max = its score, running sum = 1, O = its value row) -- and the tiles cover keys 1..64 m.  Waves whose 32 query
+// rows lie beyond Nq (the 7th query block of 769 rows has one row) take part in the staging and barriers only.
 template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NW * 64, (D <= 64 && NW == 4) ? 3 : 1) void attn_kernel(const AttnArgs a) {
     constexpr int NTHR = NW * 64;
     constexpr int KT = 64;                       // keys per tile
     constexpr int DQ = D / 16;                   // k-steps of the QK^T product
@@ -70,10 +78,36 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; i++) ot[d][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    const bool active = q0 < a.Nq;               // wave-uniform
+    const int extra = (a.Nk > KT && (a.Nk % KT) == 1) ? 1 : 0;
+    if (extra) {
+        // key 0 first: score = q . k0 (this lane's 8*DQ elements + the partner half's), p = 1
+        float dot = 0.f;
+#pragma unroll
+        for (int s = 0; s < DQ; s++) {
+            const half8_t k0 = *reinterpret_cast<const half8_t*>(kp + 16 * s + 8 * hh);
+#pragma unroll
+            for (int j = 0; j < 8; j++) dot = fmaf((float)qf[s][j], (float)k0[j], dot);
+        }
+        dot += __shfl_xor(dot, 32, 64);
+        m_run = dot * a.scale_log2;
+        l_run = hh == 0 ? 1.f : 0.f;             // the two halves' sums are added at the end
+#pragma unroll
+        for (int d = 0; d < DP; d++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const int dd = d * 32 + 8 * g4 + 4 * hh;
+                if (dd < D) {
+                    const half4_t v0 = *reinterpret_cast<const half4_t*>(vp + dd);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) ot[d][4 * g4 + e] = (float)v0[e];
+                }
+            }
+    }
 
     half8_t rk[NCH], rv[NCH];
     auto load_kv = [&](int t) {
-        const int kbase = t * KT;
+        const int kbase = extra + t * KT;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             int id = tid + c * NTHR;
@@ -101,13 +135,14 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
         }
     };
 
-    const int ntiles = (a.Nk + KT - 1) / KT;
+    const int ntiles = (a.Nk - extra + KT - 1) / KT;
     load_kv(0);
     for (int t = 0; t < ntiles; t++) {
         __syncthreads();
         store_kv();
         __syncthreads();
         if (t + 1 < ntiles) load_kv(t + 1);
+        if (!active) continue;
 
         // ---- S^T = K Q^T for the two 32-key sub-tiles
         f32x16 st[2];
@@ -122,7 +157,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
             }
         }
         // ---- online softmax (per query column == per lane; partner lane^32 holds the other 32 keys)
-        const int kbase = t * KT;
+        const int kbase = extra + t * KT;
         float mloc = -INFINITY;
         if (kbase + KT <= a.Nk) {                 // full tile: no masking
 #pragma unroll

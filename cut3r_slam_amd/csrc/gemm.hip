@@ -53,23 +53,19 @@ template <int N>
 DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Fused output of 4 consecutive columns (gn..gn+3) of row gm: bias, GELU|ReLU, up to two residuals, fp16|fp32 store,
-// optional ConvTranspose pixel-shuffle scatter.  Shared by every GEMM kernel of this file.
-DEVINL void fused_store4(const GemmArgs& g, int z, const float* bias, int gm, int gn, f32x4 v) {
-    int bcol = gn;
-    size_t orow_off;
-    if (g.shuf) {
-        const int ij = gn / g.shuf_cout;
-        bcol = gn - ij * g.shuf_cout;
-        const int i_ = ij / g.shuf, j_ = ij - i_ * g.shuf;
-        const int hw = g.shuf_Hin * g.shuf_Win;
-        const int b = gm / hw, rem = gm - b * hw;
-        const int y = rem / g.shuf_Win, x = rem - y * g.shuf_Win;
-        orow_off = (((size_t)b * g.shuf_Hin * g.shuf + (y * g.shuf + i_)) * (g.shuf_Win * g.shuf) + (x * g.shuf + j_)) *
-                       (size_t)g.ldc + bcol;
-    } else {
-        orow_off = (size_t)gm * g.ldc + gn;
+// optional ConvTranspose pixel-shuffle scatter.  Shared by every GEMM kernel of this file.  The residual operands are
+// LOADED by load_res4 (so an epilogue can issue the loads of several rows before it consumes any: a dependent global load
+// per row was the largest single cost of the short-K launches) and applied by fused_finish4 in a fixed order: bias,
+// activation, res1, res2.
+DEVINL f32x4 load_res4(const void* res, int is_f16, size_t off) {
+    if (is_f16) {
+        const half4_t rv = *reinterpret_cast<const half4_t*>((const h16*)res + off);
+        return f32x4{(float)rv[0], (float)rv[1], (float)rv[2], (float)rv[3]};
     }
-    if (bias) v += *reinterpret_cast<const f32x4*>(bias + bcol);
+    return *reinterpret_cast<const f32x4*>((const float*)res + off);
+}
+DEVINL f32x4 fused_finish4(const GemmArgs& g, f32x4 v, const f32x4& b4, bool has_bias, const f32x4& r1, const f32x4& r2) {
+    if (has_bias) v += b4;
     if (g.act == 1) {
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] = g.out_f16 ? gelu_fast(v[e]) : gelu_erf(v[e]);
@@ -77,30 +73,39 @@ DEVINL void fused_store4(const GemmArgs& g, int z, const float* bias, int gm, in
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
     }
-    if (g.res1) {
-        if (g.res1_f16) {
-            half4_t rv = *reinterpret_cast<const half4_t*>((const h16*)g.res1 + (size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn);
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] += (float)rv[e];
-        } else {
-            v += *reinterpret_cast<const f32x4*>((const float*)g.res1 + (size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn);
-        }
+    if (g.res1) v += r1;
+    if (g.res2) v += r2;
+    return v;
+}
+DEVINL size_t out_offset4(const GemmArgs& g, int gm, int gn, int& bcol) {
+    bcol = gn;
+    if (g.shuf) {
+        const int ij = gn / g.shuf_cout;
+        bcol = gn - ij * g.shuf_cout;
+        const int i_ = ij / g.shuf, j_ = ij - i_ * g.shuf;
+        const int hw = g.shuf_Hin * g.shuf_Win;
+        const int b = gm / hw, rem = gm - b * hw;
+        const int y = rem / g.shuf_Win, x = rem - y * g.shuf_Win;
+        return (((size_t)b * g.shuf_Hin * g.shuf + (y * g.shuf + i_)) * (g.shuf_Win * g.shuf) + (x * g.shuf + j_)) * (size_t)g.ldc + bcol;
     }
-    if (g.res2) {
-        if (g.res2_f16) {
-            half4_t rv = *reinterpret_cast<const half4_t*>((const h16*)g.res2 + (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn);
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] += (float)rv[e];
-        } else {
-            v += *reinterpret_cast<const f32x4*>((const float*)g.res2 + (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn);
-        }
-    }
+    return (size_t)gm * g.ldc + gn;
+}
+DEVINL void store_out4(const GemmArgs& g, int z, size_t orow_off, f32x4 v) {
     if (g.out_f16) {
         half4_t o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
         *reinterpret_cast<half4_t*>((h16*)g.C + (size_t)z * g.sC + orow_off) = o;
     } else {
         *reinterpret_cast<f32x4*>((float*)g.C + (size_t)z * g.sC + orow_off) = v;
     }
+}
+DEVINL void fused_store4(const GemmArgs& g, int z, const float* bias, int gm, int gn, f32x4 v) {
+    int bcol;
+    const size_t orow_off = out_offset4(g, gm, gn, bcol);
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, r1 = b4, r2 = b4;
+    if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + bcol);
+    if (g.res1) r1 = load_res4(g.res1, g.res1_f16, (size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn);
+    if (g.res2) r2 = load_res4(g.res2, g.res2_f16, (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn);
+    store_out4(g, z, orow_off, fused_finish4(g, v, b4, bias != nullptr, r1, r2));
 }
 
 // Fused 2-D RoPE of 4 consecutive output columns gn..gn+3 (< rope_cols) of row gm, head dimension D = 64 or 48 (quarter
@@ -157,7 +162,8 @@ DEVINL void xcd_tile(int orig, int npm, int npn, int& pid_m, int& pid_n) {
 // fetches chunk (l&7)^(l>>3)), and again on the read side.  NSTAGE-deep ring, counted vmcnt, ONE raw s_barrier per
 // K-tile: NSTAGE-2 tiles stay in flight across the barrier.
 template <int BM, int BN, int NSTAGE, int WAVES_M = 2, int WAVES_N = 2>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const GemmArgs g) {
+// (8-wave tiles whose LDS lets two workgroups share a CU are held to 128 VGPRs: 4 waves per SIMD)
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8 && (BM + BN) * BK * 2 * NSTAGE <= 81920) ? 4 : 1) void gemm_kernel(const GemmArgs g) {
     constexpr int NWAVE = WAVES_M * WAVES_N;
     constexpr int NTHR = 64 * NWAVE;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
@@ -308,15 +314,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     }
     __syncthreads();
 
-    // ---- epilogue: accumulators -> LDS (fp32) -> coalesced fused store, one row band per pass
+    // ---- epilogue: accumulators -> LDS (fp32) -> coalesced fused store, one row band per pass.  The residual rows a thread
+    // will add are loaded BEFORE the band is staged (their latency overlaps the staging and the barrier).
     float* cs = reinterpret_cast<float*>(smem);
     const float* bias = g.bias ? g.bias + (size_t)z * g.sBias : nullptr;
     constexpr int TPR = BN / 4;               // threads per output row (4 columns each)
     constexpr int RPP = NTHR / TPR;           // rows per pass
+    constexpr int ITER = (EPI_ROWS + RPP - 1) / RPP;
+    // residual rows in flight per thread (registers: the 8-wave tiles must stay <= 128 VGPRs, see the launch bounds)
+    constexpr int PF = (MT * NT >= 12) ? 2 : (ITER < 4 ? ITER : 4);
     const int c4 = (tid % TPR) * 4;
     const int gn = n0 + c4;
+    const int r0 = tid / TPR;
+    const bool col_ok = gn < N && tid < RPP * TPR;          // (TPR need not divide the block: 128x192 has 48 threads per row)
+    const bool plain = !g.shuf && g.rope_cols == 0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 b4 = zero4;
+    if (bias && col_ok && plain) b4 = *reinterpret_cast<const f32x4*>(bias + gn);
 #pragma unroll
     for (int p = 0; p < EPI_PASSES; p++) {
+        f32x4 r1v[PF];
+        auto load_r1 = [&](int i) {
+            const int r = r0 + i * RPP;
+            const int gm = m0 + p * EPI_ROWS + r;
+            return (r < EPI_ROWS && gm < M) ? load_res4(g.res1, g.res1_f16, (size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn) : zero4;
+        };
+        if (plain && col_ok && g.res1) {
+#pragma unroll
+            for (int i = 0; i < PF; i++) r1v[i] = load_r1(i);
+        }
         if (p > 0) __syncthreads();           // the previous band has been read
 #pragma unroll
         for (int i = 0; i < MT; i++)
@@ -329,13 +355,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
                     if (EPI_PASSES == 1 || (r >= 0 && r < EPI_ROWS)) cs[r * CPAD + c] = acc[i][j][e];
                 }
         __syncthreads();
-        if (gn < N && tid < RPP * TPR) {          // (TPR need not divide the block: 128x192 has 48 threads per row)
-            for (int r = tid / TPR; r < EPI_ROWS; r += RPP) {
-                const int gm = m0 + p * EPI_ROWS + r;
-                if (gm >= M) break;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
-                if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, cs + r * CPAD, c4);
-                else fused_store4(g, z, bias, gm, gn, v);
+        if (col_ok) {
+            if (plain) {
+#pragma unroll
+                for (int i = 0; i < ITER; i++) {
+                    const int r = r0 + i * RPP;
+                    const int gm = m0 + p * EPI_ROWS + r;
+                    f32x4 r1 = zero4;
+                    if (g.res1) {
+                        r1 = r1v[i % PF];
+                        if (i + PF < ITER) r1v[i % PF] = load_r1(i + PF);
+                    }
+                    if (r < EPI_ROWS && gm < M) {
+                        const f32x4 r2 = g.res2 ? load_res4(g.res2, g.res2_f16, (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn) : zero4;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
+                        store_out4(g, z, (size_t)gm * g.ldc + gn, fused_finish4(g, v, b4, bias != nullptr, r1, r2));
+                    }
+                }
+            } else {
+                for (int r = r0; r < EPI_ROWS; r += RPP) {
+                    const int gm = m0 + p * EPI_ROWS + r;
+                    if (gm >= M) break;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
+                    if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, cs + r * CPAD, c4);
+                    else fused_store4(g, z, bias, gm, gn, v);
+                }
             }
         }
     }
@@ -534,34 +578,101 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) {
 
     // ---- epilogue: per-wave staging (32 rows x 64 columns per pass) in this wave's private 16 KiB
     // (measured alternative: operand-swapped MFMAs + direct 8-byte stores from the accumulators -- 32-B row segments,
-    //  +8 us per tile)
+    //  +8 us per tile).  Residual rows are loaded before the band is staged (a dependent global load per row made this
+    //  epilogue 1.8x the K = 1024 main loop); fp16 outputs leave as 16-byte stores (8 columns per lane: stores are
+    //  issue-bound, half the instructions).  Per-element arithmetic is the same in every variant.
     constexpr int CP = 68;
     float* cs = reinterpret_cast<float*>(smem + wave * 16384);
     const float* bias = g.bias ? g.bias + (size_t)z * g.sBias : nullptr;
-    const int er = lane >> 4, ec = (lane & 15) * 4;
-    const int gn = n0 + wc * 64 + ec;
+    const bool plain = !g.shuf && g.rope_cols == 0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (plain && g.out_f16 && !g.res2 && (N & 7) == 0 && (g.ldc & 7) == 0) {
+        const int er = lane >> 3, ec = (lane & 7) * 8;
+        const int gn = n0 + wc * 64 + ec;
+        const bool col_ok = gn + 8 <= N;
+        f32x4 b0 = zero4, b1 = zero4;
+        if (bias && col_ok) { b0 = *reinterpret_cast<const f32x4*>(bias + gn); b1 = *reinterpret_cast<const f32x4*>(bias + gn + 4); }
 #pragma unroll
-    for (int mp = 0; mp < 4; mp++) {
+        for (int mp = 0; mp < 4; mp++) {
+            f32x4 ra[4], rb[4];
+            if (g.res1 && col_ok) {
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) cs[(i * 16 + fq * 4 + e) * CP + j * 16 + fr] = acc[mp * 2 + i][j][e];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (gn < N) {
-#pragma unroll EPI_UNROLL
-            for (int it = 0; it < 8; it++) {
-                const int rr = it * 4 + er;
-                const int gm = m0 + wr * 128 + mp * 32 + rr;
-                if (gm < M) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec);
-                    if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, cs + rr * CP, ec);
-                    else fused_store4(g, z, bias, gm, gn, v);
+                for (int it = 0; it < 4; it++) {
+                    const int gm = m0 + wr * 128 + mp * 32 + it * 8 + er;
+                    const size_t off = (size_t)z * g.sR1 + (size_t)min(gm, M - 1) * g.ldr1 + gn;
+                    ra[it] = load_res4(g.res1, g.res1_f16, off);
+                    rb[it] = load_res4(g.res1, g.res1_f16, off + 4);
                 }
             }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) cs[(i * 16 + fq * 4 + e) * CP + j * 16 + fr] = acc[mp * 2 + i][j][e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (col_ok) {
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int rr = it * 8 + er;
+                    const int gm = m0 + wr * 128 + mp * 32 + rr;
+                    if (gm < M) {
+                        const f32x4 v0 = fused_finish4(g, *reinterpret_cast<const f32x4*>(cs + rr * CP + ec), b0, bias != nullptr, ra[it], zero4);
+                        const f32x4 v1 = fused_finish4(g, *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + 4), b1, bias != nullptr, rb[it], zero4);
+                        half8_t o = {(h16)v0[0], (h16)v0[1], (h16)v0[2], (h16)v0[3], (h16)v1[0], (h16)v1[1], (h16)v1[2], (h16)v1[3]};
+                        *reinterpret_cast<half8_t*>((h16*)g.C + (size_t)z * g.sC + (size_t)gm * g.ldc + gn) = o;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+        const int er = lane >> 4, ec = (lane & 15) * 4;
+        const int gn = n0 + wc * 64 + ec;
+        f32x4 b4 = zero4;
+        if (bias && gn < N && plain) b4 = *reinterpret_cast<const f32x4*>(bias + gn);
+#pragma unroll
+        for (int mp = 0; mp < 4; mp++) {
+            f32x4 r1v[8], r2v[8];
+            if (plain && gn < N) {
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const int gm = min(m0 + wr * 128 + mp * 32 + it * 4 + er, M - 1);
+                    r1v[it] = g.res1 ? load_res4(g.res1, g.res1_f16, (size_t)z * g.sR1 + (size_t)gm * g.ldr1 + gn) : zero4;
+                    r2v[it] = g.res2 ? load_res4(g.res2, g.res2_f16, (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn) : zero4;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) cs[(i * 16 + fq * 4 + e) * CP + j * 16 + fr] = acc[mp * 2 + i][j][e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (gn < N) {
+                if (plain) {
+#pragma unroll
+                    for (int it = 0; it < 8; it++) {
+                        const int rr = it * 4 + er;
+                        const int gm = m0 + wr * 128 + mp * 32 + rr;
+                        if (gm < M)
+                            store_out4(g, z, (size_t)gm * g.ldc + gn,
+                                       fused_finish4(g, *reinterpret_cast<const f32x4*>(cs + rr * CP + ec), b4, bias != nullptr, r1v[it], r2v[it]));
+                    }
+                } else {
+                    for (int it = 0; it < 8; it++) {
+                        const int rr = it * 4 + er;
+                        const int gm = m0 + wr * 128 + mp * 32 + rr;
+                        if (gm < M) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec);
+                            if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, cs + rr * CP, ec);
+                            else fused_store4(g, z, bias, gm, gn, v);
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     }
 #undef CUT3R_BARRIER
 }
@@ -690,12 +801,14 @@ extern "C" int cut3r_gemm_tile_for(const cut3r_gemm_desc* d) {
     // measured (tools/bench_gemm256.py, tools/bench_gemm.py): the 256^2 ping-pong kernel wins once its grid fills the
     // chip (>= 200 tiles) on plain linears with N a multiple of 256; 3x3 convolutions and short grids stay on 128^2
     // (two co-resident workgroups hide each other's prologue / epilogue); 64^2 below 128 tiles of 128^2
-    static const long long t256_min = [] { const char* e = getenv("CUT3R_GEMM_T256_MIN"); return e ? atoll(e) : 200LL; }();
+    static const long long t256_min = [] { const char* e = getenv("CUT3R_GEMM_T256_MIN"); return e ? atoll(e) : 128LL; }();
     const long long blocks256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
-    // one workgroup per CU: a grid of 300 tiles costs two full rounds, so also require >= 85 % of the last round
+    // one workgroup per CU: a grid of 300 tiles costs two full rounds, so beyond one round require >= 85 % of the last one
+    // (round 2, tools/bench_gemm_r2.py: from 128 tiles the 256^2 kernel beats 128^2 by 20-25 % on K = 768 / 1536 projections;
+    //  at 72 tiles it loses by 50 %)
     const long long rounds = (blocks256 + 255) / 256;
     static const long long fill_pct = [] { const char* e = getenv("CUT3R_GEMM_T256_FILL"); return e ? atoll(e) : 85LL; }();
-    const bool fills = blocks256 * 100 >= rounds * 256 * fill_pct;
+    const bool fills = rounds == 1 || blocks256 * 100 >= rounds * 256 * fill_pct;
     if (d->conv_k != 3 && !d->shuf && (d->N & 255) == 0 && blocks256 >= t256_min && fills) return 256;
     // 192 x 128 (48 x 64 per wave: fewer LDS reads and L2->LDS bytes per FLOP than 128^2, still two workgroups per CU):
     // alone +19 % on the M~6k x 1536 decoder projections and +9 % on the DPT 3x3 convolutions, but inside the tracking

@@ -137,6 +137,121 @@ __global__ void lc_adam_kernel(const float* __restrict__ partial, int nblk, int 
     for (int k = 0; k < 12; k++) T[(size_t)b * 12 + k] = Mf[k];
 }
 
+// ------------------------------------------------------------------------------------------------ general term list
+// Later loop closures (track_backend.py:400-461) add two families of residuals to the chain term: every re-tracked "lc"
+// submap k has its own se(3) (matched_lie) and is tied (i) by its first map to the first map of the submap it matched and (ii)
+// by its last map to the current keyframe's map as seen from that keyframe's submap.  All of them are the same shape:
+//     w * sum_n | T[ia] a_n - T[ic] c_n |_1          (T[0] = identity, fixed; every other transform is a parameter)
+// so one kernel evaluates a LIST of such terms (device array of LcTerm) and the Adam kernel gathers, per parameter, the
+// partial rows of the terms that reference it, in term order (deterministic).
+struct LcTerm {
+    const float* a; const float* c; const unsigned char* mask;
+    int ia, ic; float w; int pad;
+};
+
+__global__ __launch_bounds__(LC_BLOCK) void lc_terms_accum_kernel(const LcTerm* __restrict__ terms, const float* __restrict__ T, int N,
+                                                                  float* __restrict__ partial, int nblk) {
+    __shared__ float red[4][LC_ROW];
+    const LcTerm tm = terms[blockIdx.y];
+    const float* Ta = T + 12 * tm.ia;
+    const float* Tc = T + 12 * tm.ic;
+    float acc[LC_ROW];
+#pragma unroll
+    for (int k = 0; k < LC_ROW; k++) acc[k] = 0.f;
+    const int base = blockIdx.x * (LC_BLOCK * LC_PPT) + threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < LC_PPT; it++) {
+        const int n = base + it * LC_BLOCK;
+        if (n >= N) break;
+        if (tm.mask && !tm.mask[n]) continue;
+        const float ax = tm.a[3 * (size_t)n], ay = tm.a[3 * (size_t)n + 1], az = tm.a[3 * (size_t)n + 2];
+        const float cx = tm.c[3 * (size_t)n], cy = tm.c[3 * (size_t)n + 1], cz = tm.c[3 * (size_t)n + 2];
+        float a0, a1, a2, c0, c1, c2;
+        apply34(Ta, ax, ay, az, a0, a1, a2);
+        apply34(Tc, cx, cy, cz, c0, c1, c2);
+        const float r0 = a0 - c0, r1 = a1 - c1, r2 = a2 - c2;
+        const float s0 = sgn(r0), s1 = sgn(r1), s2 = sgn(r2);
+        acc[24] += fabsf(r0) + fabsf(r1) + fabsf(r2);
+        acc[0] += s0 * ax; acc[1] += s0 * ay; acc[2] += s0 * az; acc[3] += s0;
+        acc[4] += s1 * ax; acc[5] += s1 * ay; acc[6] += s1 * az; acc[7] += s1;
+        acc[8] += s2 * ax; acc[9] += s2 * ay; acc[10] += s2 * az; acc[11] += s2;
+        acc[12] -= s0 * cx; acc[13] -= s0 * cy; acc[14] -= s0 * cz; acc[15] -= s0;
+        acc[16] -= s1 * cx; acc[17] -= s1 * cy; acc[18] -= s1 * cz; acc[19] -= s1;
+        acc[20] -= s2 * cx; acc[21] -= s2 * cy; acc[22] -= s2 * cz; acc[23] -= s2;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 25; k++) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 25) {
+        const int k = threadIdx.x;
+        partial[((size_t)blockIdx.y * nblk + blockIdx.x) * LC_ROW + k] = (red[0][k] + red[1][k] + red[2][k] + red[3][k]) * tm.w;
+    }
+}
+
+// one thread per transform p = 1..P-1 (p = 0 is the fixed identity and reports the loss)
+__global__ void lc_terms_adam_kernel(const LcTerm* __restrict__ terms, int n_terms, const float* __restrict__ partial, int nblk, int P,
+                                     float* __restrict__ xi, float* __restrict__ m, float* __restrict__ v, float* __restrict__ T,
+                                     float* __restrict__ loss_out, int step, AdamHyper h) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) {
+        float L = 0.f;
+        for (int t = 0; t < n_terms; t++)
+            for (int k = 0; k < nblk; k++) L += partial[((size_t)t * nblk + k) * LC_ROW + 24];
+        if (loss_out) loss_out[step] = L;
+        return;
+    }
+    if (b >= P) return;
+    float G[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) G[k] = 0.f;
+    for (int t = 0; t < n_terms; t++) {
+        const int ia = terms[t].ia, ic = terms[t].ic;
+        if (ia != b && ic != b) continue;
+        for (int k = 0; k < nblk; k++) {
+            const float* row = partial + ((size_t)t * nblk + k) * LC_ROW;
+            if (ia == b) {
+#pragma unroll
+                for (int e = 0; e < 12; e++) G[e] += row[e];
+            }
+            if (ic == b) {
+#pragma unroll
+                for (int e = 0; e < 12; e++) G[e] += row[12 + e];
+            }
+        }
+    }
+    typedef Dual<6> D;
+    D a[6], X[7], M[16];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { a[k] = D(xi[(size_t)b * 6 + k]); a[k].d[k] = 1.f; }
+    f_exp<1, D>(a, X);
+    f_matrix<1, D>(X, M);
+    const float bc1 = 1.f - powf(h.b1, (float)(step + 1)), bc2 = 1.f - powf(h.b2, (float)(step + 1));
+    float nx[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        float g = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) g += G[r * 4 + c] * M[r * 4 + c].d[j];
+        const float mj = h.b1 * m[(size_t)b * 6 + j] + (1.f - h.b1) * g;
+        const float vj = h.b2 * v[(size_t)b * 6 + j] + (1.f - h.b2) * g * g;
+        m[(size_t)b * 6 + j] = mj;
+        v[(size_t)b * 6 + j] = vj;
+        nx[j] = xi[(size_t)b * 6 + j] - (h.lr / bc1) * mj / (sqrtf(vj) / sqrtf(bc2) + h.eps);
+        xi[(size_t)b * 6 + j] = nx[j];
+    }
+    float Xf[7], Mf[16];
+    f_exp<1, float>(nx, Xf);
+    f_matrix<1, float>(Xf, Mf);
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[(size_t)b * 12 + k] = Mf[k];
+}
+
 // in-place p <- T_b p over every pointmap of submap b (the rewrite at track_backend.py:306-310)
 __global__ __launch_bounds__(256) void transform_submaps_kernel(float* __restrict__ pts, const float* __restrict__ T, long long per_sub) {
     const int b = blockIdx.y;
@@ -170,6 +285,23 @@ extern "C" int cut3r_lc_optimize(const float* first, const float* last, long lon
         hipLaunchKernelGGL(lc_accum_kernel, dim3(nblk, B), dim3(LC_BLOCK), 0, s, first, last, sub_stride, mask, cur, cur_lc, T, B, N,
                            w_fl, w_cur, workspace, nblk);
         hipLaunchKernelGGL(lc_adam_kernel, dim3((B + 63) / 64), dim3(64), 0, s, workspace, nblk, B, xi, adam_m, adam_v, T, loss_out, it, h);
+    }
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_lc_optimize_terms(const void* terms_dev, int n_terms, int P, int N, int iters, float lr, float* xi, float* adam_m,
+                                       float* adam_v, float* T, float* workspace, float* loss_out, void* stream) {
+    static_assert(sizeof(LcTerm) == sizeof(cut3r_lc_term), "cut3r_lc_term layout");
+    if (!terms_dev || !xi || !adam_m || !adam_v || !T || !workspace) return CUT3R_ERR_ARG;
+    if (n_terms < 1 || P < 2 || N <= 0 || iters < 0) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (N + LC_BLOCK * LC_PPT - 1) / (LC_BLOCK * LC_PPT);
+    AdamHyper h{lr, 0.9f, 0.999f, 1e-8f};
+    const LcTerm* terms = (const LcTerm*)terms_dev;
+    for (int it = 0; it < iters; it++) {
+        hipLaunchKernelGGL(lc_terms_accum_kernel, dim3(nblk, n_terms), dim3(LC_BLOCK), 0, s, terms, T, N, workspace, nblk);
+        hipLaunchKernelGGL(lc_terms_adam_kernel, dim3((P + 63) / 64), dim3(64), 0, s, terms, n_terms, workspace, nblk, P, xi, adam_m, adam_v, T,
+                           loss_out, it, h);
     }
     return cut3r_check_launch();
 }

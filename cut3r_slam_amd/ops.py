@@ -539,6 +539,38 @@ def lc_optimize(submaps, mask, cur, cur_lc, iters, lr=5e-4, return_loss=False):
     return (xi, T, loss) if return_loss else (xi, T)
 
 
+def lc_optimize_terms(terms, P, N, iters, lr=5e-4, return_loss=False):
+    """Fused Adam over P-1 se(3) vectors for a list of L1 terms (track_backend.py:400-461).  terms: list of
+    (a [N,3] fp32 cuda, ia, c [N,3] fp32 cuda, ic, weight, mask uint8 [N] | None) with transform indices in [0, P), 0 = the
+    fixed identity.  Returns (xi [P,6], T [P,3,4]) (+ per-iteration loss)."""
+    _req(len(terms) >= 1 and P >= 2, "at least one term and one free transform")
+    keep = []
+    arr = (_lib.LcTerm * len(terms))()
+    dev = terms[0][0].device
+    for t, (a, ia, c, ic, w, mask) in enumerate(terms):
+        _cuda(a, c, mask)
+        _req(a.dtype == F32 and c.dtype == F32 and a.is_contiguous() and c.is_contiguous() and a.numel() == 3 * N and c.numel() == 3 * N,
+             "term operands: contiguous fp32 [N,3]")
+        _req(0 <= ia < P and 0 <= ic < P, "transform index out of range")
+        if mask is not None:
+            _req(mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == N, "mask uint8 [N]")
+        arr[t].a, arr[t].c, arr[t].mask = a.data_ptr(), c.data_ptr(), (mask.data_ptr() if mask is not None else None)
+        arr[t].ia, arr[t].ic, arr[t].w, arr[t].pad = int(ia), int(ic), float(w), 0
+        keep.append((a, c, mask))
+    raw = bytes(arr)
+    terms_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    lib = _lib.load()
+    xi = torch.zeros(P, 6, device=dev)
+    m, v = torch.zeros_like(xi), torch.zeros_like(xi)
+    T = torch.eye(4, device=dev)[:3].reshape(1, 12).repeat(P, 1).contiguous()
+    ws = torch.empty(lib.cut3r_lc_workspace_floats(len(terms), N), device=dev)
+    loss = torch.zeros(max(iters, 1), device=dev) if return_loss else None
+    check(lib.cut3r_lc_optimize_terms(_p(terms_dev), len(terms), int(P), int(N), int(iters), float(lr), _p(xi), _p(m), _p(v), _p(T), _p(ws),
+                                      _p(loss), _stream()), "cut3r_lc_optimize_terms")
+    T = T.view(P, 3, 4)
+    return (xi, T, loss) if return_loss else (xi, T)
+
+
 def transform_submaps(submaps, T):
     """in place: every point of submap b <- T[b] (3x4) applied (track_backend.py:301-310)."""
     _cuda(submaps, T)

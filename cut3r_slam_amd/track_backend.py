@@ -5,7 +5,8 @@
   NMS       : 0.8 * mean(bidirectional reprojection overlap) + 0.2 * patch-feature overlap, accept if > 0.4
   re-track  : 6-view inference over [5 keyframes of the matched submap, current keyframe], chained to the anchor
   optimise  : first loop  -> fused HIP Adam over per-submap se(3) (ops.lc_optimize: 2 launches / iteration)
-              later loops -> same objective plus the matched-submap terms, through cut3r_slam_amd.lietorch autograd
+              later loops -> chain + matched-submap + current-vs-lc terms, the same fused optimiser over a term list
+                             (ops.lc_optimize_terms), Adam over the submap AND the lc-submap corrections
   rewrite   : every pointmap of every corrected submap in place (ops.transform_submaps) + the 7-float poses
 """
 from __future__ import annotations
@@ -46,7 +47,10 @@ class TrackBackend:
             ops.patch_overlap_count(f0.contiguous(), f1.contiguous(), thr, self._ws, counts[i:i + 1])
         return counts.float() / float(N - 1)
 
-    def nms(self, ids_matched, idx_current, K4, th=0.4):
+    def nms_scores(self, ids_matched, idx_current, K4):
+        """scores [B] of the loop candidates `ids_matched` for keyframe idx_current (factor_graph.py:561-577):
+        0.8 * mean(overlap of the candidates' maps in the current camera, overlap of the current map in the candidates'
+        cameras) + 0.2 * patch-feature overlap (compute_feature_overlap_batch, :328-341).  Returned on the host."""
         kf = self.keyframes
         h, w = kf.submap_ds.shape[2], kf.submap_ds.shape[3]
         ids = torch.as_tensor(np.asarray(ids_matched), dtype=torch.long)
@@ -59,7 +63,10 @@ class TrackBackend:
         ops.overlap_fwd(pm_cur, kf.w2c[ids.to(kf.w2c.device)].contiguous(), K4, w, h, c2a, clamp_z=False)
         feat = self._feat_overlap(kf.featI[idx_current], [kf.featI[int(i)] for i in ids])
         overlap = (a2c.float() / (h * w) + c2a.float() / (h * w)) / 2
-        scores = (0.8 * overlap + 0.2 * feat).cpu()
+        return (0.8 * overlap + 0.2 * feat).cpu()
+
+    def nms(self, ids_matched, idx_current, K4, th=0.4):
+        scores = self.nms_scores(ids_matched, idx_current, K4)
         if float(scores.max()) > th:
             return int(torch.argmax(scores))
         return None
@@ -141,53 +148,46 @@ class TrackBackend:
             updates["loss"] = res[2]
         return updates
 
-    def loop_closure(self, pointmaps_lc, idx_matched, idx_current):
-        """later loops (track_backend.py:361-524): adds the matched-submap terms; torch expressions over the HIP Lie
-        ops (cut3r_slam_amd.lietorch) with autograd -- not fused yet."""
-        kf, dev = self.keyframes, self.device
+    def loop_closure(self, pointmaps_lc, idx_matched, idx_current, return_loss=False):
+        """Second and later loops (track_backend.py:361-524): Adam over the per-submap corrections `_align_lie` [B-1,6] AND one
+        se(3) per re-tracked "lc" submap (`matched_lie` [Bc,6]) on three L1 terms -- the chain of first/last maps (:447), each
+        lc submap's first map against the first map of the submap it matched (:449) and each loop's current map against
+        the last map of its lc submap (:451).  One fused HIP optimiser call (ops.lc_optimize_terms: two launches per iteration)
+        over the resident stores; returns (aligned lc submap of THIS loop [6,h,w,3], updates) like the reference."""
+        kf = self.keyframes
         sub1 = idx_current // 5
-        block = kf.submap_ds[0:sub1 + 1]
+        block = kf.submap_ds[0:sub1 + 1]                                                 # [B,6,h,w,3] view of the resident store
         B, N6, h, w, _ = block.shape
-        fl = torch.stack([block[:, 0], block[:, -1]], dim=1).reshape(B, 2, -1, 3)
-        prev_cur = np.array(self.closed_loop["idx_current"])
+        N = h * w
+        prev_cur = np.array(self.closed_loop["idx_current"], dtype=np.int64)
         sub_cur_all = np.append(prev_cur // 5, sub1)
-        pm_cur = torch.cat([kf.submap_ds[prev_cur // 5, prev_cur % 5], kf.submap_ds[sub1, idx_current % 5][None]], 0)
-        lc_all = torch.cat([torch.stack(self.closed_loop["pointmaps_lc"], 0), pointmaps_lc[None]], 0).float()
-        lc_fl = torch.stack([lc_all[:, 0], lc_all[:, -1]], dim=1)
+        pm_cur = torch.cat([kf.submap_ds[torch.as_tensor(prev_cur // 5), torch.as_tensor(prev_cur % 5)],
+                            kf.submap_ds[sub1, idx_current % 5][None]], 0).contiguous()                     # [Bc,h,w,3] global frame
+        lc_all = torch.cat([torch.stack(self.closed_loop["pointmaps_lc"], 0), pointmaps_lc[None]], 0).float().contiguous()   # [Bc,6,h,w,3]
         Bc = lc_all.shape[0]
-        sub_matched_all = np.append(np.array(self.closed_loop["idx_matched"]) // 5, idx_matched // 5)
-        with torch.enable_grad():
-            a_lie = torch.nn.Parameter(torch.zeros(B - 1, 6, device=dev))
-            m_lie = torch.nn.Parameter(torch.zeros(Bc, 6, device=dev))
-            opt = torch.optim.Adam([{"params": a_lie, "lr": 5e-4}, {"params": m_lie, "lr": 5e-4}])
-            lie0 = torch.zeros(1, 6, device=dev)
-            sc = torch.as_tensor(sub_cur_all, device=dev)
-            sm = torch.as_tensor(sub_matched_all, device=dev)
-            for _ in range(self.loop_iters):
-                opt.zero_grad()
-                T = SE3.exp(torch.cat([lie0, a_lie], 0)).matrix()
-                R, t = T[:, :3, :3], T[:, :3, 3].unsqueeze(1)
-                Tm = SE3.exp(m_lie).matrix()
-                Rm, tm = Tm[:, :3, :3], Tm[:, :3, 3].unsqueeze(1)
-                fla = torch.matmul(fl, R.transpose(1, 2).unsqueeze(1)) + t.unsqueeze(1)
-                lca = torch.matmul(lc_fl.reshape(Bc, 2, -1, 3), Rm.transpose(1, 2).unsqueeze(1)) + tm.unsqueeze(1)
-                cura = torch.matmul(pm_cur.reshape(Bc, -1, 3), R[sc].transpose(1, 2)) + t[sc]
-                loss = (fla[:-1, -1] - fla[1:, 0]).abs().mean() + (lca[:, 0] - fla[sm, 0]).abs().mean() + \
-                    (cura - lca[:, -1]).abs().mean()
-                loss.backward()
-                opt.step()
-        with torch.no_grad():
-            se3 = SE3.exp(torch.cat([lie0, a_lie.detach()], 0))
-            T = se3.matrix()[:, :3, :4].contiguous()
-            Tm = SE3.exp(m_lie.detach()).matrix()
-            new_pose = self._rewrite(0, sub1, T)
-            lc_al = torch.matmul(lc_all.reshape(Bc, N6, -1, 3), Tm[:, :3, :3].transpose(1, 2).unsqueeze(1)) + Tm[:, :3, 3].reshape(Bc, 1, 1, 3)
-            lc_al = lc_al.reshape(Bc, N6, h, w, 3)
-            for i in range(Bc - 1):
-                self.closed_loop["pointmaps_lc"][i] = lc_al[i]
+        sub_matched_all = np.append(np.array(self.closed_loop["idx_matched"], dtype=np.int64) // 5, idx_matched // 5)
+        # transform table: 0..B-1 = submap corrections (0 fixed = lie_0), B..B+Bc-1 = matched_lie
+        terms = []
+        w_fl = 1.0 / (3.0 * (B - 1) * N) if B > 1 else 0.0
+        w_c = 1.0 / (3.0 * Bc * N)
+        for p in range(B - 1):
+            terms.append((block[p, N6 - 1], p, block[p + 1, 0], p + 1, w_fl, None))
+        for k in range(Bc):
+            terms.append((lc_all[k, 0], B + k, block[int(sub_matched_all[k]), 0], int(sub_matched_all[k]), w_c, None))
+        for k in range(Bc):
+            terms.append((pm_cur[k], int(sub_cur_all[k]), lc_all[k, N6 - 1], B + k, w_c, None))
+        res = ops.lc_optimize_terms(terms, B + Bc, N, self.loop_iters, 5e-4, return_loss)
+        xi, T = res[0], res[1]
+        se3 = SE3.exp(xi[:B].contiguous())
+        new_pose = self._rewrite(0, sub1, T[:B].contiguous())
+        ops.transform_submaps(lc_all, T[B:].reshape(Bc, 12).contiguous())              # lc submaps moved by their matched transform (:513-516)
+        for i in range(Bc - 1):
+            self.closed_loop["pointmaps_lc"][i] = lc_all[i]
         updates = {"pose_updates": se3.data, "submap_idx": range(0, sub1 + 1), "camera_idx": range(0, (sub1 + 1) * 5 + 1),
                    "camera_pose": torch.from_numpy(new_pose)}
-        return lc_al[-1], updates
+        if return_loss:
+            updates["loss"] = res[2]
+        return lc_all[-1], updates
 
     # ------------------------------------------------------------------ entry point (track_backend.py:527-586)
     def run(self):
@@ -210,6 +210,11 @@ class TrackBackend:
         anchor = idx_matched // 5
         selected = list(range(anchor * 5, (anchor + 1) * 5)) + [idx_current]
         pm_lc, conf_lc, poses_lc = self.track(selected, anchor)
+        return True, self.close_loop(pm_lc, idx_matched, idx_current)
+
+    def close_loop(self, pm_lc, idx_matched, idx_current):
+        """submap-level optimisation + bookkeeping of one accepted loop (track_backend.py:559-575).  pm_lc [6,h,w,3]: the
+        re-tracked submap [5 keyframes of the matched submap, current keyframe] in the matched submap's frame."""
         if not self.lc_initialized:
             updates = self.loop_closure_init(pm_lc[-1], idx_matched, idx_current)
             self.lc_initialized = True
@@ -221,4 +226,4 @@ class TrackBackend:
         self.closed_loop["idx_current"].append(idx_current)
         self.closed_loop["idx_matched"].append(idx_matched)
         self.closed_loop["pointmaps_lc"].append(stored)
-        return True, updates
+        return updates

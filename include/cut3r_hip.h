@@ -214,6 +214,22 @@ int cut3r_lc_workspace_floats(int B, int N);
 int cut3r_lc_optimize(const float* first, const float* last, long long sub_stride, const unsigned char* mask, const float* cur,
                       const float* cur_lc, int B, int N, long long n_masked, int iters, float lr, float* xi, float* adam_m,
                       float* adam_v, float* T, float* workspace, float* loss_out, void* stream);
+/* General form for the second and later loop closures (TrackBackend.loop_closure, hislam2/track_backend.py:400-461: the
+ * chain term + the matched-submap term + the current-vs-lc term, Adam over `_align_lie` AND `matched_lie`).  The objective
+ * is a LIST of L1 terms  w * sum_n | T[ia] a_n - T[ic] c_n |_1  over [N,3] point arrays; T[0] is the fixed identity, every
+ * other row of T [P,12] is exp of a row of xi [P,6] and is optimised.  terms_dev: DEVICE array of n_terms cut3r_lc_term.
+ * workspace: cut3r_lc_workspace_floats(n_terms, N) floats.  xi/adam_m/adam_v zero- and T identity-initialised by the
+ * caller.  Two launches per iteration, deterministic. */
+typedef struct cut3r_lc_term {
+    const float* a;              /* [N,3] points moved by T[ia] */
+    const float* c;              /* [N,3] points moved by T[ic] */
+    const unsigned char* mask;   /* NULL or uint8 [N]: points with mask 0 are skipped */
+    int ia, ic;                  /* transform indices, 0 = fixed identity */
+    float w;                     /* weight of the term (1 / (3 * #points of its mean)) */
+    int pad;
+} cut3r_lc_term;
+int cut3r_lc_optimize_terms(const void* terms_dev, int n_terms, int P, int N, int iters, float lr, float* xi, float* adam_m,
+                            float* adam_v, float* T, float* workspace, float* loss_out, void* stream);
 /* in place p <- T_b p for the points_per_submap points of each of the B submaps (pts: [B, points_per_submap, 3]) */
 int cut3r_transform_submaps(float* pts, const float* T, int B, long long points_per_submap, void* stream);
 

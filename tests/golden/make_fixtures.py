@@ -218,8 +218,76 @@ def gen_graph_fixture():
     print("wrote graph: edges", len(fx[f"ii_{n-1}"]), "loop", fx["loop_last"], "ratios", ratios)
 
 
+def gen_nms_fixture():
+    """Loop-candidate scoring: the reference's FactorGraph.NMS (factor_graph.py:561-582) itself, run on the CPU.  Its body calls
+    `.cuda()` on its arguments; the harness turns that into a no-op (torch.Tensor.cuda patched for this call only -- the
+    reference file is untouched).  Also records compute_feature_overlap_batch (:328-341) and both cal_overlap_bi calls."""
+    FG, pose_vec_to_matrix, patch_overlap, depth_to_pointmap = import_reference_graph()
+    g = np.random.Generator(np.random.PCG64(23))
+    n, H, W, Np, Cf = 14, 24, 32, 48, 32
+    K = np.array([[30.0, 0, 15.5], [0, 30.0, 11.5], [0, 0, 1.0]])
+    poses = torch.from_numpy(synth_trajectory(g, n))
+    c2w = pose_vec_to_matrix(poses)
+    depth = torch.from_numpy(g.uniform(2.0, 3.0, size=(n, H, W)).astype(np.float32))
+    pm = depth_to_pointmap(depth, c2w, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+    base = g.standard_normal((Np, Cf)).astype(np.float32)
+    feats = np.stack([base[g.permutation(Np)] + a * g.standard_normal((Np, Cf)).astype(np.float32)
+                      for a in np.linspace(0.0, 1.6, n)]).astype(np.float32)
+    feats = torch.from_numpy(feats)
+    graph = FG(types.SimpleNamespace(), device="cpu", max_factors=48)
+    cur = n - 1
+    fx = {"poses": poses.numpy(), "c2w": c2w.numpy(), "pointmaps": pm.numpy(), "K": K, "feats": feats.numpy(), "idx_current": np.int64(cur)}
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for name, ids in (("a", [0, 1, 2, 3]), ("b", [2, 5, 7]), ("c", [8, 9])):
+            ids_t = torch.as_tensor(ids)
+            mask, feat_sim = graph.compute_feature_overlap_batch(feats[cur], feats[ids_t], return_item=True)
+            a2c = graph.cal_overlap_bi(pm[ids_t], c2w[cur][None], K).squeeze(-1)
+            c2a = graph.cal_overlap_bi(pm[cur][None], c2w[ids_t], K).squeeze(0)
+            scores = 0.8 * (a2c + c2a) / 2 + 0.2 * feat_sim
+            for th in (0.4, 0.95):
+                k = graph.NMS(pm[ids_t], feats[ids_t], c2w[ids_t], pm[cur], feats[cur], c2w[cur], K, th=th)
+                fx[f"{name}_k_th{int(th * 100)}"] = np.int64(-1 if k is None else int(k))
+            fx[f"{name}_ids"] = np.asarray(ids, np.int64)
+            fx[f"{name}_feat_sim"] = feat_sim.numpy()
+            fx[f"{name}_feat_mask"] = mask.numpy()
+            fx[f"{name}_a2c"] = a2c.numpy()
+            fx[f"{name}_c2a"] = c2a.numpy()
+            fx[f"{name}_scores"] = scores.numpy()
+    finally:
+        torch.Tensor.cuda = real_cuda
+    np.savez_compressed(os.path.join(HERE, "nms.npz"), **fx)
+    print("wrote nms", {k: (v.tolist() if v.size < 6 else v.shape) for k, v in fx.items() if len(k) > 1 and k[1] == "_"})
+
+
+def gen_camera_fixture():
+    """pose_encoding_to_camera / quaternion_to_matrix (src/dust3r/utils/camera.py:364-420), geotrf (utils/geometry.py:49-115)
+    and hislam2 pose_vec_to_matrix (util/utils.py:676-700) on seeded inputs -- the host pose helpers of the trackers."""
+    sys.path[:0] = [REF, os.path.join(REF, "src")]
+    from src.dust3r.utils.camera import pose_encoding_to_camera, quaternion_to_matrix
+    from src.dust3r.utils.geometry import geotrf
+    _, pose_vec_to_matrix, _, _ = import_reference_graph()
+    g = np.random.Generator(np.random.PCG64(31))
+    enc = g.standard_normal((9, 7)).astype(np.float32)
+    enc[:, 3:] /= np.linalg.norm(enc[:, 3:], axis=1, keepdims=True)
+    enc[4, 3:] *= 1.7                                        # non-unit quaternion: two_s = 2 / |q|^2 (camera.py:378)
+    c2w = pose_encoding_to_camera(torch.from_numpy(enc))
+    pts = torch.from_numpy(g.standard_normal((9, 5, 7, 3)).astype(np.float32))
+    vec = g.standard_normal((9, 7)).astype(np.float32)       # (t, q_xyzw), un-normalised: pose_vec_to_matrix normalises
+    fx = {"enc": enc, "c2w": c2w.numpy(), "R": quaternion_to_matrix(torch.from_numpy(enc[:, 3:])).numpy(),
+          "pts": pts.numpy(), "geotrf": geotrf(c2w, pts).numpy(), "pose_vec": vec,
+          "pose_vec_c2w": pose_vec_to_matrix(torch.from_numpy(vec)).numpy()}
+    np.savez_compressed(os.path.join(HERE, "camera.npz"), **fx)
+    print("wrote camera", {k: v.shape for k, v in fx.items()})
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear"]
+    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "nms", "camera"]
+    if "nms" in what:
+        gen_nms_fixture()
+    if "camera" in what:
+        gen_camera_fixture()
     if "rope" in what:
         gen_rope_fixture()
     if "graph" in what:

@@ -55,3 +55,39 @@ def test_add_factors_filters_only_existing_edges_and_rm():
     assert list(zip(*[a.tolist() for a in g.edges_numpy()[:2]])) == [(0, 1), (0, 1), (1, 0), (2, 0)]
     g.rm_factors(torch.tensor([True, False, False, True]))
     assert list(zip(*[a.tolist() for a in g.edges_numpy()[:2]])) == [(0, 1), (1, 0)]
+
+
+def test_end_to_end_oracle_graph_replays_the_reference_edge_lists():
+    """oracle/slam_run.RefGraph (the independent restatement used by the end-to-end trajectory oracle) against the reference
+    FactorGraph run recorded in graph.npz: identical ordered edge lists and ages after every add."""
+    import os
+    import numpy as np
+    from oracle import slam_run as SR
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "graph.npz"))
+    c2w, pm, K = f["c2w"], f["pointmaps"], f["K"]
+    K4 = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]], np.float32)
+    n = c2w.shape[0]
+    g = SR.RefGraph()
+    g.add_neighborhood_factors(0, 3, r=3)
+    for i in range(n):
+        if i >= 6:
+            g.add_neighborhood_factors(i - 3, i + 1, r=3)
+        if i > 2:
+            g.add(i, c2w[:i], pm[:i], c2w[i], pm[i], K4)
+        ii, jj, age = g.edges_numpy()
+        np.testing.assert_array_equal(ii, f[f"ii_{i}"])
+        np.testing.assert_array_equal(jj, f[f"jj_{i}"])
+        np.testing.assert_array_equal(age, f[f"age_{i}"])
+
+
+def test_host_pose_helpers_equal_the_reference_fixture():
+    import os
+    import numpy as np
+    import torch
+    from cut3r_slam_amd import geom_host as gh
+    from oracle import slam_oracle as SO
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "camera.npz"))
+    np.testing.assert_allclose(gh.pose_encoding_to_camera(f["enc"]), f["c2w"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(gh.pose_vec_to_matrix(f["pose_vec"]), f["pose_vec_c2w"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(SO.pose_encoding_to_camera(torch.from_numpy(f["enc"])).numpy(), f["c2w"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(SO.pose_vec_to_matrix(torch.from_numpy(f["pose_vec"])).numpy(), f["pose_vec_c2w"], rtol=0, atol=1e-6)

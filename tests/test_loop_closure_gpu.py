@@ -64,3 +64,99 @@ def test_transform_submaps_in_place_matches_se3_action():
     torch.cuda.synchronize()
     ref = torch.einsum("bij,bshwj->bshwi", T[:, :, :3].cpu(), sub) + T[:, :, 3].cpu().reshape(B, 1, 1, 1, 3)
     np.testing.assert_allclose(dev.cpu().numpy(), ref.numpy(), atol=2e-6)
+
+
+def _drifting_store(S, h, w, seed):
+    """keyframe store of S submaps with a planted per-submap drift (stored frame = drift^-1 of the true frame), consistent poses"""
+    sub, mask, _, _, drift = _drifting_submaps(S, h, w, seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    conf = torch.rand(S, 6, h, w, generator=g) - 0.08              # a few non-positive confidences: the first loop masks them
+    pose = torch.zeros(S * 5 + 6, 7)
+    pose[:, :3] = torch.randn(S * 5 + 6, 3, generator=g)
+    q = torch.randn(S * 5 + 6, 4, generator=g)
+    pose[:, 3:] = q / q.norm(dim=1, keepdim=True)
+    return sub, conf, pose, drift
+
+
+def test_three_successive_closures_match_fp64_restatement():
+    """TrackBackend.close_loop x3 (first loop: loop_closure_init; second and third: loop_closure with the matched-submap and
+    current-vs-lc terms, all on the fused HIP optimiser) vs oracle/lc_oracle.LoopCloser (fp64 autograd restatement of
+    hislam2/track_backend.py:220-358, 361-524, 559-575).  Checks poses, submaps and closed_loop['pointmaps_lc'] after every
+    closure -- in particular that later loops store the lc submap ALIGNED by its matched transform (:566-575).
+    Parity unpinned vs lietorch (absent from the reference); tolerance: an L1 objective gives sign() gradients, so the fp32 and
+    fp64 Adam trajectories may separate by a few lr = 5e-4 steps per coordinate."""
+    from cut3r_slam_amd.config import tiny_config
+    from cut3r_slam_amd.model import Cut3rModel
+    from cut3r_slam_amd.slam import Cut3rSlam
+    from cut3r_slam_amd.weights import synth_state_dict
+    S, h, w, iters = 7, 16, 24, 150
+    cfg = tiny_config("dpt")
+    model = Cut3rModel(cfg, synth_state_dict(cfg, 3), DEV, minimal=True)
+    conf_d = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 1, "kf_every": 2}, "frontend": {"iteration": iters}}}
+    slam = Cut3rSlam(model, conf_d, (2 * h, 2 * w), buffer=S * 5 + 8, device=DEV)
+    sub, conf, pose, drift = _drifting_store(S, h, w, 5)
+    kf = slam.keyframes
+    kf.submap_ds[:S] = sub.to(DEV)
+    kf.conf_ds[:S] = conf.to(DEV)
+    kf.set_poses(0, pose.numpy())
+    kf.counter.value = S * 5 + 6
+    ref = LO.LoopCloser(sub.clone(), conf.clone(), pose.clone(), iters)
+    be = slam.backend
+    g = torch.Generator().manual_seed(9)
+    T = torch.matrix_exp(LO.twist(drift)).float()
+    loops = [(3 * 5 + 2, 0 * 5 + 1), (5 * 5 + 1, 1 * 5 + 3), (6 * 5 + 3, 2 * 5 + 2)]        # (idx_current, idx_matched), submaps 3/5/6 -> 0/1/2
+    for n, (idx_cur, idx_m) in enumerate(loops):
+        sc, sm = idx_cur // 5, idx_m // 5
+        # re-tracked submap: the matched submap's own maps (first 5 slots) + the current map as the matched submap sees it
+        pm_lc = kf.submap_ds[sm].clone().cpu()
+        cur_true = kf.submap_ds[sc, idx_cur % 5].cpu().reshape(-1, 3) @ T[sc, :3, :3].T + T[sc, :3, 3]
+        pm_lc[5] = (cur_true + 0.002 * torch.randn(h * w, 3, generator=g)).reshape(h, w, 3)
+        pm_lc = pm_lc + 0.001 * torch.randn(pm_lc.shape, generator=g)
+        xi_ref = ref.close(pm_lc.clone(), idx_m, idx_cur)
+        upd = be.close_loop(pm_lc.to(DEV), idx_m, idx_cur)
+        torch.cuda.synchronize()
+        B = sc + 1
+        np.testing.assert_allclose(SE3(upd["pose_updates"]).log().cpu().numpy()[:, :3], xi_ref.numpy()[:B, :3], atol=8 * 5e-4, err_msg=f"loop {n}: tau")
+        np.testing.assert_allclose(kf.submap_ds[:B].cpu().numpy(), ref.sub[:B].numpy(), atol=2e-2, err_msg=f"loop {n}: submaps")
+        np.testing.assert_allclose(kf.pose[:B * 5 + 1, :3].numpy(), ref.pose[:B * 5 + 1, :3].numpy(), atol=2e-2, err_msg=f"loop {n}: positions")
+        qa, qb = kf.pose[:B * 5 + 1, 3:].numpy(), ref.pose[:B * 5 + 1, 3:].numpy()
+        assert np.abs(np.abs((qa * qb).sum(1)) - 1).max() < 1e-4, f"loop {n}: orientations"
+        assert len(be.closed_loop["pointmaps_lc"]) == n + 1
+        for k in range(n + 1):
+            np.testing.assert_allclose(be.closed_loop["pointmaps_lc"][k].cpu().numpy(), ref.closed["pointmaps_lc"][k].numpy(), atol=2e-2,
+                                       err_msg=f"loop {n}: stored lc submap {k}")
+        # untouched later submaps stay bit-identical
+        assert torch.equal(kf.submap_ds[B:S].cpu(), sub[B:S])
+    assert be.closed_loop["idx_current"] == [c for c, _ in loops] and be.closed_loop["idx_matched"] == [m for _, m in loops]
+    # the later loops really moved their lc submaps (the round-1 bug stored the unaligned one)
+    assert (be.closed_loop["pointmaps_lc"][2].cpu() - ref.closed["pointmaps_lc"][2].float()).abs().max() < 2e-2
+
+
+def test_term_list_optimiser_loss_and_convergence_vs_fp64():
+    """ops.lc_optimize_terms on the later-loop objective alone: identical loss at iteration 0 (all transforms = identity),
+    same loss trajectory, parameters within a few Adam steps of the fp64 autograd run (oracle/lc_oracle.loop_closure)."""
+    B, Bc, h, w, iters = 6, 2, 24, 32, 200
+    sub, _, _, _, drift = _drifting_submaps(B, h, w, 21)
+    g = torch.Generator().manual_seed(4)
+    N = h * w
+    sc, sm = [3, 5], [0, 1]
+    T = torch.matrix_exp(LO.twist(drift)).float()
+    lc_all = torch.stack([sub[m] + 0.002 * torch.randn(6, h, w, 3, generator=g) for m in sm], 0)
+    pm_cur = torch.stack([sub[3, 2], sub[5, 4]], 0)
+    for k in range(Bc):
+        lc_all[k, 5] = (pm_cur[k].reshape(-1, 3) @ T[sc[k], :3, :3].T + T[sc[k], :3, 3]).reshape(h, w, 3)
+    xi_r, T_r, xim_r, Tm_r, losses = LO.loop_closure(sub, lc_all, pm_cur, sc, sm, iters)
+    subd, lcd, curd = sub.to(DEV), lc_all.to(DEV).contiguous(), pm_cur.to(DEV).contiguous()
+    terms = [(subd[p, 5], p, subd[p + 1, 0], p + 1, 1.0 / (3 * (B - 1) * N), None) for p in range(B - 1)]
+    terms += [(lcd[k, 0], B + k, subd[sm[k], 0], sm[k], 1.0 / (3 * Bc * N), None) for k in range(Bc)]
+    terms += [(curd[k], sc[k], lcd[k, 5], B + k, 1.0 / (3 * Bc * N), None) for k in range(Bc)]
+    xi, Tt, loss = ops.lc_optimize_terms(terms, B + Bc, N, iters, 5e-4, return_loss=True)
+    torch.cuda.synchronize()
+    loss = loss.cpu().numpy()
+    assert abs(loss[0] - losses[0]) < 1e-5 * max(1.0, losses[0])
+    np.testing.assert_allclose(loss, np.asarray(losses), rtol=2e-2, atol=1e-3)
+    assert loss[-1] < 0.7 * loss[0]
+    np.testing.assert_allclose(xi[:B].cpu().numpy(), xi_r.numpy(), atol=6 * 5e-4)
+    np.testing.assert_allclose(xi[B:].cpu().numpy(), xim_r.numpy(), atol=6 * 5e-4)
+    np.testing.assert_allclose(Tt[:B].cpu().numpy(), T_r[:, :3, :4].numpy(), atol=5e-3)
+    np.testing.assert_allclose(Tt[B:].cpu().numpy(), Tm_r[:, :3, :4].numpy(), atol=5e-3)
