@@ -499,6 +499,30 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const unsigned ch
     }
 }
 
+// cv2.remap(src, map, INTER_LINEAR, BORDER_CONSTANT 0) on uint8 HWC with OpenCV's fixed-point map: coordinates in 1/32 pixel
+// (ix = round(32 u), integer part ix >> 5, fraction ix & 31), bilinear weights 32*a*b with a in {32 - fx, fx}, b in {32 - fy, fy}
+// (= OpenCV's BilinearTab_i, whose entries are exact for 5-bit fractions), result (sum + 2^14) >> 15.  This is the second half of
+// cv2.undistort (the map comes from initUndistortRectifyMap, built on the host once per sequence: cut3r_slam_amd/stream.py).
+__global__ __launch_bounds__(256) void remap_linear_u8_kernel(const unsigned char* __restrict__ src, int H, int W, int C,
+                                                              const int* __restrict__ map_ix, const int* __restrict__ map_iy,
+                                                              unsigned char* __restrict__ dst, int Ho, int Wo) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= Wo) return;
+    const size_t o = (size_t)y * Wo + x;
+    const int ix = map_ix[o], iy = map_iy[o];
+    const int sx = ix >> 5, sy = iy >> 5, fx = ix & 31, fy = iy & 31;
+    const int w00 = 32 * (32 - fx) * (32 - fy), w01 = 32 * fx * (32 - fy), w10 = 32 * (32 - fx) * fy, w11 = 32 * fx * fy;
+    const bool x0 = sx >= 0 && sx < W, x1 = sx + 1 >= 0 && sx + 1 < W, y0 = sy >= 0 && sy < H, y1 = sy + 1 >= 0 && sy + 1 < H;
+    for (int c = 0; c < C; c++) {
+        const int p00 = (x0 && y0) ? src[((size_t)sy * W + sx) * C + c] : 0;
+        const int p01 = (x1 && y0) ? src[((size_t)sy * W + sx + 1) * C + c] : 0;
+        const int p10 = (x0 && y1) ? src[((size_t)(sy + 1) * W + sx) * C + c] : 0;
+        const int p11 = (x1 && y1) ? src[((size_t)(sy + 1) * W + sx + 1) * C + c] : 0;
+        const int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+        dst[o * C + c] = (unsigned char)(v > 255 ? 255 : v);
+    }
+}
+
 }  // namespace
 
 extern "C" int cut3r_abi_version(void) { return 1; }
@@ -644,5 +668,13 @@ extern "C" int cut3r_resize_linear_u8(const void* src, int H0, int W0, int C, vo
     if (!src || !dst || H0 < 1 || W0 < 1 || H1 < 1 || W1 < 1 || C < 1 || C > 4 || H1 > 65535) return CUT3R_ERR_ARG;
     hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((W1 + 255) / 256, H1), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned char*)src, H0, W0, C, (unsigned char*)dst, H1, W1, chw_out);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_remap_linear_u8(const void* src, int H, int W, int C, const int32_t* map_ix, const int32_t* map_iy, void* dst, int Ho,
+                                     int Wo, void* stream) {
+    if (!src || !dst || !map_ix || !map_iy || H < 1 || W < 1 || Ho < 1 || Wo < 1 || C < 1 || C > 4 || Ho > 65535) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(remap_linear_u8_kernel, dim3((Wo + 255) / 256, Ho), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src, H, W,
+                       C, map_ix, map_iy, (unsigned char*)dst, Ho, Wo);
     return cut3r_check_launch();
 }

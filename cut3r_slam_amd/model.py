@@ -789,22 +789,41 @@ ARCroco3DStereo = Cut3rModel
 
 
 def _config_from_ctor_string(s: str, base: Cut3rConfig) -> Cut3rConfig:
-    """Parse 'ARCroco3DStereo(ARCroco3DStereoConfig(state_size=768, ..., enc_embed_dim=1024, ...))' without eval."""
+    """Parse 'ARCroco3DStereo(ARCroco3DStereoConfig(state_size=768, ..., enc_embed_dim=1024, ...))' (the string the reference
+    eval()s, model.py:72-92) without eval.  Output activations other than the ones this runtime implements --
+    depth_mode ('exp', -inf, inf), conf_mode ('exp', 1, inf), pose_mode ('exp', -inf, inf) (heads/postprocess.py:11-63) -- and a
+    checkpoint without pose head are refused instead of being silently mis-evaluated."""
     if not s:
         return base
     d = base.to_dict()
     for key in ("state_size", "local_mem_size", "enc_embed_dim", "enc_depth", "enc_num_heads", "dec_embed_dim",
-                "dec_depth", "dec_num_heads", "state_dec_num_heads", "ray_enc_depth"):
+                "dec_depth", "dec_num_heads", "state_dec_num_heads", "ray_enc_depth", "patch_size", "mlp_ratio"):
         m = re.search(rf"\b{key}\s*=\s*(\d+)", s)
         if m:
             d[key] = int(m.group(1))
     m = re.search(r"head_type\s*=\s*['\"](\w+)['\"]", s)
     if m:
         d["head_type"] = m.group(1)
-    m = re.search(r"img_size\s*=\s*\((\d+)\s*,\s*(\d+)\)", s)
+    m = re.search(r"img_size\s*=\s*[\(\[]\s*(\d+)\s*,\s*(\d+)\s*[\)\]]", s)
     if m:
         d["img_size"] = (int(m.group(1)), int(m.group(2)))
-    m = re.search(r"rgb_head\s*=\s*(True|False)", s)
+    for key in ("rgb_head", "pose_head"):
+        m = re.search(rf"\b{key}\s*=\s*(True|False)", s)
+        if m:
+            d[key] = m.group(1) == "True"
+    m = re.search(r"pos_embed\s*=\s*['\"]RoPE(\d+(?:\.\d+)?)['\"]", s)
     if m:
-        d["rgb_head"] = m.group(1) == "True"
+        d["rope_freq"] = float(m.group(1))
+    elif re.search(r"pos_embed\s*=", s):
+        raise NotImplementedError("only RoPE position embeddings (pos_embed='RoPE<freq>') are implemented")
+    want = {"depth_mode": ("exp", "-inf", "inf"), "conf_mode": ("exp", "1", "inf"), "pose_mode": ("exp", "-inf", "inf")}
+    for key, exp in want.items():
+        m = re.search(rf"\b{key}\s*=\s*[\(\[]\s*['\"](\w+)['\"]\s*,\s*([^,]+?)\s*,\s*([^\)\]]+?)\s*[\)\]]", s)
+        if m:
+            got = (m.group(1), m.group(2).replace("float('inf')", "inf").replace('float("inf")', "inf").replace("1.0", "1").replace(" ", ""),
+                   m.group(3).replace("float('inf')", "inf").replace('float("inf")', "inf").replace(" ", ""))
+            if got != exp:
+                raise NotImplementedError(f"{key}={got}: this runtime implements {exp} only")
+    if not d.get("pose_head", True):
+        raise NotImplementedError("checkpoints without pose head are not supported (the SLAM trackers need camera_pose)")
     return Cut3rConfig.from_dict(d)

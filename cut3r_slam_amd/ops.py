@@ -495,6 +495,22 @@ def logdepth_accum(prev_depth, pts, out):
     check(lib.cut3r_logdepth_accum(_p(prev_depth), _p(pts), n, _p(out), _stream()), "cut3r_logdepth_accum")
 
 
+def remap_linear_u8(src_hwc, map_ix, map_iy, out=None):
+    """cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) with a fixed-point map (1/32 pixel): src uint8 [H,W,C]; map_ix/map_iy int32 [Ho,Wo]"""
+    _cuda(src_hwc, map_ix, map_iy, out)
+    _req(src_hwc.dtype == torch.uint8 and src_hwc.dim() == 3 and src_hwc.is_contiguous(), "src uint8 [H,W,C] contiguous")
+    H, W, Cc = src_hwc.shape
+    _req(map_ix.dtype == torch.int32 and map_iy.dtype == torch.int32 and map_ix.shape == map_iy.shape and map_ix.dim() == 2
+         and map_ix.is_contiguous() and map_iy.is_contiguous(), "maps int32 [Ho,Wo]")
+    Ho, Wo = map_ix.shape
+    if out is None:
+        out = torch.empty((Ho, Wo, Cc), dtype=torch.uint8, device=src_hwc.device)
+    _req(out.dtype == torch.uint8 and out.shape == (Ho, Wo, Cc) and out.is_contiguous(), "out uint8 [Ho,Wo,C]")
+    lib = _lib.load()
+    check(lib.cut3r_remap_linear_u8(_p(src_hwc), H, W, Cc, _p(map_ix), _p(map_iy), _p(out), Ho, Wo, _stream()), "cut3r_remap_linear_u8")
+    return out
+
+
 def resize_linear_u8(img_hwc, H1, W1, chw_out=True):
     """cv2.resize(img, (W1, H1)) (INTER_LINEAR, u8) on the GPU.  img_hwc u8 [H0,W0,C] -> u8 [C,H1,W1] (or [H1,W1,C])."""
     _cuda(img_hwc)

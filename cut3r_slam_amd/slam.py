@@ -42,10 +42,16 @@ class Cut3rSlam:
         self.backend = TrackBackend(self, self.keyframes, self.config["Tracking"]["frontend"], device)
         self.do_lc = self.config["Tracking"]["frontend"].get("iteration", 0) > 0
         self.freeze_counter = 0
+        # hi2.py:103 keeps EVERY full-resolution frame (`self.images[tstamp] = image`) for terminate(); here that is opt-in
+        # (frames stay on the device, 0.6 MB each at 384x512): demo.py switches it on when --add_kf semantics are wanted
+        self.keep_images = False
+        self.images = {}
 
     @torch.no_grad()
     def run(self, tstamp, image, intrinsics, image_ds, intrinsics_ds, second_last_frame=False, last_frame=False):
         """hi2.py:101-133 without the GS mapper: image_ds [1,3,H,W] uint8 at tracking resolution."""
+        if self.keep_images:
+            self.images[int(tstamp)] = image
         self.filterx.kfFilter(tstamp, image_ds, intrinsics=intrinsics_ds, second_last_frame=second_last_frame,
                               last_frame=last_frame)
         run_backend, viz_idx, submap_idx = self.tracker.run(tstamp, last_frame=last_frame)
@@ -88,6 +94,37 @@ class Cut3rSlam:
                                second_last_frame=mark_tail and i == n - 2, last_frame=mark_tail and i == n - 1)
                 if on_frame is not None:
                     on_frame(t_start + i, out)
+
+    @torch.no_grad()
+    def terminate(self, add_kf=False, gap=30):
+        """hi2.py:152-229 without the Gaussian mapper.  With add_kf (demo_s.py:171 passes True) every pair of consecutive
+        keyframes more than `gap` frames apart gets ONE extra view at the middle frame: the kept full-resolution frame is resized
+        to the tracking resolution (bilinear, align_corners=False, hi2.py:198) and relocalised against the earlier keyframe by a
+        2-view inference (TrackFrontend.predict, track_frontend.py:102-162).  The reference hands these views to
+        `mapper.add_new_view`; tracking-only, they are returned: list of dicts (tstamp, pose [7] c2w, depth [H,W],
+        pointmap [h,w,3], conf [h,w], submap).  Returns (keyframes.pose as numpy [buffer,7], new views)."""
+        kf = self.keyframes
+        last = kf.counter.value
+        views = []
+        if add_kf:
+            if not self.images:
+                raise RuntimeError("terminate(add_kf=True) needs the frames: set slam.keep_images = True before run()")
+            ts = kf.tstamp[:max(last - 1, 0)]
+            H, W = kf.ht, kf.wd
+            for i in range(len(ts) - 1):
+                t0, t1 = float(ts[i]), float(ts[i + 1])
+                if t1 - t0 > gap:
+                    interval = (t1 - t0) // 2
+                    t_new = int(t0 + interval)
+                    img = self.images[t_new]
+                    img = img[0] if img.dim() == 4 else img
+                    if tuple(img.shape[-2:]) != (H, W):
+                        f = torch.nn.functional.interpolate(img[None].float(), size=(H, W), mode="bilinear", align_corners=False)[0]
+                        img = f.round().clamp(0, 255).to(torch.uint8)
+                    pose, depth, pm, conf = self.tracker.predict(img.to(self.device), kf.image[i], kf.pose[i], kf.depth[i],
+                                                                 kf.submap_ds[i // 5, i % 5])
+                    views.append({"tstamp": t_new, "pose": pose, "depth": depth, "pointmap": pm, "conf": conf, "submap": i // 5})
+        return kf.pose.numpy().copy(), views
 
     def trajectory(self):
         """(tstamps [t], poses [t,7] c2w (t, q_xyzw)) of the tracked keyframes (demo_s.py:97-100)."""

@@ -258,6 +258,12 @@ int cut3r_ba_step(const float* Gij, const float* disps, const float* intr, const
  * not in the build image: parity unpinned, see oracle/oracle_geom.c).  src u8 [H0,W0,C] interleaved (device); dst u8
  * [C,H1,W1] when chw_out != 0 (the layout demo_s.py:73 permutes to) else [H1,W1,C]. */
 int cut3r_resize_linear_u8(const void* src, int H0, int W0, int C, void* dst, int H1, int W1, int chw_out, void* stream);
+/* cv2.undistort's resampling step (demo_s.py:63-64 `cv2.undistort(image, K, calib[4:])` = initUndistortRectifyMap + remap with
+ * INTER_LINEAR, BORDER_CONSTANT 0): src/dst uint8 HWC; map_ix/map_iy int32 [Ho,Wo] = source coordinates in 1/32 pixel
+ * (round(32 u)), built once per sequence on the host (cut3r_slam_amd/stream.py:undistort_map).  PARITY UNPINNED vs cv2
+ * (absent from the build image): follows the published fixed-point algorithm (5 fraction bits, 15-bit weights). */
+int cut3r_remap_linear_u8(const void* src, int H, int W, int C, const int32_t* map_ix, const int32_t* map_iy, void* dst, int Ho, int Wo,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -104,3 +104,35 @@ def resize_linear_u8(img, H1, W1):
     out = np.empty((H1, W1, Cc), np.uint8)
     lib().oracle_resize_linear_u8(_ptr(img, C.c_ubyte), H0, W0, Cc, _ptr(out, C.c_ubyte), H1, W1)
     return out
+
+
+def undistort_map(K4, dist, H, W):
+    """cv2.initUndistortRectifyMap(K, dist, None, K, (W, H), CV_16SC2) restated pixel by pixel (plain loops, float64): source
+    coordinates of every destination pixel in 1/32 pixel.  PARITY UNPINNED (no cv2 here)."""
+    fx, fy, cx, cy = [float(v) for v in K4]
+    d = [float(v) for v in dist] + [0.0] * (8 - len(dist))
+    k1, k2, p1, p2, k3, k4, k5, k6 = d
+    ix = np.zeros((H, W), np.int32)
+    iy = np.zeros((H, W), np.int32)
+    for i in range(H):
+        y = (i - cy) / fy
+        for j in range(W):
+            x = (j - cx) / fx
+            r2 = x * x + y * y
+            kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2)
+            xd = x * kr + p1 * 2 * x * y + p2 * (r2 + 2 * x * x)
+            yd = y * kr + p1 * (r2 + 2 * y * y) + p2 * 2 * x * y
+            ix[i, j] = int(round(32.0 * (fx * xd + cx)))          # Python round: ties to even, like cvRound
+            iy[i, j] = int(round(32.0 * (fy * yd + cy)))
+    return ix, iy
+
+
+def remap_linear_u8(img, ix, iy):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W, Cc = img.shape
+    ix = np.ascontiguousarray(ix, dtype=np.int32)
+    iy = np.ascontiguousarray(iy, dtype=np.int32)
+    Ho, Wo = ix.shape
+    out = np.empty((Ho, Wo, Cc), np.uint8)
+    lib().oracle_remap_linear_u8(_ptr(img, C.c_ubyte), H, W, Cc, _ptr(ix, C.c_int32), _ptr(iy, C.c_int32), _ptr(out, C.c_ubyte), Ho, Wo)
+    return out

@@ -160,3 +160,26 @@ void oracle_resize_linear_u8(const unsigned char *src, int H0, int W0, int C, un
         }
     }
 }
+
+/* cv2.remap(src, map, INTER_LINEAR, BORDER_CONSTANT 0) for uint8 HWC with a fixed-point map (ix, iy = round(32 * source coordinate)):
+ * OpenCV's remapBilinear with FixedPtCast<int, uchar, 15> -- weights BilinearTab_i = 32*a*b (exact for 5-bit fractions),
+ * (sum + 2^14) >> 15, taps outside the image read the border value 0.  TEST INFRASTRUCTURE; parity unpinned vs cv2. */
+void oracle_remap_linear_u8(const unsigned char *src, int H, int W, int C, const int *map_ix, const int *map_iy, unsigned char *dst,
+                            int Ho, int Wo) {
+    for (int y = 0; y < Ho; y++)
+        for (int x = 0; x < Wo; x++) {
+            const int ix = map_ix[(size_t)y * Wo + x], iy = map_iy[(size_t)y * Wo + x];
+            const int sx = ix >> 5, sy = iy >> 5, fx = ix & 31, fy = iy & 31;
+            const int w[4] = {32 * (32 - fx) * (32 - fy), 32 * fx * (32 - fy), 32 * (32 - fx) * fy, 32 * fx * fy};
+            for (int c = 0; c < C; c++) {
+                int acc = 1 << 14;
+                for (int k = 0; k < 4; k++) {
+                    const int xx = sx + (k & 1), yy = sy + (k >> 1);
+                    const int p = (xx >= 0 && xx < W && yy >= 0 && yy < H) ? src[((size_t)yy * W + xx) * C + c] : 0;
+                    acc += p * w[k];
+                }
+                acc >>= 15;
+                dst[((size_t)y * Wo + x) * C + c] = (unsigned char)(acc > 255 ? 255 : acc);
+            }
+        }
+}

@@ -131,6 +131,29 @@ def test_skinny_gemm_rows_do_not_depend_on_the_batch():
         assert torch.equal(part, full[:m]), m
 
 
+@pytest.mark.parametrize("M,N,K", [(1536, 1024, 1024), (2000, 768, 768), (777, 512, 320)])
+def test_every_tile_kernel_gives_the_same_bits(M, N, K):
+    """A row's result must not depend on the tile kernel that computed it (the encoder is batch invariant bit for bit and
+    windows batched through the decoder equal windows decoded alone only because of this): same MFMA, same K order, and the
+    same epilogue arithmetic (gemm.hip is compiled with -ffp-contract=off: the compiler contracted the GELU differently in the
+    256^2 kernel once) -- for every epilogue the model uses."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).half().to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r32 = torch.randn(M, N, generator=g).to(DEV)
+    cases = ((0, None, torch.float16), (1, None, torch.float16), (0, r32, torch.float32), (0, r32.half(), torch.float16), (2, None, torch.float32),
+             (1, None, torch.float32), (0, None, torch.float32))
+    for act, res, odt in cases:
+        ref = torch.zeros(M, N, dtype=odt, device=DEV)
+        ops.linear(A, W, ref, b, act, res, tile=128)
+        for tile in (64, 256, 192128, 128192, 256128, 12864):
+            out = torch.zeros(M, N, dtype=odt, device=DEV)
+            ops.linear(A, W, out, b, act, res, tile=tile)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (tile, act, odt, int((out != ref).sum()))
+
+
 def test_gemm_strided_output_and_inplace_residual():
     g = torch.Generator().manual_seed(1)
     M, N, K = 70, 96, 64

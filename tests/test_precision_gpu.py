@@ -1,0 +1,192 @@
+"""GPU: precision budget and shape coverage of the network path.
+
+Precision protocol: the reference runs its matmuls in TF32 (src/croco/models/croco.py:13),
+the MI355X path feeds fp16 operands to fp32-accumulating MFMAs -- both carry a 10-bit mantissa.  For every output we measure
+    e_hip  = max|HIP - oracle_fp32| / max|oracle_fp32|        and        e_tf32 = max|oracle_tf32 - oracle_fp32| / max|oracle_fp32|
+(oracle_tf32 = the same CPU oracle with every matmul/conv/attention operand rounded to 10 mantissa bits) and require
+e_hip <= 2 x e_tf32 (+ a 2e-4 floor for outputs where both are at rounding level): the HIP path is as close to exact fp32 as the
+reference's own arithmetic.  Absolute tolerances below are the errors measured on MI355X in round 2, times 3.
+
+Shapes: BASELINE config 1 at its real size (224x224 pair, ViT-L, linear head, state_size 256), the ScanNet crop 368x512
+(demo_s.py --cropborder 20), a 6-view 384x512 window; `from_pretrained` round trip; fp16 range probe of every activation buffer.
+"""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cut3r_slam_amd import synth  # noqa: E402
+from cut3r_slam_amd.config import Cut3rConfig, config1_224, production_config, tiny_config  # noqa: E402
+from cut3r_slam_amd.model import Cut3rModel  # noqa: E402
+from cut3r_slam_amd.weights import synth_state_dict  # noqa: E402
+from oracle import cut3r_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+KEYS = ("camera_pose", "pts3d_in_self_view", "conf_self")
+
+
+def _rel(got, ref):
+    got, ref = torch.as_tensor(got).double().cpu(), torch.as_tensor(ref).double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+
+
+def _images(n, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand(3, H // 8 + 16, W // 8 + 16, generator=g)
+    base = torch.nn.functional.interpolate(base[None], scale_factor=8, mode="bilinear", align_corners=False)[0]
+    return torch.stack([(base[:, 3 * t:3 * t + H, 5 * t:5 * t + W] * 255).round().clamp(0, 255).to(torch.uint8) for t in range(n)])
+
+
+def _budget(tag, preds, ref32, reftf, tol, mask_fn=None):
+    """prints the error table, asserts e_hip <= tol[key] and e_hip <= 2 e_tf32 + 2e-4"""
+    worst = {}
+    for i in range(len(ref32)):
+        for k in KEYS:
+            a, b, c = preds[i][k].float().cpu(), ref32[i][k], reftf[i][k] if reftf is not None else None
+            if mask_fn is not None and k == "pts3d_in_self_view":
+                m = mask_fn(b)
+                a, b, c = a[m], b[m], (c[m] if c is not None else None)
+            e_hip = _rel(a, b)
+            e_tf = _rel(c, b) if c is not None else float("nan")
+            w = worst.setdefault(k, [0.0, 0.0])
+            w[0], w[1] = max(w[0], e_hip), max(w[1], e_tf if e_tf == e_tf else 0.0)
+    print(f"[precision {tag}] " + " | ".join(f"{k}: hip {v[0]:.2e} tf32 {v[1]:.2e} (tol {tol[k]:.0e})" for k, v in worst.items()))
+    for k, (e_hip, e_tf) in worst.items():
+        assert e_hip <= tol[k], (tag, k, e_hip)
+        if reftf is not None:
+            assert e_hip <= 2.0 * e_tf + 2e-4, (tag, k, e_hip, e_tf)
+    return worst
+
+
+def test_precision_budget_medium_config_vs_tf32_emulation():
+    cfg = synth.medium_config()
+    sd = synth_state_dict(cfg, 11)
+    imgs = _images(4, 64, 96, 2)
+    x = O.normalize(imgs)
+    ref32, st32 = O.forward_views(cfg, sd, x, minimal=True, return_states=True)
+    with O.matmul_precision("tf32"):
+        reftf, sttf = O.forward_views(cfg, sd, x, minimal=True, return_states=True)
+    model = Cut3rModel(cfg, sd, DEV, minimal=True)
+    preds, taps = model.forward_window(imgs.to(DEV), return_taps=True)
+    torch.cuda.synchronize()
+    _budget("medium 4 views", preds, ref32, reftf, {"camera_pose": 2e-3, "pts3d_in_self_view": 6e-3, "conf_self": 6e-3})
+    for i in range(4):
+        e_hip = _rel(taps["states"][i][0][None], st32[i + 1][0])
+        e_tf = _rel(sttf[i + 1][0], st32[i + 1][0])
+        print(f"[precision medium] state tokens after view {i}: hip {e_hip:.2e} tf32 {e_tf:.2e}")
+        assert e_hip <= 6e-3 and e_hip <= 2.0 * e_tf + 2e-4
+
+
+def test_config1_real_size_224_pair_linear_head():
+    """BASELINE configs[0]: single 224x224 image pair through the ViT-L / linear-head / state_size=256 model (model.py:1120-1137)"""
+    cfg = config1_224()
+    sd = synth_state_dict(cfg, 2)
+    imgs = _images(2, 224, 224, 5)
+    x = O.normalize(imgs)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref32 = O.forward_views(cfg, sd, x, minimal=True)
+    with O.matmul_precision("tf32"):
+        reftf = O.forward_views(cfg, sd, x, minimal=True)
+    model = Cut3rModel(cfg, sd, DEV, minimal=True)
+    preds, _ = model.forward_window(imgs.to(DEV))
+    torch.cuda.synchronize()
+    # pos_z (linear_head.py:316) flips the sign of xyz where the regressed z is ~0: those pixels are excluded (as in the golden test)
+    _budget("config1 224x224 pair", preds, ref32, reftf, {"camera_pose": 3e-3, "pts3d_in_self_view": 1.5e-2, "conf_self": 1.5e-2},
+            mask_fn=lambda r: r[..., 2] > 0.03 * r.abs().max())
+    del model
+
+
+@pytest.fixture(scope="module")
+def prod():
+    cfg = production_config()
+    sd = synth_state_dict(cfg, seed=0)
+    model = Cut3rModel(cfg, sd, DEV, minimal=True)
+    yield cfg, sd, model
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_scannet_crop_368x512_window(prod):
+    """ScanNet frames after --cropborder 20 are 600x440 -> 368x512 (demo_s.py:66-73, scripts/run_scannet.py): 23 x 32 = 736 tokens"""
+    cfg, sd, model = prod
+    imgs = _images(2, 368, 512, 7)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref32 = O.forward_views(cfg, sd, O.normalize(imgs), minimal=True)
+    preds, _ = model.forward_window(imgs.to(DEV))
+    torch.cuda.synchronize()
+    assert preds[0]["pts3d_in_self_view"].shape == (1, 368, 512, 3)
+    _budget("production 368x512 2 views", preds, ref32, None, {"camera_pose": 3e-3, "pts3d_in_self_view": 1.5e-2, "conf_self": 1.5e-2})
+
+
+def test_six_view_full_size_window_and_fp16_headroom(prod):
+    """the steady-state tracking window (6 views, 384x512) against the fp32 oracle, and the largest magnitude every fp16
+    activation buffer reached (range risk of fp16 operands vs the reference's TF32: VERDICT r1 weak #6; random weights only --
+    no checkpoint exists)"""
+    cfg, sd, model = prod
+    imgs = _images(6, 384, 512, 0)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref32 = O.forward_views(cfg, sd, O.normalize(imgs), minimal=True)
+    from cut3r_slam_amd import ops
+    was = model.use_graphs
+    model.use_graphs = False
+    peaks = {}
+    names = ("linear", "linear_batched", "layernorm", "layernorm_dual", "attention", "conv3x3_nhwc", "conv_transpose_nhwc", "upsample2x", "cast_f16",
+             "rope_2d", "rope_2d_qk", "im2col_patch")
+    real = {n: getattr(ops, n) for n in names}
+
+    def probe(n):
+        def fn(*a, **k):
+            r = real[n](*a, **k)
+            for t in list(a) + list(k.values()):
+                if isinstance(t, torch.Tensor) and t.dtype == torch.float16 and t.is_cuda and t.numel():
+                    m = t.detach().abs().max().float()
+                    peaks[n] = torch.maximum(peaks[n], m) if n in peaks else m
+            return r
+        return fn
+
+    for n in names:
+        setattr(ops, n, probe(n))
+    try:
+        preds, _ = model.forward_window(imgs.to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        for n in names:
+            setattr(ops, n, real[n])
+        model.use_graphs = was
+    _budget("production 384x512 6 views", preds, ref32, None, {"camera_pose": 3e-3, "pts3d_in_self_view": 1.5e-2, "conf_self": 1.5e-2})
+    pk = sorted(((float(v), n) for n, v in peaks.items()), reverse=True)
+    assert pk and all(np.isfinite(p) for p, _ in pk)
+    print("[fp16 headroom] largest |value| seen in any fp16 operand/result of each op over a 6-view window: " +
+          ", ".join(f"{n} {p:.1f}" for p, n in pk) + f" | headroom to 65504: x{65504.0 / max(pk[0][0], 1e-9):.0f}")
+    assert pk[0][0] < 65504.0 / 16, pk[:3]
+
+
+def test_from_pretrained_round_trip(tmp_path):
+    """a checkpoint in the reference's format ({'model': state_dict, 'args': Namespace(model=<constructor string>)},
+    src/dust3r/model.py:72-92) loads through Cut3rModel.from_pretrained (weights_only, constructor string parsed, not eval'd)
+    and gives bit-identical outputs to the directly constructed model; a missing file never reaches for a hub"""
+    cfg = tiny_config("dpt")
+    sd = synth_state_dict(cfg, 3)
+    ctor = ("ARCroco3DStereo(ARCroco3DStereoConfig(freeze='encoder', pos_embed='RoPE100', rgb_head=True, pose_head=True, "
+            f"img_size=({cfg.img_size[0]}, {cfg.img_size[1]}), head_type='dpt', output_mode='pts3d+pose', depth_mode=('exp', -inf, inf), "
+            f"conf_mode=('exp', 1, inf), pose_mode=('exp', -inf, inf), enc_embed_dim={cfg.enc_embed_dim}, enc_depth={cfg.enc_depth}, "
+            f"enc_num_heads={cfg.enc_num_heads}, dec_embed_dim={cfg.dec_embed_dim}, dec_depth={cfg.dec_depth}, dec_num_heads={cfg.dec_num_heads}, "
+            f"state_size={cfg.state_size}, state_dec_num_heads={cfg.state_dec_num_heads}, local_mem_size={cfg.local_mem_size}, ray_enc_depth={cfg.ray_enc_depth}))")
+    path = os.path.join(tmp_path, "ckpt.pth")
+    torch.save({"model": {("module." + k if i % 2 else k): v for i, (k, v) in enumerate(sd.items())}, "args": argparse.Namespace(model=ctor)}, path)
+    m1 = Cut3rModel.from_pretrained(path, device=DEV, minimal=True)
+    assert m1.cfg == cfg
+    m0 = Cut3rModel(cfg, sd, DEV, minimal=True)
+    imgs = _images(3, 32, 48, 1).to(DEV)
+    a, _ = m0.forward_window(imgs)
+    a = [{k: v.clone() for k, v in p.items()} for p in a]
+    b, _ = m1.forward_window(imgs)
+    for pa, pb in zip(a, b):
+        for k in pa:
+            assert torch.equal(pa[k], pb[k]), k
+    with pytest.raises(FileNotFoundError):
+        Cut3rModel.from_pretrained(os.path.join(tmp_path, "missing.pth"))

@@ -301,3 +301,33 @@ def test_loop_closure_backend_runs_end_to_end_and_reduces_the_disagreement():
     # NMS path executes with the HIP overlap + feature kernels
     k = be.nms(np.array([0, 1, 2]), idx_current, [20.0, 20.0, 11.75, 7.75])
     assert k is None or 0 <= k < 3
+
+
+def test_terminate_add_kf_densifies_wide_keyframe_gaps():
+    """Hi2.terminate(add_kf=True) (hi2.py:177-214; demo_s.py:171): every pair of consecutive keyframes more than 30 frames apart
+    gets one extra view at the middle frame, relocalised by TrackFrontend.predict against the earlier keyframe -- same
+    frames, same outputs as calling predict directly; without kept frames it fails loudly."""
+    model = _model()
+    cfgd = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 1, "kf_every": 40}, "frontend": {"iteration": 0}}}
+    slam = Cut3rSlam(model, cfgd, (H, W), buffer=24, device=DEV)
+    frames = _frames(330, seed=5)
+    intr = torch.tensor([40.0, 40.0, 23.5, 15.5])
+    with pytest.raises(RuntimeError):
+        slam.terminate(add_kf=True)
+    slam.keep_images = True
+    n = len(frames)
+    for t in range(n):
+        slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+    kf = slam.keyframes
+    traj, views = slam.terminate(add_kf=True)
+    ts = kf.tstamp[:kf.counter.value - 1].numpy()
+    gaps = [i for i in range(len(ts) - 1) if ts[i + 1] - ts[i] > 30]
+    assert len(gaps) >= 6 and len(views) == len(gaps)
+    assert traj.shape == (kf.buffer, 7)
+    for i, v in zip(gaps, views):
+        assert v["tstamp"] == int(ts[i] + (ts[i + 1] - ts[i]) // 2) and v["submap"] == i // 5
+        pose, depth, pm, conf = slam.tracker.predict(frames[v["tstamp"]].to(DEV), kf.image[i], kf.pose[i], kf.depth[i])
+        assert torch.equal(pose, v["pose"]) and torch.equal(depth, v["depth"]) and torch.equal(pm, v["pointmap"]) and torch.equal(conf, v["conf"])
+        assert torch.isfinite(v["pose"]).all() and v["pointmap"].shape == (H // 2, W // 2, 3)
+    _, none = slam.terminate(add_kf=False)
+    assert none == []

@@ -116,3 +116,56 @@ def test_ate_recovers_a_known_similarity_and_noise_level(tmp_path):
     assert 0.6 * s * 0.01 * np.sqrt(3) < res["rmse"] < 1.2 * s * 0.01 * np.sqrt(3)      # residual = scaled noise
     exact = E.ate_rmse(np.concatenate([stamps[:, None], ((gt_p - t) @ R) / s, quat], 1), gt)
     assert exact["rmse"] < 1e-9
+
+
+def test_checkpoint_constructor_string_is_parsed_without_eval():
+    import pytest
+    from cut3r_slam_amd.config import production_config
+    from cut3r_slam_amd.model import _config_from_ctor_string
+    s = ("ARCroco3DStereo(ARCroco3DStereoConfig(freeze='encoder', pos_embed='RoPE100', rgb_head=True, pose_head=True, img_size=(512, 512), "
+         "head_type='dpt', output_mode='pts3d+pose', depth_mode=('exp', -inf, inf), conf_mode=('exp', 1, inf), pose_mode=('exp', -inf, inf), "
+         "enc_embed_dim=1024, enc_depth=24, enc_num_heads=16, dec_embed_dim=768, dec_depth=12, dec_num_heads=12, landscape_only=False, state_size=768, "
+         "state_pe='2d', local_mem_size=256))")
+    c = _config_from_ctor_string(s, production_config())
+    assert (c.state_size, c.head_type, c.img_size, c.enc_depth, c.dec_num_heads, c.rope_freq, c.rgb_head) == (768, "dpt", (512, 512), 24, 12, 100.0, True)
+    c1 = _config_from_ctor_string("ARCroco3DStereo(ARCroco3DStereoConfig(state_size=256, head_type='linear', img_size=(224, 224), rgb_head=False))", production_config())
+    assert (c1.state_size, c1.head_type, c1.img_size, c1.rgb_head) == (256, "linear", (224, 224), False)
+    for bad in ("depth_mode=('square', 0, inf)", "conf_mode=('exp', 0, inf)", "pose_head=False", "pos_embed='cosine'"):
+        with pytest.raises(NotImplementedError):
+            _config_from_ctor_string(f"ARCroco3DStereo(ARCroco3DStereoConfig({bad}))", production_config())
+
+
+def test_undistort_map_closed_forms_and_oracle_agreement():
+    """cut3r_slam_amd.stream.undistort_map (vectorised numpy, product) vs oracle/geom.undistort_map (plain per-pixel loops) and
+    closed forms: zero distortion -> identity map (32*j, 32*i); pure radial k1 at the principal point -> fixed point.
+    PARITY UNPINNED against cv2.initUndistortRectifyMap (cv2 is not in the image)."""
+    import numpy as np
+    from cut3r_slam_amd.stream import undistort_map
+    from oracle import geom as G
+    H, W = 37, 53
+    K4 = (40.0, 42.0, 25.5, 18.25)
+    ix, iy = undistort_map(K4, [0, 0, 0, 0], H, W)
+    assert np.array_equal(ix, np.tile(32 * np.arange(W, dtype=np.int32), (H, 1)))
+    assert np.array_equal(iy, np.tile(32 * np.arange(H, dtype=np.int32)[:, None], (1, W)))
+    tum = [0.2624, -0.9531, -0.0054, 0.0026, 1.1633]             # calib/tum.txt (fr1) coefficients
+    ix, iy = undistort_map(K4, tum, H, W)
+    rx, ry = G.undistort_map(K4, tum, H, W)
+    assert np.array_equal(ix, rx) and np.array_equal(iy, ry)
+    assert np.abs(ix - 32 * np.arange(W)[None, :]).max() > 32        # the coefficients really move pixels
+    ix8, iy8 = undistort_map(K4, tum + [0.01, -0.02, 0.003], H, W)
+    rx8, ry8 = G.undistort_map(K4, tum + [0.01, -0.02, 0.003], H, W)
+    assert np.array_equal(ix8, rx8) and np.array_equal(iy8, ry8)
+
+
+def test_remap_oracle_identity_shift_and_border():
+    import numpy as np
+    from oracle import geom as G
+    g = np.random.default_rng(0)
+    img = g.integers(0, 256, (9, 11, 3), dtype=np.uint8)
+    jj, ii = np.meshgrid(np.arange(11), np.arange(9))
+    assert np.array_equal(G.remap_linear_u8(img, 32 * jj, 32 * ii), img)                        # identity
+    out = G.remap_linear_u8(img, 32 * jj + 16, 32 * ii)                                       # half a pixel to the right
+    exp = (img[:, :-1].astype(np.int64) * 16384 + img[:, 1:].astype(np.int64) * 16384 + 16384) >> 15
+    assert np.array_equal(out[:, :-1], exp.astype(np.uint8))
+    assert np.array_equal(out[:, -1], ((img[:, -1].astype(np.int64) * 16384 + 16384) >> 15).astype(np.uint8))    # border value 0 beyond the edge
+    assert np.array_equal(G.remap_linear_u8(img, 32 * jj - 64, 32 * ii)[:, :2], np.zeros((9, 2, 3), np.uint8))   # fully outside

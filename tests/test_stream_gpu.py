@@ -73,3 +73,38 @@ def test_demo_driver_end_to_end(tmp_path):
     assert np.all(np.diff(rows[:, 0]) > 0) and np.isfinite(rows).all()
     np.testing.assert_allclose(np.linalg.norm(rows[:, 4:], axis=1), 1.0, atol=1e-4)     # unit quaternions
     np.testing.assert_allclose(np.load(out / "intrinsics.npy"), [480.0, 480.0, 256.0, 192.0], rtol=1e-6)
+
+
+def test_undistort_remap_bit_exact_vs_oracle_and_through_mono_stream(tmp_path):
+    """cv2.undistort (demo_s.py:63-64; scripts/run_tum.py passes --undistort with calib/tum.txt's 5 coefficients): HIP remap ==
+    the oracle's C restatement of OpenCV's fixed-point bilinear remap, bit for bit; zero distortion == identity; mono_stream
+    applies it before the crop.  PARITY UNPINNED against cv2 itself (absent here)."""
+    import numpy as np
+    from PIL import Image
+    from cut3r_slam_amd import ops
+    from cut3r_slam_amd.stream import mono_stream, undistort_map
+    from oracle import geom as G
+    g = np.random.default_rng(3)
+    H, W = 120, 160
+    img = g.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    K4 = [129.3, 129.1, 79.6, 63.8]
+    dist = [0.2624, -0.9531, -0.0054, 0.0026, 1.1633]
+    ix, iy = undistort_map(K4, dist, H, W)
+    got = ops.remap_linear_u8(torch.from_numpy(img).to(DEV), torch.from_numpy(ix).to(DEV), torch.from_numpy(iy).to(DEV)).cpu().numpy()
+    assert np.array_equal(got, G.remap_linear_u8(img, ix, iy))
+    assert (got != img).mean() > 0.5
+    ix0, iy0 = undistort_map(K4, [0, 0, 0, 0], H, W)
+    same = ops.remap_linear_u8(torch.from_numpy(img).to(DEV), torch.from_numpy(ix0).to(DEV), torch.from_numpy(iy0).to(DEV)).cpu().numpy()
+    assert np.array_equal(same, img)
+    # through the stream generator: undistort, crop 4, resize -- equals the same chain on the oracle
+    d = tmp_path / "frames"
+    d.mkdir()
+    Image.fromarray(img).save(d / "0001.png")
+    calib = np.array(K4 + dist)
+    (t, image, intr, image_ds, intr_ds, last), = list(mono_stream(str(d), calib, undistort=True, cropborder=4, device=DEV))
+    und = G.remap_linear_u8(img, ix, iy)[4:-4, 4:-4]
+    h0, w0 = und.shape[:2]
+    h1 = int((512 / w0 * h0) // 16) * 16
+    ref = G.resize_linear_u8(np.ascontiguousarray(und), h1, 512)
+    assert np.array_equal(image_ds[0].permute(1, 2, 0).cpu().numpy(), ref)
+    np.testing.assert_allclose(intr_ds[0, 2].item(), (K4[2] - 4) * 512 / w0)
