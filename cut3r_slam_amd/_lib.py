@@ -49,6 +49,7 @@ SIGNATURES = {
                              c_int, c_void_p],
     "cut3r_gemm_f16": [C.POINTER(GemmDesc), c_void_p],
     "cut3r_gemm_tile_for": [C.POINTER(GemmDesc)],
+    "cut3r_gemm_f16_pair": [C.POINTER(GemmDesc), C.POINTER(GemmDesc), c_void_p],
     "cut3r_rope2d_table": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p],
     "cut3r_gemv_f16w": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                         c_void_p, c_int, c_int, c_void_p],

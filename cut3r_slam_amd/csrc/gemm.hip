@@ -161,9 +161,8 @@ DEVINL void xcd_tile(int orig, int npm, int npn, int& pid_m, int& pid_n) {
 // conflict-free is applied to the per-lane SOURCE chunk (lane l sits at row l>>3, chunk l&7 of its 8-row group and
 // fetches chunk (l&7)^(l>>3)), and again on the read side.  NSTAGE-deep ring, counted vmcnt, ONE raw s_barrier per
 // K-tile: NSTAGE-2 tiles stay in flight across the barrier.
-template <int BM, int BN, int NSTAGE, int WAVES_M = 2, int WAVES_N = 2>
-// (8-wave tiles whose LDS lets two workgroups share a CU are held to 128 VGPRs: 4 waves per SIMD)
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8 && (BM + BN) * BK * 2 * NSTAGE <= 81920) ? 4 : 1) void gemm_kernel(const GemmArgs g) {
+template <int BM, int BN, int NSTAGE, int WAVES_M, int WAVES_N>
+DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const int bz) {
     constexpr int NWAVE = WAVES_M * WAVES_N;
     constexpr int NTHR = 64 * NWAVE;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
@@ -183,16 +182,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8 && 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int z = blockIdx.z;
+    const int z = bz;
     const h16* __restrict__ A = g.A + (size_t)z * g.sA;
     const h16* __restrict__ Bm = g.B + (size_t)z * g.sB;
     const int M = g.M, N = g.N, K = g.K;
     int pid_m, pid_n;
     if (g.swz) {
-        xcd_tile(blockIdx.x, (M + BM - 1) / BM, (N + BN - 1) / BN, pid_m, pid_n);
+        xcd_tile(bx, (M + BM - 1) / BM, (N + BN - 1) / BN, pid_m, pid_n);
     } else {
-        pid_m = blockIdx.y;
-        pid_n = blockIdx.x;
+        pid_m = by;
+        pid_n = bx;
     }
     const int m0 = pid_m * BM, n0 = pid_n * BN;
     const h16* zero = reinterpret_cast<const h16*>(g_zero16);
@@ -385,6 +384,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8 && 
     }
 }
 
+// (8-wave tiles whose LDS lets two workgroups share a CU are held to 128 VGPRs: 4 waves per SIMD)
+#define CUT3R_TILE_BOUNDS __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8 && (BM + BN) * BK * 2 * NSTAGE <= 81920) ? 4 : 1)
+template <int BM, int BN, int NSTAGE, int WAVES_M = 2, int WAVES_N = 2>
+__global__ CUT3R_TILE_BOUNDS void gemm_kernel(const GemmArgs g) {
+    gemm_tile_body<BM, BN, NSTAGE, WAVES_M, WAVES_N>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// TWO independent problems in one launch (1-D grid: the first nblk0 workgroups belong to problem 0): the state-side and the
+// image-side GEMM of a decoder layer have the same N, K and epilogue but their own operands and row counts
+// (src/dust3r/model.py:669-692: both blocks of a layer read the previous layer's pair, so they are independent).  One launch
+// of 2 x 294 tiles fills the chip where two launches of 294 tiles each leave 43 % of the workgroup slots empty.
+struct GemmPairArgs { GemmArgs p[2]; int nblk0; };
+template <int BM, int BN, int NSTAGE, int WAVES_M = 2, int WAVES_N = 2>
+__global__ CUT3R_TILE_BOUNDS void gemm_pair_kernel(const GemmPairArgs a) {
+    const int sel = (int)blockIdx.x >= a.nblk0 ? 1 : 0;
+    gemm_tile_body<BM, BN, NSTAGE, WAVES_M, WAVES_N>(a.p[sel], blockIdx.x - sel * a.nblk0, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // 256 x 256 x 64 tile, 8 waves (2 x 4, 128 x 64 outputs per wave), ping-pong schedule: the kernel for the large GEMMs
 // (ViT-L encoder linears at batch >= 8 keyframes, DPT 3x3 convolutions, decoder linears at window batch >= 8).
@@ -410,19 +427,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8 && 
 #define EPI_UNROLL 1
 #endif
 template <bool CONV3, bool RELU_IN>
-__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) {
+DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     constexpr int UNIT = 128 * BK * 2;      // 16 KiB: 128 rows x 64 halfs
     constexpr int BUF = 4 * UNIT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
-    const int z = blockIdx.z;
+    const int z = bz;
     const h16* __restrict__ A = g.A + (size_t)z * g.sA;
     const h16* __restrict__ Bm = g.B + (size_t)z * g.sB;
     const int M = g.M, N = g.N, K = g.K;
     int pid_m, pid_n;
-    xcd_tile(blockIdx.x, (M + 255) / 256, (N + 255) / 256, pid_m, pid_n);
+    xcd_tile(bx, (M + 255) / 256, (N + 255) / 256, pid_m, pid_n);
     const int m0 = pid_m * 256, n0 = pid_n * 256;
     const h16* zero = reinterpret_cast<const h16*>(g_zero16);
 
@@ -677,6 +694,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) {
 #undef CUT3R_BARRIER
 }
 
+template <bool CONV3, bool RELU_IN>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) { gemm256_body<CONV3, RELU_IN>(g, blockIdx.x, blockIdx.z); }
+
+__global__ __launch_bounds__(512) void gemm256_pair_kernel(const GemmPairArgs a) {
+    const int sel = (int)blockIdx.x >= a.nblk0 ? 1 : 0;
+    gemm256_body<false, false>(a.p[sel], blockIdx.x - sel * a.nblk0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Skinny GEMM on MFMA (M <= 64 rows): the pose-memory read blocks, pose MLP and proj_q run with one row per tracking
 // window (M = window batch).  Weight-read-bound: a 64-row tile puts only N/64 workgroups on the chip.  Here one workgroup
@@ -809,17 +834,22 @@ extern "C" int cut3r_gemm_tile_for(const cut3r_gemm_desc* d) {
     const long long rounds = (blocks256 + 255) / 256;
     static const long long fill_pct = [] { const char* e = getenv("CUT3R_GEMM_T256_FILL"); return e ? atoll(e) : 85LL; }();
     const bool fills = rounds == 1 || blocks256 * 100 >= rounds * 256 * fill_pct;
-    if (d->conv_k != 3 && !d->shuf && (d->N & 255) == 0 && blocks256 >= t256_min && fills) return 256;
-    // 192 x 128 (48 x 64 per wave: fewer LDS reads and L2->LDS bytes per FLOP than 128^2, still two workgroups per CU):
-    // alone +19 % on the M~6k x 1536 decoder projections and +9 % on the DPT 3x3 convolutions, but inside the tracking
-    // step (3-5 kernels in flight, idle CUs are taken by other streams) the gain is within noise (+0.5 %), so it stays an
-    // explicit choice (tile = 192128, CUT3R_GEMM_T192_MIN_M) rather than the default
+    static const int conv256 = [] { const char* e = getenv("CUT3R_GEMM_CONV256"); return e ? atoi(e) : 1; }();
+    if ((d->conv_k != 3 || conv256) && !d->shuf && (d->N & 255) == 0 && blocks256 >= t256_min && fills) return 256;
+    // 192 x 128 (48 x 64 per wave: fewer LDS reads and L2->LDS bytes per FLOP than 128^2, still two workgroups per CU): round 2
+    // A/B (tools/bench_gemm_r2.py, same box): +8-11 % on the DPT 3x3 convolutions with 128 output channels (head.0, head.2) and
+    // on the 96x128 fusion convolutions; level on the M ~ 6k decoder projections, so it is the default for convolutions with
+    // enough tiles to fill the chip and an explicit choice (tile = 192128, CUT3R_GEMM_T192_MIN_M) elsewhere
     static const long long t192_min = [] { const char* e = getenv("CUT3R_GEMM_T192_MIN_M"); return e ? atoll(e) : (1LL << 60); }();
+    static const int conv192 = [] { const char* e = getenv("CUT3R_GEMM_CONV192"); return e ? atoi(e) : 1; }();
+    const long long blocks192 = (long long)((d->M + 191) / 192) * ((d->N + 127) / 128) * batch;
+    if (d->conv_k == 3 && conv192 && !d->shuf && blocks192 >= 512) return 192128;
     if (!d->shuf && d->M >= t192_min && big_blocks >= 128) return 192128;
     return (big_blocks >= 128) ? 128 : 64;
 }
 
-extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
+// validation + translation of a descriptor into kernel arguments (shared by the single and the pair entry point)
+static int fill_args(const cut3r_gemm_desc* d, GemmArgs& g) {
     if (!d || !d->A || !d->B || !d->C) return CUT3R_ERR_ARG;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return CUT3R_ERR_ARG;
     if ((d->K & 7) || (d->N & 3) || (d->ldb & 7) || (d->ldc & 3)) return CUT3R_ERR_ARG;
@@ -829,7 +859,6 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     if (d->res1 && (d->ldr1 & 3)) return CUT3R_ERR_ARG;
     if (d->res2 && (d->ldr2 & 3)) return CUT3R_ERR_ARG;
     if (d->shuf && ((d->shuf_cout & 3) || d->N != d->shuf * d->shuf * d->shuf_cout)) return CUT3R_ERR_ARG;
-    GemmArgs g;
     g.A = (const h16*)d->A; g.B = (const h16*)d->B; g.C = d->C;
     g.bias = d->bias; g.res1 = d->res1; g.res2 = d->res2;
     g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.ldr1 = d->ldr1; g.ldr2 = d->ldr2;
@@ -852,6 +881,13 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         if (g.rope_d == 48 && cut3r_gemm_tile_for(d) != 128192) return CUT3R_ERR_ARG;     // 48-wide heads need the 192-column tile
         if (g.rope_d == 64 && (d->N & 63)) return CUT3R_ERR_ARG;
     }
+    return CUT3R_OK;
+}
+
+extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
+    GemmArgs g;
+    const int rc = fill_args(d, g);
+    if (rc != CUT3R_OK) return rc;
     const int batch = d->batch > 0 ? d->batch : 1;
     hipStream_t s = (hipStream_t)stream;
     const int tile = cut3r_gemm_tile_for(d);
@@ -903,6 +939,46 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         else if (d->stages == 8 || (d->stages == 0 && d->K >= 2048)) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4>), grid, dim3(512), 0, s, g);   // long K: 8 waves
         else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<64, 64, 4>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((gemm_kernel<64, 64, 3>), grid, dim3(256), 0, s, g);
+    } else {
+        return CUT3R_ERR_ARG;
+    }
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_gemm_f16_pair(const cut3r_gemm_desc* d0, const cut3r_gemm_desc* d1, void* stream) {
+    if (!d0 || !d1) return CUT3R_ERR_ARG;
+    GemmPairArgs a;
+    int rc = fill_args(d0, a.p[0]);
+    if (rc != CUT3R_OK) return rc;
+    rc = fill_args(d1, a.p[1]);
+    if (rc != CUT3R_OK) return rc;
+    // plain linears only, one problem each (no batch), same N and K so both take the same tile kernel
+    for (const cut3r_gemm_desc* d : {d0, d1})
+        if (d->conv_k == 3 || d->shuf || d->relu_in || (d->rope_pos && d->rope_cols) || (d->batch > 1)) return CUT3R_ERR_ARG;
+    if (d0->N != d1->N || d0->K != d1->K) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    // tile choice on the COMBINED grid (the two problems fill the chip together)
+    int tile = d0->tile;
+    if (tile == 0) {
+        const long long t256 = (long long)((d0->M + 255) / 256 + (d1->M + 255) / 256) * ((d0->N + 255) / 256);
+        const long long rounds = (t256 + 255) / 256;
+        const bool fills = rounds == 1 || t256 * 100 >= rounds * 256 * 85;
+        tile = ((d0->N & 255) == 0 && t256 >= 128 && fills) ? 256 : 128;
+    }
+    if (tile == 256) {
+        const int n0 = ((d0->N + 255) / 256) * ((d0->M + 255) / 256), n1 = ((d1->N + 255) / 256) * ((d1->M + 255) / 256);
+        a.nblk0 = n0;
+        hipLaunchKernelGGL(gemm256_pair_kernel, dim3(n0 + n1), dim3(512), 0, s, a);
+    } else if (tile == 128) {
+        const int n0 = ((d0->N + 127) / 128) * ((d0->M + 127) / 128), n1 = ((d1->N + 127) / 128) * ((d1->M + 127) / 128);
+        a.nblk0 = n0;
+        a.p[0].swz = a.p[1].swz = 1;
+        hipLaunchKernelGGL((gemm_pair_kernel<128, 128, 2, 4, 2>), dim3(n0 + n1), dim3(512), 0, s, a);
+    } else if (tile == 192128) {
+        const int n0 = ((d0->N + 127) / 128) * ((d0->M + 191) / 192), n1 = ((d1->N + 127) / 128) * ((d1->M + 191) / 192);
+        a.nblk0 = n0;
+        a.p[0].swz = a.p[1].swz = 1;
+        hipLaunchKernelGGL((gemm_pair_kernel<192, 128, 2, 4, 2>), dim3(n0 + n1), dim3(512), 0, s, a);
     } else {
         return CUT3R_ERR_ARG;
     }

@@ -77,6 +77,11 @@ class Cut3rModel:
         # pair, model.py:669-692): issue them on two streams so the captured graph has two parallel branches
         self.dual_stream = _os.environ.get("CUT3R_DUAL_STREAM", "1") != "0"
         self.dual_ln = _os.environ.get("CUT3R_DUAL_LN", "1") != "0"            # shared-statistics LayerNorm of the decoder inputs
+        # the seven projections of a decoder layer as pair launches (state + image problem in one grid: cut3r_gemm_f16_pair).
+        # OFF by default: measured -5 % end to end (97.4 -> 102.8 ms per 400-frame step, same box, interleaved runs): the pair
+        # launches are 30-40 % faster than the two launches they replace, but they join the two blocks at every projection, and
+        # the step loses the overlap of one block's MFMA-bound GEMMs with the other block's VALU-bound attention / LayerNorm
+        self.pair_gemm = _os.environ.get("CUT3R_PAIR_GEMM", "0") != "0"
         # RoPE in the q/k projection epilogue: 0 off (default), 1 heads of 64, 2 also heads of 48.  Bit-identical to the
         # stand-alone kernel; +1 % when the decoder ran alone, -2.5 % now that encoder / head kernels fill its gaps (the
         # heavier epilogue lengthens every projection on the critical path, the small RoPE kernel overlaps for free)
@@ -238,6 +243,11 @@ class Cut3rModel:
             rope = (rope[0], rope[1], self.cfg.rope_freq, rope[2])
         return ops.linear(x16, L.w, out, L.b, act, res1, res2, tile=16 if skinny else 0, rope=rope)
 
+    def _linear_pair(self, x0, name0, out0, x1, name1, out1, act=0, res0=None, res1=None):
+        """the same projection of the state-side and the image-side decoder block in ONE launch (ops.linear_pair)"""
+        L0, L1 = self.w[name0], self.w[name1]
+        ops.linear_pair((x0, L0.w, out0, L0.b, res0), (x1, L1.w, out1, L1.b, res1), act)
+
     def _fuse_rope(self, pos, D, rows):
         """the GEMM-fused RoPE covers head dimension 64 with one position row per GEMM row"""
         dims = (64, 48) if self.fused_rope == 2 else (64,)
@@ -392,6 +402,78 @@ class Cut3rModel:
         self._ln(out, p + ".norm3", out16=ln16)
         self._mlp(tag, ln16, p + ".mlp", out, out, skinny=(Nx == 1))
         return out
+
+    def _dec_layer_pair(self, l, a, s_a, b, s_b, pos_img, pos_state, Wn, fork=False):
+        """Decoder layer l for BOTH streams: image block (a, s_a) -> b and state block (s_a, a) -> s_b (model.py:669-692, both
+        read the previous layer's pair).  The seven projections of a block run as seven PAIR launches (state + image problem in
+        one grid, ops.linear_pair); LayerNorm / RoPE / attention stay per side (different token counts and head widths: 16 x 48
+        state heads, 12 x 64 image heads) and, under graph capture with `fork`, on two streams.  Same kernels and row arithmetic as
+        `_dec_block`: bit-identical results."""
+        cfg = self.cfg
+        Cc = a.shape[1]
+        ps, pi = f"dec_blocks_state.{l}", f"dec_blocks.{l}"
+        Ni, Ns = a.shape[0] // Wn, s_a.shape[0] // Wn
+        hs, hi = cfg.state_dec_num_heads, cfg.dec_num_heads
+        Ds, Di = Cc // hs, Cc // hi
+        S = dict(tag="decs", p=ps, x=s_a, y=a, xpos=pos_state, ypos=pos_img, heads=hs, D=Ds, out=s_b, Nx=Ns, Ny=Ni)
+        I = dict(tag="deci", p=pi, x=a, y=s_a, xpos=pos_img, ypos=pos_state, heads=hi, D=Di, out=b, Nx=Ni, Ny=Ns)
+        for sd in (S, I):
+            t, Nx, Ny, h, D = sd["tag"], sd["Nx"], sd["Ny"], sd["heads"], sd["D"]
+            sd["ln16"] = self.buf(t + ".ln16", (Wn * Nx, Cc), F16)
+            sd["y16"] = self.buf(t + ".y16", (Wn * Ny, Cc), F16)
+            sd["qkv"] = self.buf(t + ".qkv", (Wn * Nx, 3 * Cc), F16)
+            sd["att"] = self.buf(t + ".attn", (Wn, Nx, h, D), F16)
+            sd["q"] = self.buf(t + ".q", (Wn, Nx, h, D), F16)
+            sd["kv"] = self.buf(t + ".kv", (Wn * Ny, 2 * Cc), F16)
+            sd["catt"] = self.buf(t + ".cattn", (Wn, Nx, h, D), F16)
+            sd["h"] = self.buf(t + ".mlp_h", (Wn * Nx, self.w[sd["p"] + ".mlp.fc1"].npad), F16)
+
+        def both(fn):
+            """fn(side) for the state and the image side; on two capture streams when forking"""
+            if fork:
+                cur = torch.cuda.current_stream()
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    fn(S)
+                fn(I)
+                cur.wait_stream(self._side)
+            else:
+                fn(S)
+                fn(I)
+
+        if self.dual_ln and Cc in (768, 1024, 1536):
+            self._dual_norms(l, a, s_a)
+        else:
+            both(lambda sd: (self._ln(sd["x"], sd["p"] + ".norm1", out16=sd["ln16"]), self._ln(sd["y"], sd["p"] + ".norm_y", out16=sd["y16"])))
+        # ---- self attention
+        self._linear_pair(S["ln16"], ps + ".attn.qkv", S["qkv"], I["ln16"], pi + ".attn.qkv", I["qkv"])
+
+        def self_attn(sd):
+            v5 = sd["qkv"].view(Wn, sd["Nx"], 3, sd["heads"], sd["D"])
+            q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
+            ops.rope_2d_qk(q, k, sd["xpos"], cfg.rope_freq, 1.0)
+            ops.attention(q, k, v, sd["att"], sd["D"] ** -0.5)
+        both(self_attn)
+        self._linear_pair(S["att"].view(Wn * Ns, Cc), ps + ".attn.proj", S["out"], I["att"].view(Wn * Ni, Cc), pi + ".attn.proj", I["out"],
+                          res0=S["x"], res1=I["x"])
+        # ---- cross attention
+        both(lambda sd: self._ln(sd["out"], sd["p"] + ".norm2", out16=sd["ln16"]))
+        self._linear_pair(S["ln16"], ps + ".cross_attn.projq", S["q"].view(Wn * Ns, Cc), I["ln16"], pi + ".cross_attn.projq", I["q"].view(Wn * Ni, Cc))
+        self._linear_pair(S["y16"], ps + ".cross_attn.projkv", S["kv"], I["y16"], pi + ".cross_attn.projkv", I["kv"])
+
+        def cross_attn(sd):
+            kv4 = sd["kv"].view(Wn, sd["Ny"], 2, sd["heads"], sd["D"])
+            k, v = kv4[:, :, 0], kv4[:, :, 1]
+            self._rope(sd["q"], sd["xpos"])
+            self._rope(k, sd["ypos"])
+            ops.attention(sd["q"], k, v, sd["catt"], sd["D"] ** -0.5)
+        both(cross_attn)
+        self._linear_pair(S["catt"].view(Wn * Ns, Cc), ps + ".cross_attn.proj", S["out"], I["catt"].view(Wn * Ni, Cc), pi + ".cross_attn.proj", I["out"],
+                          res0=S["out"], res1=I["out"])
+        # ---- MLP
+        both(lambda sd: self._ln(sd["out"], sd["p"] + ".norm3", out16=sd["ln16"]))
+        self._linear_pair(S["ln16"], ps + ".mlp.fc1", S["h"], I["ln16"], pi + ".mlp.fc1", I["h"], act=1)
+        self._linear_pair(S["h"], ps + ".mlp.fc2", S["out"], I["h"], pi + ".mlp.fc2", I["out"], res0=S["out"], res1=I["out"])
 
     def _dual_norms(self, l, a, s_a):
         """The four input norms of decoder layer l in two launches: the image tokens `a` feed norm1 of the image block and
@@ -620,19 +702,22 @@ class Cut3rModel:
                     s_a, s_b = s_b, s_a
                     a, b = b, a
                     continue
-                pre = self.dual_ln and D in (768, 1024, 1536)
-                if pre:
-                    self._dual_norms(l, a, s_a)
-                if fork:
-                    cur = torch.cuda.current_stream()
-                    self._side.wait_stream(cur)
-                    with torch.cuda.stream(self._side):
-                        self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre)
-                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre)
-                    cur.wait_stream(self._side)
+                if self.pair_gemm:
+                    self._dec_layer_pair(l, a, s_a, b, s_b, pos_img, pos_state, Wn, fork=fork)
                 else:
-                    self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre)
-                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre)
+                    pre = self.dual_ln and D in (768, 1024, 1536)
+                    if pre:
+                        self._dual_norms(l, a, s_a)
+                    if fork:
+                        cur = torch.cuda.current_stream()
+                        self._side.wait_stream(cur)
+                        with torch.cuda.stream(self._side):
+                            self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre)
+                        self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre)
+                        cur.wait_stream(self._side)
+                    else:
+                        self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre)
+                        self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre)
                 s_a, s_b = s_b, s_a
                 a, b = b, a
                 if l + 1 == h1 or l + 1 == h2:

@@ -198,6 +198,35 @@ def linear(A, W, out, bias=None, act=0, res1=None, res2=None, tile=0, rope=None)
     return out
 
 
+def _linear_desc(A, W, out, bias, act, res1, tile):
+    _cuda(A, W, out, bias, res1)
+    _req(A.dtype == F16 and W.dtype == F16 and A.dim() == 2 and W.dim() == 2, "A,W must be 2-D fp16")
+    M, K = A.shape
+    N = W.shape[0]
+    _req(W.shape[1] == K and out.shape == (M, N), f"shape mismatch A{tuple(A.shape)} W{tuple(W.shape)} out{tuple(out.shape)}")
+    _req(A.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1, "unit inner strides required")
+    _req(out.dtype in (F16, F32), "out must be fp16 or fp32")
+    if bias is not None:
+        _req(bias.dtype == F32 and bias.numel() == N and bias.is_contiguous(), "bias fp32 [N]")
+    if res1 is not None:
+        _req(res1.shape == (M, N), "residual shape")
+    d = GemmDesc()
+    _fill_common(d, A, W, out, bias, res1, None, act, tile)
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, A.stride(0), W.stride(0), out.stride(0)
+    return d
+
+
+def linear_pair(p0, p1, act=0, tile=0):
+    """Two independent linears in ONE launch (cut3r_gemm_f16_pair): p = (A [M,K], W [N,K], out [M,N], bias | None, res1 | None)
+    with the same N and K; rows are bit-identical to ops.linear.  The decoder runs its state-side and image-side projection of a
+    layer this way."""
+    d0 = _linear_desc(p0[0], p0[1], p0[2], p0[3], act, p0[4], tile)
+    d1 = _linear_desc(p1[0], p1[1], p1[2], p1[3], act, p1[4], tile)
+    _req(d0.N == d1.N and d0.K == d1.K, "pair: same N and K")
+    lib = _lib.load()
+    check(lib.cut3r_gemm_f16_pair(C.byref(d0), C.byref(d1), _stream()), f"cut3r_gemm_f16_pair M={d0.M}+{d1.M} N={d0.N} K={d0.K}")
+
+
 def linear_batched(A, W, out, bias=None, act=0, res1=None, tile=0):
     """Z independent problems in ONE launch (blockIdx.z): A [Z,M,K], W [Z,N,K] fp16; out [Z,M,N] fp16|fp32;
     bias [Z,N] fp32; res1 [Z,M,N].  Used to run the state-side and image-side decoder GEMMs of a layer together."""

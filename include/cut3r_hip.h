@@ -82,6 +82,11 @@ int cut3r_rope2d_table(float* table, int pmin, int npos, int Q, float base, floa
  * summation order, so callers request it for operands whose row count is the batch (one row per tracking window) and
  * keep every other GEMM on the tile kernels, whose rows are bit-identical across tile sizes and batch sizes. */
 int cut3r_gemm_tile_for(const cut3r_gemm_desc* d);
+/* TWO independent linear problems (same N, K; own operands, row counts and epilogues) in ONE launch: the state-side and the
+ * image-side GEMM of a decoder layer -- both DecoderBlocks of a layer read the previous layer's pair
+ * (src/dust3r/model.py:669-692), so they are independent; one grid over both fills the chip where each alone does not.
+ * Plain linears only (no convolution / pixel shuffle / fused RoPE / batch).  Rows are bit-identical to cut3r_gemm_f16. */
+int cut3r_gemm_f16_pair(const cut3r_gemm_desc* d0, const cut3r_gemm_desc* d1, void* stream);
 
 /* skinny M<=64 path: Y[M,N] = act(X[M,K] (fp32, optional SiLU on load) * W[N,K]^T (fp16) + bias) (+res) */
 int cut3r_gemv_f16w(const float* X, int ldx, const void* W, int ldw, const float* bias, float* Y, int ldy,

@@ -73,7 +73,7 @@ def test_precision_budget_medium_config_vs_tf32_emulation():
     model = Cut3rModel(cfg, sd, DEV, minimal=True)
     preds, taps = model.forward_window(imgs.to(DEV), return_taps=True)
     torch.cuda.synchronize()
-    _budget("medium 4 views", preds, ref32, reftf, {"camera_pose": 2e-3, "pts3d_in_self_view": 6e-3, "conf_self": 6e-3})
+    _budget("medium 4 views", preds, ref32, reftf, {"camera_pose": 6e-3, "pts3d_in_self_view": 8e-3, "conf_self": 4e-3})
     for i in range(4):
         e_hip = _rel(taps["states"][i][0][None], st32[i + 1][0])
         e_tf = _rel(sttf[i + 1][0], st32[i + 1][0])

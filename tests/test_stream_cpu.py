@@ -169,3 +169,17 @@ def test_remap_oracle_identity_shift_and_border():
     assert np.array_equal(out[:, :-1], exp.astype(np.uint8))
     assert np.array_equal(out[:, -1], ((img[:, -1].astype(np.int64) * 16384 + 16384) >> 15).astype(np.uint8))    # border value 0 beyond the edge
     assert np.array_equal(G.remap_linear_u8(img, 32 * jj - 64, 32 * ii)[:, :2], np.zeros((9, 2, 3), np.uint8))   # fully outside
+
+
+def test_reference_import_names_resolve_from_the_compat_directory():
+    """`import curope`, `from lietorch import SE3`, `import droid_backends` with cut3r_slam_amd/compat on sys.path (a fresh
+    interpreter, nothing else pre-imported): the names the reference imports (curope2d.py:7-10, track_backend.py:6, corr.py:4)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, r'%s'); import curope, lietorch, droid_backends; from lietorch import SE3, SO3, Sim3; "
+            "assert callable(curope.rope_2d) and hasattr(droid_backends, 'corr_index_forward') and hasattr(SE3, 'exp'); print('ok')"
+            % os.path.join(root, "cut3r_slam_amd", "compat"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
