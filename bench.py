@@ -400,7 +400,9 @@ def main():
     if dump:                               # tests: the replicated result of every rank
         k = slam.tracker.t1
         ii, jj, age = slam.graph.edges_numpy()
-        np.savez(f"{dump}.rank{rank}.npz", pose=slam.keyframes.pose[:k].numpy(), depth_sum=slam.keyframes.depth[:k].double().sum(dim=(1, 2)).cpu().numpy(),
+        # (depth of the last keyframe: written by the owner of the last window only until the next window rewrites it)
+        np.savez(f"{dump}.rank{rank}.npz", pose=slam.keyframes.pose[:k].numpy(), depth_sum=slam.keyframes.depth[:k - 1].double().sum(dim=(1, 2)).cpu().numpy(),
+                 submap_sum=slam.keyframes.submap_ds[:(k - 1) // 5].double().sum(dim=(2, 3, 4)).cpu().numpy(),
                  w2c=slam.keyframes.w2c[:k].cpu().numpy(), ii=ii, jj=jj, k=k)
 
     roofline, cpu_base, op_points, traj = None, None, None, None

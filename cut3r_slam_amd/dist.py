@@ -8,11 +8,14 @@ chaining (/root/reference/hislam2/track_frontend.py:216-234: needs the previous 
 graph decisions are sequential.  Per step every rank
   1. pushes `wb` consecutive windows through the network in one batched pass (encoder for its new keyframes, decoder +
      heads batched over the windows),
-  2. exchanges the three consumed outputs (pts3d_in_self_view, conf_self, camera_pose: 19 MB per window at 384x512) with
-     ONE all_gather per tensor,
-  3. replays the chaining of all world*wb windows in sequence order (O(1) device work per window: the keyframe store stays
-     replicated, any rank can serve the trajectory), counts the O(#keyframes) reprojection overlaps only for the windows
-     it owns, sums the owners' counts with one small all-reduce, and takes the graph decisions (host only, replicated).
+  2. exchanges 352 bytes per window: the two log-depth sums and the six raw poses the chain needs (all_gather), after which
+     every rank knows every scale and every chained pose by a host scan (log-scales add, poses compose: SURVEY 8(e)(2)),
+  3. aligns and stores ITS OWN windows (O(wb) device work), completes the stride-2 pointmap / confidence stores of the step
+     with two in-place all_gathers (4.7 MB per window instead of the 19 MB of full-resolution outputs; depth rows only on
+     request), counts the O(#keyframes) reprojection overlaps for its own windows, sums the owners' counts with one small
+     all-reduce, and takes the graph decisions (host only, replicated).
+  (world == 1 keeps the sequential replay of TrackFrontend.track_many, which reads the stored depth like the reference;
+  CUT3R_SCAN=1 forces the scan form, whose results are bit-identical for every world size.)
 
 Pipelining: the replay of step s runs on a side HIP stream while the encoder graph of step s+1 executes on the main
 stream; the decoder graph of step s+1 is launched after the replay has been issued (a graph with parallel branches
@@ -76,6 +79,12 @@ class ShardedTracker:
         self._enc_stream, self._ahead = None, None        # look-ahead encoder pass: (ranges, features, event)
         self.encode_ahead = os.environ.get("CUT3R_ENC_AHEAD", "1") == "1"
         self.side_priority = int(os.environ.get("CUT3R_SIDE_PRIORITY", "0"))         # 0: measured best; -1 (high) starves the network pass once the host runs ahead
+        # scan form of the replay (TrackFrontend.track_sharded): every rank stores and counts only ITS windows; scalars, the
+        # stride-2 stores and the counts are exchanged.  Always on with more than one rank; CUT3R_SCAN=1 forces it for one rank
+        # (bit-identical to the multi-rank result by construction: same scalars, same host scan)
+        self.scan = world > 1 or force_collective or os.environ.get("CUT3R_SCAN", "0") == "1"
+        self.replicate_depth = os.environ.get("CUT3R_REPLICATE_DEPTH", "0") == "1"
+        self._chain = None
         self.stats = {"append_s": 0.0, "issue_s": 0.0, "issue_enc_s": 0.0, "replay_s": 0.0, "replay_wait_s": 0.0, "exchange_s": 0.0, "steps": 0}     # host wall-clock per phase
 
     def frames_needed(self, total_steps: int, kf_every: int, win: int) -> int:
@@ -140,8 +149,8 @@ class ShardedTracker:
             self._side.wait_event(ev)
             ev.synchronize()                        # pinned pose copy complete (issued a whole network pass ago)
             self.stats["replay_wait_s"] += time.perf_counter() - tic
-            for g in gathered:
-                if g.is_cuda:
+            for g in (gathered if not self.scan or self.track_fn is not None else [t for o in gathered[0] for t in o]):
+                if torch.is_tensor(g) and g.is_cuda:
                     g.record_stream(self._side)     # allocated on the main stream, consumed on the side stream
             ctx = torch.cuda.stream(self._side)
         else:
@@ -150,6 +159,11 @@ class ShardedTracker:
                 self.stats["replay_wait_s"] += time.perf_counter() - tic
             ctx = contextlib.nullcontext()
         with ctx:
+            if self.scan and self.track_fn is None:
+                fin = self._replay_scan(ranges_all, gathered, defer)
+                self.slam.tracker.t1 = ranges_all[-1][1]
+                self.stats["replay_s"] += time.perf_counter() - tic
+                return fin
             outs = [tuple(g[j * V:(j + 1) * V] for g in gathered) for j in range(len(ranges_all))]
             if self.track_fn is not None:
                 for (a, b), o in zip(ranges_all, outs):
@@ -165,6 +179,62 @@ class ShardedTracker:
                 self.slam.tracker.t1 = ranges_all[-1][1]
         self.stats["replay_s"] += time.perf_counter() - tic
         return fin
+
+    # ---- scan-form replay (multi-GPU)
+    def _gather_rows(self, block, per_rank):
+        """in-place all-gather of `block` [world * per_rank, ...] (this rank's rows already hold its own data)"""
+        world, rank = self.world, self.rank
+        if self.emulate_gather:
+            own = block[rank * per_rank:(rank + 1) * per_rank]
+            for r in range(world):                       # debug: stand-in traffic for the other ranks' rows
+                if r != rank:
+                    block[r * per_rank:(r + 1) * per_rank].copy_(own)
+            return
+        if not dist.is_initialized() or (world == 1 and not self.force_collective):
+            return
+        if block.is_cuda and dist.get_backend() == "nccl":
+            own = block[rank * per_rank:(rank + 1) * per_rank]
+            dist.all_gather_into_tensor(block.view(-1), own.reshape(-1))       # RCCL in-place form: own rows are the rank's chunk
+        else:
+            own = block[rank * per_rank:(rank + 1) * per_rank].cpu()
+            parts = [torch.empty_like(own) for _ in range(world)]
+            dist.all_gather(parts, own)                                        # gloo (CPU tests; two ranks on one GPU)
+            for r in range(world):
+                if r != rank:
+                    block[r * per_rank:(r + 1) * per_rank].copy_(parts[r])
+
+    def _gather_store(self, sub0, n, phase):
+        kf = self.slam.keyframes
+        if phase == 0:
+            self._gather_rows(kf.submap_ds[sub0:sub0 + n], self.wb)
+            self._gather_rows(kf.conf_ds[sub0:sub0 + n], self.wb)
+        elif self.replicate_depth:                       # rows of views 0..4 of every window (a keyframe's final depth)
+            self._gather_rows(kf.depth[sub0 * 5:(sub0 + n) * 5], self.wb * 5)
+
+    def _replay_scan(self, ranges_all, payload, defer):
+        own_outs, scal = payload
+        tr = self.slam.tracker
+        if self._chain is None:
+            self._chain = tr.chain_state(ranges_all[0][0])
+        i0 = self.rank * self.wb
+        return tr.track_sharded(ranges_all, (i0, i0 + self.wb), own_outs, scal.numpy(), self._chain, self._gather_store,
+                                self._exchange_counts, defer_decisions=defer)
+
+    def _exchange_scalars(self, scal_own):
+        """[wb, 44] fp64 device -> [world * wb, 44] (rank order = window order)"""
+        world = self.world
+        if self.emulate_gather:
+            return torch.cat([scal_own] * world, 0)
+        if not dist.is_initialized() or (world == 1 and not self.force_collective):
+            return scal_own
+        if scal_own.is_cuda and dist.get_backend() == "nccl":
+            buf = torch.empty((world,) + tuple(scal_own.shape), dtype=scal_own.dtype, device=scal_own.device)
+            dist.all_gather_into_tensor(buf.view(-1), scal_own.reshape(-1))
+            return buf.view(-1, scal_own.shape[1])
+        host = scal_own.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        return torch.cat(parts, 0).to(scal_own.device)
 
     def _append_range(self, frames, t, n_frames, kf_every, win, intr, first_t0):
         """register the keyframes among frames t..t+n_frames-1 (once: a look-ahead may already have done it)"""
@@ -241,6 +311,27 @@ class ShardedTracker:
                 tic = time.perf_counter()
                 fin()
                 self.stats["replay_s"] += time.perf_counter() - tic
+        if self.scan and self.infer_fn is None:
+            # 4s. scan form: the three outputs stay on this rank (private copies: the graph's buffers are rewritten by the next
+            #     pass); only [wb, 44] fp64 scalars per rank cross the links now, the stores follow in the replay
+            tic = time.perf_counter()
+            V = self.views
+            own = [tuple(o[j * V:(j + 1) * V].clone() for o in outs) for j in range(wb)]
+            scal = self._exchange_scalars(slam.tracker.window_scalars(own))
+            slot = self.stats["steps"] & 1
+            if self._pose_pinned[slot] is None or self._pose_pinned[slot].shape != scal.shape or self._pose_pinned[slot].dtype != scal.dtype:
+                self._pose_pinned[slot] = torch.empty(tuple(scal.shape), dtype=scal.dtype).pin_memory()
+            scal_host = self._pose_pinned[slot]
+            scal_host.copy_(scal, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.stats["exchange_s"] += time.perf_counter() - tic
+            self.stats["steps"] += 1
+            self._pending = (ranges_all, (own, scal_host), ev)
+            self._next_t0 = ranges_all[-1][1] - 1
+            if not self.pipelined:
+                self.flush()
+            return t + n_frames
         # 4. one exchange over xGMI (private copies when world == 1)
         tic = time.perf_counter()
         if self.emulate_gather:      # debug (bench CUT3R_EMULATE_WORLD): this rank's outputs stand in for every other rank's

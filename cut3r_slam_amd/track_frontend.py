@@ -290,6 +290,128 @@ class TrackFrontend:
             finish()
         return None
 
+    # ------------------------------------------------------------------ multi-GPU: scan form of the chaining
+    # The chain is a scan: window k's scale is exp(mean(log depth_stored[t0] - log d_k[view 0])) with depth_stored[t0] =
+    # s_{k-1} * d_{k-1}[view 5] (track_frontend.py:216-222, 235), i.e.
+    #       log s_k = log s_{k-1} + ( sum log d_{k-1}[view 5] - sum log d_k[view 0] ) / (H W),
+    # and the poses compose through the 7-float pose of the shared keyframe.  So a rank only needs TWO fp64 sums and the 6 raw
+    # poses of every other rank's windows (352 bytes per window) to know every scale and every chained pose; it then aligns and
+    # stores ITS OWN windows, the stride-2 stores are all-gathered in place, it counts overlaps for its own windows against the
+    # now complete store, and one small all-reduce sums the counts.  Per rank and step: O(window_batch) device work + O(world *
+    # window_batch) host 4x4 math.  (log(fl32(s d)) vs log s + log d differ at the 1e-7 level: results agree
+    # with the sequential form to fp32 rounding, and are bit-identical across ranks and across world sizes.)
+    def window_scalars(self, outs):
+        """device fp64 [n, 44] per window: (sum log z of view 0, sum log z of the last view, the V x 7 raw pose encodings)"""
+        n = len(outs)
+        V, H, W, _ = outs[0][0].shape
+        if getattr(self, "_ones_hw", None) is None or self._ones_hw.shape != (H, W):
+            self._ones_hw = torch.ones(H, W, device=self.device)
+            self._ones_pts = torch.ones(H, W, 3, device=self.device)
+        acc = torch.zeros(n, 2, dtype=torch.float64, device=self.device)
+        for j, (pts, _, _) in enumerate(outs):
+            ops.logdepth_accum(self._ones_hw, pts[0], acc[j, 0:1])          # sum(log 1 - log z) = -sum log z
+            ops.logdepth_accum(self._ones_hw, pts[V - 1], acc[j, 1:2])
+        poses = torch.stack([o[2].detach().reshape(-1) for o in outs], 0).to(self.device, torch.float64)
+        return torch.cat([-acc, poses], 1)
+
+    def chain_state(self, t0):
+        """scan state in front of the window that starts at keyframe t0: log-scale 0 with the STORED depth of that keyframe"""
+        kf = self.keyframes
+        H, W = kf.ht, kf.wd
+        if getattr(self, "_ones_hw", None) is None or self._ones_hw.shape != (H, W):
+            self._ones_hw = torch.ones(H, W, device=self.device)
+            self._ones_pts = torch.ones(H, W, 3, device=self.device)
+        acc = torch.zeros(1, dtype=torch.float64, device=self.device)
+        ops.logdepth_accum(kf.depth[t0], self._ones_pts, acc)                 # sum(log stored - log 1)
+        return {"log_s": 0.0, "L5": float(acc.item())}
+
+    def track_sharded(self, ranges, own, outs_own, scal, chain, gather_store, exchange_counts, defer_decisions=False):
+        """One step of the multi-GPU tracker.  ranges: ALL windows of the step, in order; own = (i0, i1): the ones this rank
+        inferred, with outputs outs_own [(pts, conf, pose_enc)]; scal: host float64 [len(ranges), 44] from every rank's
+        window_scalars; chain: scan state (updated in place).  gather_store(sub0, n, phase) completes the stride-2 stores (phase 0) /
+        the depth rows (phase 1) of submaps sub0..sub0+n-1 on every rank; exchange_counts sums the owners' int32 counts."""
+        kf, graph, ds = self.keyframes, self.graph, self.downsample_ratio
+        H, W = kf.ht, kf.wd
+        h, w = kf.submap_ds.shape[2:4]
+        n = len(ranges)
+        i0, i1 = own
+        per = []
+        # ---- host scan: scale and chained poses of every window of the step
+        for k, (t0, t1) in enumerate(ranges):
+            V = t1 - t0
+            L0, L5 = float(scal[k, 0]), float(scal[k, 1])
+            host = np.asarray(scal[k, 2:2 + 7 * V], np.float64).reshape(V, 7).astype(np.float32)
+            poses = gh.pose_encoding_to_camera(host)
+            first_w2c = gh.inv4(poses[0])
+            lsum = chain["log_s"] * (H * W) + chain["L5"] - L0
+            align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
+            prev_c2w = gh.pose_vec_to_matrix(kf.pose[t0].numpy()[None])[0]
+            chained = [gh.chain_pose(first_w2c, poses[v], prev_c2w[:3, :3], prev_c2w[:3, 3], align_s) for v in range(V)]
+            rows = kf.set_poses(t0, gh.matrices_to_pose_vecs(np.stack(chained)), upload=False)
+            chain["log_s"], chain["L5"] = math.log(float(align_s)), L5
+            per.append((chained, align_s, rows))
+        # device mirror of every new world->camera row (other ranks' windows included: the forward counts need all cameras)
+        ta, tb = ranges[0][0], ranges[-1][1]
+        allrows = np.zeros((tb - ta, 12), np.float32)
+        for (t0, t1), (_, _, rows) in zip(ranges, per):
+            allrows[t0 - ta:t1 - ta] = rows
+        if getattr(self, "_rows_pinned", None) is None or self._rows_pinned.shape[0] < tb - ta:
+            self._rows_pinned = torch.zeros(max(64, tb - ta), 12).pin_memory()
+        self._rows_pinned[:tb - ta].copy_(torch.from_numpy(allrows))
+        kf.w2c[ta:tb].copy_(self._rows_pinned[:tb - ta], non_blocking=True)
+        L = ((tb + 63) // 64) * 64
+        nown = i1 - i0
+        cm = getattr(self, "_counts_many", None)
+        if cm is None or cm.shape[0] < nown or cm.shape[-1] < L:
+            self._counts_many = torch.zeros(nown, 6, 2, max(256, 2 * L), dtype=torch.int32, device=self.device)
+            self._counts_many_host = torch.zeros(tuple(self._counts_many.shape), dtype=torch.int32).pin_memory()
+        intr_all = kf.intrinsic[ta:tb].numpy()
+
+        def update(k, counting):
+            (t0, t1), (pts, conf, _), (chained, s_win, rows) = ranges[k], outs_own[k - i0], per[k]
+            V = t1 - t0
+            intr = intr_all[t0 - ta:t1 - ta]
+            if not all(np.array_equal(intr[v], intr[0]) for v in range(V)):
+                raise NotImplementedError("sharded tracking assumes one calibration per window")
+            sub = t0 // 5
+            ops.window_update(pts, conf, np.concatenate([c[:3, :4].reshape(-1) for c in chained]), float(s_win), ds,
+                              kf.submap_ds[sub, :V], kf.conf_ds[sub, :V], kf.depth[t0:t1], kf.submap_ds, kf.w2c, t0,
+                              3 if counting else (1 << 30), [float(x) for x in intr[0]], self._counts_many[k - i0, :V], w2c_new=rows.reshape(-1))
+
+        # ---- phase A: align + store the own windows; phase B: complete the stores; phase C: count for the own windows
+        for k in range(i0, i1):
+            update(k, False)
+        gather_store(ranges[0][0] // 5, n, 0)          # stride-2 pointmaps + confidences of every window of the step
+        all_counts = torch.zeros(n, 6, 2, L, dtype=torch.int32)
+        if self._ev is None:
+            self._ev = torch.cuda.Event()
+        for k in range(i0, i1):
+            update(k, True)
+        # a keyframe shared by two windows keeps the LATER window's pose (sequential order of track()): window_update wrote each
+        # own window's rows for its counts; the table of the whole step goes in again so that every rank ends with the same mirror
+        kf.w2c[ta:tb].copy_(self._rows_pinned[:tb - ta], non_blocking=True)
+        gather_store(ranges[0][0] // 5, n, 1)          # (optional) depth rows, after the last local write to them
+        self._counts_many_host[:nown].copy_(self._counts_many[:nown], non_blocking=True)
+        self._ev.record()
+        self._ev.synchronize()                                    # THE round trip of the step's replay
+        for k in range(i0, i1):
+            t0, t1 = ranges[k]
+            all_counts[k, :t1 - t0, :, :t1] = self._counts_many_host[k - i0, :t1 - t0, :, :t1]
+        total = exchange_counts(all_counts).numpy()
+        centres = kf.pose[:tb, :3].numpy()
+
+        def finish():
+            for k, (t0, t1) in enumerate(ranges):
+                done = {}
+                if t1 - 1 >= 3:
+                    for tk, cf, cb in graph.window_tickets(t0, t1, centres, total[k, :t1 - t0], H * W, h * w):
+                        done[tk["idx"]] = (tk, cf.copy(), cb.copy())
+                self._decide(t0, t1, False, done)
+        if defer_decisions:
+            return finish
+        finish()
+        return None
+
     def track_batch(self, ranges):
         """several consecutive 6-keyframe windows: ONE batched decoder/head inference, then the reference's sequential
         chaining + graph update window by window (identical results to calling track() per window)."""

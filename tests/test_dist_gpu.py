@@ -1,4 +1,4 @@
-"""GPU: the multi-rank driver end to end on real kernels.  An 8-GPU node is not available to the tests, so two ranks share
+"""GPU: the multi-rank driver end to end on real kernels (scan-form replay: scalars + stride-2 stores + counts exchanged).  An 8-GPU node is not available to the tests, so two ranks share
 GPU 0 and exchange through gloo (CUT3R_DIST_BACKEND=gloo; RCCL refuses two ranks on one device): window assignment,
 encoder look-ahead, replicated chaining, owner-only overlap counting + count all-reduce, decisions.  Both ranks must end
 with the same poses / stores / ordered edge lists, and these must match a single-rank run over the same windows."""
@@ -35,16 +35,23 @@ def test_two_ranks_on_one_gpu_match_each_other_and_a_single_rank(tmp_path):
     two = str(tmp_path / "two")
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--window-batch", "2"] + common,
-               {"CUT3R_DIST_BACKEND": "gloo", "CUT3R_DUMP_STATE": two})
+               {"CUT3R_DIST_BACKEND": "gloo", "CUT3R_DUMP_STATE": two, "CUT3R_REPLICATE_DEPTH": "1"})
     assert '"n_gpus": 2' in out
     one = str(tmp_path / "one")
     _run([sys.executable, "bench.py", "--window-batch", "4"] + common, {"CUT3R_DUMP_STATE": one})
     r0, r1, s = np.load(two + ".rank0.npz"), np.load(two + ".rank1.npz"), np.load(one + ".rank0.npz")
     assert int(r0["k"]) == int(r1["k"]) == int(s["k"]) == 6 + 5 * 4 * 3            # 3 steps of 4 windows
-    for key in ("pose", "w2c", "depth_sum", "ii", "jj"):
+    for key in ("pose", "w2c", "depth_sum", "submap_sum", "ii", "jj"):
         np.testing.assert_array_equal(r0[key], r1[key], err_msg=key)             # replicated state: bit-identical across ranks
     np.testing.assert_array_equal(r0["ii"], s["ii"])
     np.testing.assert_array_equal(r0["jj"], s["jj"])
     np.testing.assert_allclose(r0["pose"], s["pose"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(r0["depth_sum"], s["depth_sum"], rtol=1e-4)
+    np.testing.assert_allclose(r0["submap_sum"], s["submap_sum"], rtol=1e-4, atol=1e-4 * np.abs(s["submap_sum"]).max())   # (sums of signed coordinates)
     assert len(r0["ii"]) > 100
+    # the scan form on ONE rank (CUT3R_SCAN=1) is bit-identical to the two-rank result: same scalars, same host scan
+    scan1 = str(tmp_path / "scan1")
+    _run([sys.executable, "bench.py", "--window-batch", "4"] + common, {"CUT3R_DUMP_STATE": scan1, "CUT3R_SCAN": "1"})
+    c = np.load(scan1 + ".rank0.npz")
+    for key in ("pose", "w2c", "depth_sum", "submap_sum", "ii", "jj"):
+        np.testing.assert_array_equal(r0[key], c[key], err_msg="scan, one rank: " + key)
