@@ -95,6 +95,13 @@ SIGNATURES = {
     "cut3r_corr_index_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "cut3r_corr_index_backward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "cut3r_ba_workspace_floats": [c_int, c_int, c_int, c_int, c_int, c_int],
+    "cut3r_ba_assemble": [c_void_p] * 12 + [c_int] * 7 + [c_void_p] * 5,
+    "cut3r_ba_solve": [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "cut3r_ba_backsub": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "cut3r_ba_proj_trans": [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 4,
+    "cut3r_bi_inter": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "cut3r_altcorr_forward": [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p],
+    "cut3r_altcorr_backward": [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p, c_void_p],
     "cut3r_ba_step": [c_void_p] * 12 + [c_int] * 6 + [c_float, c_float] + [c_void_p] * 5,
 }
 RESTYPES = {"cut3r_ba_workspace_floats": c_ll}

@@ -45,9 +45,7 @@ def edge_structure(ii, jj, P, fixedp):
     return kx, kk, order.astype(np.int32), src_ptr, present
 
 
-def BA(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp=1, ep=0.1, lm=1e-4):
-    """One full-BA Gauss-Newton step.  target/weight [1,N,ht,wd,2]; eta [M,ht,wd] (or broadcastable); poses SE3 [1,P];
-    disps [1,P,ht,wd]; intrinsics [1,P,4] (or [1,4]); ii,jj LongTensor [N].  Returns (poses, disps, info)."""
+def _prepare(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp):
     dev = disps.device
     B, P, ht, wd = disps.shape
     if B != 1:
@@ -56,7 +54,6 @@ def BA(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp=1, ep=0.1, 
     HW = ht * wd
     kx, kk, order, src_ptr, present = edge_structure(ii, jj, P, fixedp)
     M = len(kx)
-    Pf = P - fixedp
     ii_d = ii.to(dev, torch.int32).contiguous()
     jj_d = jj.to(dev, torch.int32).contiguous()
     G = poses[0] if isinstance(poses, SE3) else SE3(poses[0])
@@ -65,26 +62,200 @@ def BA(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp=1, ep=0.1, 
     if intr.shape[0] == 1:
         intr = intr.expand(P, 4)
     intr = intr.contiguous()
-    eta_d = eta.to(dev).float().expand(M, ht, wd).reshape(M, HW).contiguous() if eta.numel() != M * HW else eta.reshape(M, HW).float().contiguous()
-    tgt = target.reshape(N, HW, 2).float().contiguous()
-    wgt = weight.reshape(N, HW, 2).float().contiguous()
-    dsp = disps.reshape(P, HW).float().contiguous()
-    lib = _lib.load()
-    ws = torch.empty(int(lib.cut3r_ba_workspace_floats(P, ht, wd, N, M, fixedp)), device=dev)
-    dx = torch.empty(Pf, 6, device=dev)
-    dz = torch.empty(M, HW, device=dev)
-    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    eta_d = None
+    if eta is not None:
+        eta_d = eta.to(dev).float().expand(M, ht, wd).reshape(M, HW).contiguous() if eta.numel() != M * HW else eta.reshape(M, HW).float().contiguous()
     t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
-    # keep the index tensors alive until the launches are enqueued (a temporary would be recycled by the allocator)
-    src_ptr_d, order_d, kx_d, present_d = t(src_ptr, torch.int32), t(order, torch.int32), t(kx, torch.int32), t(present, torch.uint8)
-    check(lib.cut3r_ba_step(_p(Gij), _p(dsp), _p(intr), _p(tgt), _p(wgt), _p(eta_d), _p(ii_d), _p(jj_d),
-                            _p(src_ptr_d), _p(order_d), _p(kx_d), _p(present_d),
-                            P, ht, wd, N, M, fixedp, float(ep), float(lm), _p(ws), _p(dx), _p(dz), _p(flag), _stream()), "cut3r_ba_step")
+    return dict(dev=dev, P=P, ht=ht, wd=wd, N=N, HW=HW, M=M, kx=kx, G=G, Gij=Gij, intr=intr, eta=eta_d, ii=ii_d, jj=jj_d,
+                tgt=target.reshape(N, HW, 2).float().contiguous(), wgt=weight.reshape(N, HW, 2).float().contiguous(),
+                dsp=disps.reshape(P, HW).float().contiguous(),
+                # index tensors kept alive until the launches are enqueued (a temporary would be recycled by the allocator)
+                src_ptr=t(src_ptr, torch.int32), order=t(order, torch.int32), kx_d=t(kx, torch.int32), present=t(present, torch.uint8))
+
+
+def _assemble(c, fixedp, motion_only=False):
+    """undamped reduced system of the edges in `c`: S [n,n], vS [n], diag(H) [n] (cut3r_ba_assemble) + the workspace holding E, C, w"""
+    lib = _lib.load()
+    dev, n = c["dev"], (c["P"] - fixedp) * 6
+    ws = torch.empty(int(lib.cut3r_ba_workspace_floats(c["P"], c["ht"], c["wd"], c["N"], c["M"], fixedp)), device=dev)
+    S, vS, hd = torch.empty(n, n, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
+    eta = c["eta"] if c["eta"] is not None else torch.zeros(c["M"], c["HW"], device=dev)
+    check(lib.cut3r_ba_assemble(_p(c["Gij"]), _p(c["dsp"]), _p(c["intr"]), _p(c["tgt"]), _p(c["wgt"]), _p(eta), _p(c["ii"]), _p(c["jj"]),
+                                _p(c["src_ptr"]), _p(c["order"]), _p(c["kx_d"]), _p(c["present"]), c["P"], c["ht"], c["wd"], c["N"], c["M"],
+                                fixedp, int(motion_only), _p(ws), _p(S), _p(vS), _p(hd), _stream()), "cut3r_ba_assemble")
+    return ws, S, vS, hd
+
+
+def _solve(S, vS, hd, ep, lm):
+    lib = _lib.load()
+    n = S.shape[0]
+    dx = torch.empty(n // 6, 6, device=S.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=S.device)
+    scratch = torch.empty(n * n, device=S.device)
+    check(lib.cut3r_ba_solve(_p(S), _p(vS), _p(hd), n, float(ep), float(lm), _p(scratch), _p(dx), _p(flag), _stream()), "cut3r_ba_solve")
+    return dx, flag
+
+
+def BA(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp=1, ep=0.1, lm=1e-4, group=None, edge_mask=None):
+    """One full-BA Gauss-Newton step.  target/weight [1,N,ht,wd,2]; eta [M,ht,wd] (or broadcastable); poses SE3 [1,P];
+    disps [1,P,ht,wd]; intrinsics [1,P,4] (or [1,4]); ii,jj LongTensor [N].  Returns (poses, disps, info).
+
+    Multi-GPU (north_star: per-edge BA sharded with an all-reduce of the normal-equation blocks): pass the torch.distributed
+    `group` and this rank's `edge_mask` (bool [N]) -- edges MUST be split by source frame `ii` so that a source frame's depth
+    blocks stay on one rank (`shard_edges_by_source`).  Each rank assembles the undamped reduced system of its edges, S / vS /
+    diag(H) are summed with ONE all-reduce of (6(P-fixedp))^2 + 12(P-fixedp) floats, every rank solves the same damped system and
+    updates the disparities of its own source frames; the disparity increments are then summed (disjoint supports)."""
+    dev = disps.device
+    B, P, ht, wd = disps.shape
+    if edge_mask is not None:
+        keep = torch.as_tensor(edge_mask, dtype=torch.bool)
+        if int(keep.sum()) == 0:
+            raise ValueError("this rank holds no edge: give every rank at least one source frame")
+        sel = keep.nonzero().reshape(-1)
+        target, weight = target[:, sel.to(target.device)], weight[:, sel.to(weight.device)]
+        ii_l, jj_l = ii[sel.to(ii.device)], jj[sel.to(jj.device)]
+        kx_all = np.unique(np.asarray(ii.cpu()))
+        if eta.numel() == len(kx_all) * ht * wd:                      # eta is indexed by source frame: keep this rank's rows
+            rows = np.searchsorted(kx_all, np.unique(np.asarray(ii_l.cpu())))
+            eta = eta.reshape(len(kx_all), ht, wd)[torch.as_tensor(rows, device=eta.device)]
+    else:
+        ii_l, jj_l = ii, jj
+    c = _prepare(target, weight, eta, poses, disps, intrinsics, ii_l, jj_l, fixedp)
+    ws, S, vS, hd = _assemble(c, fixedp)
+    if group is not None:
+        import torch.distributed as dist
+        packed = torch.cat([S.reshape(-1), vS, hd])
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(packed, group=group)
+        else:
+            host = packed.cpu()
+            dist.all_reduce(host, group=group)
+            packed = host.to(dev)
+        n = S.shape[0]
+        S, vS, hd = packed[:n * n].reshape(n, n).contiguous(), packed[n * n:n * n + n].contiguous(), packed[n * n + n:].contiguous()
+    dx, flag = _solve(S, vS, hd, ep, lm)
+    M, HW, kx = c["M"], c["HW"], c["kx"]
+    dz = torch.empty(M, HW, device=dev)
+    check(_lib.load().cut3r_ba_backsub(_p(ws), _p(dx), _p(c["present"]), P, ht, wd, c["N"], M, fixedp, _p(dz), _stream()), "cut3r_ba_backsub")
     # retraction (ba.py:100-105)
     full_dx = torch.zeros(P, 6, device=dev)
     full_dx[fixedp:] = dx
-    new_poses = SE3(G.data[None]).retr(full_dx[None])
+    new_poses = SE3(c["G"].data[None]).retr(full_dx[None])
+    inc = torch.zeros(P, ht, wd, device=dev)
+    inc[torch.as_tensor(kx, device=dev)] = dz.view(M, ht, wd)
+    if group is not None:
+        import torch.distributed as dist
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(inc, group=group)
+        else:
+            host = inc.cpu()
+            dist.all_reduce(host, group=group)
+            inc = host.to(dev)
     new_disps = disps.clone()
-    new_disps[0, torch.as_tensor(kx, device=dev)] += dz.view(M, ht, wd)
+    new_disps[0] += inc
     new_disps = torch.where(new_disps > 10, torch.zeros_like(new_disps), new_disps).clamp(min=0.001)
-    return new_poses, new_disps, {"dx": dx, "dz": dz, "failed": flag, "kx": kx}
+    return new_poses, new_disps, {"dx": dx, "dz": dz, "failed": flag, "kx": kx, "S": S, "vS": vS}
+
+
+def shard_edges_by_source(ii, world, rank):
+    """bool mask [N]: edges whose source frame belongs to `rank` (source frames dealt round-robin in sorted order) -- keeps
+    C_k, w_k, E_.k of a frame on one rank"""
+    ii_h = np.asarray(torch.as_tensor(ii).cpu(), np.int64)
+    kx = np.unique(ii_h)
+    owner = {int(k): n % world for n, k in enumerate(kx)}
+    return torch.as_tensor([owner[int(i)] == rank for i in ii_h])
+
+
+def MoBA(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp=1, rig=1, ep=0.1, lm=1e-4):
+    """Motion-only bundle adjustment (geom/ba.py:110-158): the pose block of the normal equations with block_solve's damping
+    (geom/chol.py:32-45); disparities stay fixed.  rig = 1 (the reference's only use)."""
+    if rig != 1:
+        raise NotImplementedError("rig > 1 (multi-camera rigs) is not used by the reference")
+    B, P, ht, wd = disps.shape
+    c = _prepare(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp)
+    _, S, vS, hd = _assemble(c, fixedp, motion_only=True)
+    dx, flag = _solve(S, vS, hd, ep, lm)
+    full_dx = torch.zeros(P, 6, device=disps.device)
+    full_dx[fixedp:] = dx
+    return SE3(c["G"].data[None]).retr(full_dx[None])
+
+
+def schur_solve_mono_prior(C, w, Hs, Es, vs, ep=0.1, lm=1e-4, dzcov=False):
+    """geom/chol.py:80-107 on the GPU (dense torch ops: the reduced system is M*D x M*D with D = hs*ws scale-grid nodes).
+    C, w [1,M,HW]; Hs [1,M,M,D,D]; Es [1,M,M,D,HW]; vs [1,M,D].  Returns (dso [1,M,D], dz [1,M,HW], dzcov [M,HW])."""
+    D = Hs.shape[-1]
+    B, M, HW = C.shape
+    Q = (1.0 / C).view(B, M * HW, 1)
+    w = w.reshape(B, M * HW, 1)
+    H = Hs.permute(0, 1, 3, 2, 4).reshape(B, M * D, M * D)
+    E = Es.permute(0, 1, 3, 2, 4).reshape(B, M * D, M * HW)
+    v = vs.reshape(B, M * D, 1)
+    I = torch.eye(M * D, device=H.device)
+    H = H + (ep + lm * H) * I
+    Et = E.transpose(1, 2)
+    S = H - torch.matmul(E, Q * Et)
+    v = v - torch.matmul(E, Q * w)
+    L, info = torch.linalg.cholesky_ex(S)
+    if int(info.max()) != 0:                                  # CholeskySolver swallows the failure and returns zeros (chol.py:13-18)
+        dso = torch.zeros_like(v)
+        L = torch.zeros_like(S)
+    else:
+        dso = torch.cholesky_solve(v, L)
+    dz = (Q * (w - Et @ dso)).reshape(B, M, HW)
+    cov = None
+    if dzcov:
+        Fm = torch.linalg.solve_triangular(L, E * Q[..., 0], upper=False) if int(info.max()) == 0 else torch.zeros_like(E)
+        cov = (torch.sum(torch.square(Fm), dim=1) + Q[..., 0]).reshape(M, HW)
+    return dso.reshape(B, M, D), dz, cov
+
+
+def get_prior_depth_aligned(depth_prior, scales):
+    """geom/ba.py:160-170"""
+    from . import droid_backends
+    M, ht, wd = depth_prior.shape
+    hs, ws = scales.shape[-2:]
+    meshx, meshy = torch.meshgrid(torch.linspace(0, hs - 1 - 1e-6, ht), torch.linspace(0, ws - 1 - 1e-6, wd), indexing="ij")
+    grid = torch.stack((meshy, meshx), -1).to(depth_prior.device)
+    grid = grid.unsqueeze(0).expand(M, -1, -1, -1).contiguous()
+    mscales_bi, Jbi = droid_backends.bi_inter(scales, grid)
+    return depth_prior * mscales_bi, Jbi
+
+
+def JDSA(target, weight, eta, poses, disps, intrinsics, disps_prior, dscales, ii, jj, alpha, ep=0.1, lm=1e-4):
+    """Joint depth and scale adjustment (geom/ba.py:172-241): disparities of the source frames + one bilinear scale grid per
+    frame that aligns its monocular prior; poses fixed.  disps [1,P,ht,wd], disps_prior [P,ht,wd], dscales [P,hs,ws]
+    (updated in place like the reference).  Returns (disps, dscales, dzcov)."""
+    from . import droid_backends
+    B, P, ht, wd = disps.shape
+    dev = disps.device
+    HW = ht * wd
+    G = poses[0] if isinstance(poses, SE3) else SE3(poses[0])
+    Cm, wv = droid_backends.proj_trans(G.data, disps[0], intrinsics.reshape(-1, 4)[0], target, weight, ii, jj)
+    kx = torch.unique(ii.to(dev))
+    M = kx.shape[0]
+    prior = disps_prior[kx]
+    m = (prior > 0).to(torch.float).view(-1, HW)
+    hs, ws = dscales.shape[-2:]
+    disps_bi, Jbi = get_prior_depth_aligned(prior, dscales[kx])
+    rd = (disps[0, kx] - disps_bi).view(-1, HW)
+    Jd = torch.ones_like(rd).view(1, -1, 1, HW)
+    Jso = -m.unsqueeze(-1) * prior.view(-1, HW).unsqueeze(-1) * Jbi.view(M, HW, -1)[None]         # [1,M,HW,D]
+    al = torch.ones(M, HW, 1, device=dev) * alpha
+    D = hs * ws
+    wJsoT = (al * Jso).transpose(2, 3)                                                           # [1,M,D,HW]
+    # the scatter of the reference puts frame k's blocks on the diagonal (kx, kx): block-diagonal Hs / Es
+    Hs = torch.zeros(1, M, M, D, D, device=dev)
+    Es = torch.zeros(1, M, M, D, HW, device=dev)
+    idx = torch.arange(M, device=dev)
+    Hs[0, idx, idx] = (wJsoT @ Jso)[0]
+    Es[0, idx, idx] = (wJsoT * Jd)[0]
+    vs = (-wJsoT @ rd[None].unsqueeze(-1))[..., 0]                                               # [1,M,D]
+    al = al.squeeze(-1)
+    C = Cm[None] + m * al * (Jd * Jd).squeeze(2)[0] + (1 - m) * eta.view(M, HW)
+    w = wv[None] - m * al * rd * Jd.squeeze(2)[0]
+    dso, dz, dzcov = schur_solve_mono_prior(C.reshape(1, M, HW), w.reshape(1, M, HW), Hs, Es, vs, ep, lm, dzcov=True)
+    new_disps = disps.clone()
+    new_disps[0, kx] += dz.view(M, ht, wd)
+    dscales[kx] += dso.view(-1, hs, ws)
+    new_disps = torch.where(new_disps > 10, torch.zeros_like(new_disps), new_disps).clamp(min=0.001)
+    return new_disps, dscales, dzcov

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(BA_BLOCK) void ba_edge_kernel(const float* __restri
 #pragma unroll
             for (int a = 0; a < 6; a++) Eb[(size_t)a * HW] += Ei_sum[a];
         }
-        Cm[(size_t)m * HW + k] = Csum + eta[(size_t)m * HW + k] + 1e-7f;
+        Cm[(size_t)m * HW + k] = eta ? Csum + eta[(size_t)m * HW + k] + 1e-7f : Csum;      // eta == NULL: raw sums (proj_trans)
         wm[(size_t)m * HW + k] = wsum;
     }
     (void)Pf;
@@ -361,6 +361,119 @@ __global__ __launch_bounds__(256) void ba_dz_kernel(const float* __restrict__ E,
     dz[(size_t)m * HW + k] = s / Cm[(size_t)m * HW + k];
 }
 
+// diagonal of the reduced pose Hessian (for the damping, which acts on the SUM over all ranks' edges)
+__global__ void ba_hdiag_kernel(const float* __restrict__ H, int Pf, float* __restrict__ hd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Pf * 6) return;
+    const int p = i / 6, a = i % 6;
+    hd[i] = H[(((size_t)p * Pf + p) * 6 + a) * 6 + a];
+}
+// Sd = S + diag(ep + lm * hdiag)   (chol.py:56-57 on the reduced system: the Schur correction does not touch the damping)
+__global__ void ba_damp_kernel(const float* __restrict__ S, const float* __restrict__ hd, int n, float ep, float lm, float* __restrict__ Sd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * n) return;
+    const int r = i / n, c = i % n;
+    Sd[i] = S[i] + ((r == c) ? (ep + lm * hd[r]) : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------ bi_inter (geom/ba.py:160-170)
+// scales [M,hs,ws], grid [M,ht,wd,2] (x, y in scale-grid units) -> vals [M,ht,wd] (bilinear), J [M,ht,wd,hs*ws] (d val / d node)
+__global__ __launch_bounds__(256) void bi_inter_kernel(const float* __restrict__ scales, const float* __restrict__ grid, int M, int hs, int ws,
+                                                       int HW, float* __restrict__ vals, float* __restrict__ J) {
+    const size_t p = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (p >= (size_t)M * HW) return;
+    const int m = (int)(p / HW);
+    const float gx = grid[2 * p], gy = grid[2 * p + 1];
+    const float fx = floorf(gx), fy = floorf(gy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float dx = gx - fx, dy = gy - fy;
+    const float* sc = scales + (size_t)m * hs * ws;
+    float* Jp = J + p * (size_t)(hs * ws);
+    for (int i = 0; i < hs * ws; i++) Jp[i] = 0.f;
+    float v = 0.f;
+#pragma unroll
+    for (int oy = 0; oy < 2; oy++)
+#pragma unroll
+        for (int ox = 0; ox < 2; ox++) {
+            const int xx = x0 + ox, yy = y0 + oy;
+            const float w = (ox ? dx : 1.f - dx) * (oy ? dy : 1.f - dy);
+            if (xx >= 0 && xx < ws && yy >= 0 && yy < hs) {
+                v += w * sc[yy * ws + xx];
+                Jp[yy * ws + xx] += w;
+            }
+        }
+    vals[p] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ alt-corr (modules/corr.py:74-139)
+// fmap1 [BN,H,W,C], fmap2 [BN,H2,W2,C], coords [BN,S,H,W,2] (x,y in fmap2 pixels) -> corr [BN,S,(2r+1)^2,H,W]:
+// corr[n,s,(i,j),y,x] = sum_c fmap1[n,y,x,c] * bilinear(fmap2[n])(coords + (i - r, j - r))[c]  (x offset = i, y offset = j,
+// zero outside) -- the on-the-fly form of CorrBlock: identical values to the lookup in the all-pairs volume.
+__global__ __launch_bounds__(64) void altcorr_fwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                         const float* __restrict__ coords, int BN, int S, int H, int W, int H2, int W2,
+                                                         int C, int r, float* __restrict__ corr) {
+    const int rd = 2 * r + 1;
+    const size_t pix = blockIdx.x;                     // (n, s, y, x)
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), s_ = (int)((pix / ((size_t)W * H)) % S), n = (int)(pix / ((size_t)W * H * S));
+    const int lane = threadIdx.x;
+    const float cx = coords[pix * 2], cy = coords[pix * 2 + 1];
+    const float fx = floorf(cx), fy = floorf(cy);
+    const float dx = cx - fx, dy = cy - fy;
+    const float* a = f1 + (((size_t)n * H + y) * W + x) * C;
+    for (int i = 0; i < rd; i++)
+        for (int j = 0; j < rd; j++) {
+            const int xa = (int)fx - r + i, ya = (int)fy - r + j;
+            float acc = 0.f;
+#pragma unroll
+            for (int oy = 0; oy < 2; oy++)
+#pragma unroll
+                for (int ox = 0; ox < 2; ox++) {
+                    const int xx = xa + ox, yy = ya + oy;
+                    if (xx < 0 || xx >= W2 || yy < 0 || yy >= H2) continue;
+                    const float w = (ox ? dx : 1.f - dx) * (oy ? dy : 1.f - dy);
+                    const float* b = f2 + (((size_t)n * H2 + yy) * W2 + xx) * C;
+                    float d = 0.f;
+                    for (int c = lane; c < C; c += 64) d = fmaf(a[c], b[c], d);
+                    acc += w * d;
+                }
+            acc = wave_sum(acc);
+            if (lane == 0) corr[((((size_t)n * S + s_) * rd * rd + (size_t)i * rd + j) * H + y) * W + x] = acc;
+        }
+}
+// gradients w.r.t. fmap1 and fmap2 (atomic adds into zeroed buffers; coords get no gradient, as in DROID-SLAM)
+__global__ __launch_bounds__(64) void altcorr_bwd_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                         const float* __restrict__ coords, const float* __restrict__ gcorr, int BN, int S,
+                                                         int H, int W, int H2, int W2, int C, int r, float* __restrict__ g1,
+                                                         float* __restrict__ g2) {
+    const int rd = 2 * r + 1;
+    const size_t pix = blockIdx.x;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), s_ = (int)((pix / ((size_t)W * H)) % S), n = (int)(pix / ((size_t)W * H * S));
+    const int lane = threadIdx.x;
+    const float cx = coords[pix * 2], cy = coords[pix * 2 + 1];
+    const float fx = floorf(cx), fy = floorf(cy);
+    const float dx = cx - fx, dy = cy - fy;
+    const size_t o1 = (((size_t)n * H + y) * W + x) * C;
+    for (int i = 0; i < rd; i++)
+        for (int j = 0; j < rd; j++) {
+            const float g = gcorr[((((size_t)n * S + s_) * rd * rd + (size_t)i * rd + j) * H + y) * W + x];
+            if (g == 0.f) continue;
+            const int xa = (int)fx - r + i, ya = (int)fy - r + j;
+#pragma unroll
+            for (int oy = 0; oy < 2; oy++)
+#pragma unroll
+                for (int ox = 0; ox < 2; ox++) {
+                    const int xx = xa + ox, yy = ya + oy;
+                    if (xx < 0 || xx >= W2 || yy < 0 || yy >= H2) continue;
+                    const float w = g * (ox ? dx : 1.f - dx) * (oy ? dy : 1.f - dy);
+                    const size_t o2 = (((size_t)n * H2 + yy) * W2 + xx) * C;
+                    for (int c = lane; c < C; c += 64) {
+                        atomicAdd(&g1[o1 + c], w * f2[o2 + c]);
+                        atomicAdd(&g2[o2 + c], w * f1[o1 + c]);
+                    }
+                }
+        }
+}
+
 inline int grid_for(size_t total, int block = 256) {
     size_t gsz = (total + block - 1) / block;
     if (gsz > 8192) gsz = 8192;
@@ -394,37 +507,132 @@ extern "C" long long cut3r_ba_workspace_floats(int P, int ht, int wd, int N, int
     return (long long)N * nblk * BA_HROW + Pf * M * 6 * HW + 3 * M * HW + Pf * Pf * 36 + Pf * 6 + n * n + n + n * n + 64;
 }
 
-extern "C" int cut3r_ba_step(const float* Gij, const float* disps, const float* intr, const float* target, const float* weight,
-                             const float* eta, const int* ii, const int* jj, const int* src_ptr, const int* src_edges, const int* kx,
-                             const unsigned char* present, int P, int ht, int wd, int N, int M, int fixedp, float ep, float lm,
-                             float* workspace, float* dx, float* dz, int* flag, void* stream) {
-    if (!Gij || !disps || !intr || !target || !weight || !eta || !ii || !jj || !src_ptr || !src_edges || !kx || !present || !workspace ||
-        !dx || !dz || !flag)
+// workspace layout shared by the staged entry points
+struct BaWs { float *Hpart, *E, *Cm, *wm, *H, *v, *S, *vS, *L; int nblk, n; };
+static BaWs ba_ws(float* workspace, int P, int ht, int wd, int N, int M, int fixedp) {
+    const long long HW = (long long)ht * wd;
+    const int Pf = P - fixedp;
+    BaWs w;
+    w.nblk = (int)((HW + BA_BLOCK - 1) / BA_BLOCK);
+    w.n = Pf * 6;
+    w.Hpart = workspace;
+    w.E = w.Hpart + (size_t)N * w.nblk * BA_HROW;
+    w.Cm = w.E + (size_t)Pf * M * 6 * HW;
+    w.wm = w.Cm + (size_t)M * HW;
+    w.H = w.wm + (size_t)M * HW + (size_t)M * HW;     // (third M*HW slot reserved)
+    w.v = w.H + (size_t)Pf * Pf * 36;
+    w.S = w.v + (size_t)Pf * 6;
+    w.vS = w.S + (size_t)w.n * w.n;
+    w.L = w.vS + w.n;
+    return w;
+}
+
+extern "C" int cut3r_ba_assemble(const float* Gij, const float* disps, const float* intr, const float* target, const float* weight,
+                                 const float* eta, const int* ii, const int* jj, const int* src_ptr, const int* src_edges, const int* kx,
+                                 const unsigned char* present, int P, int ht, int wd, int N, int M, int fixedp, int motion_only,
+                                 float* workspace, float* S_out, float* vS_out, float* hdiag_out, void* stream) {
+    if (!Gij || !disps || !intr || !target || !weight || !ii || !jj || !src_ptr || !src_edges || !kx || !present || !workspace || !S_out ||
+        !vS_out || !hdiag_out)
         return CUT3R_ERR_ARG;
     const int Pf = P - fixedp;
     if (P <= 0 || Pf <= 0 || ht <= 0 || wd <= 0 || N <= 0 || M <= 0 || fixedp < 0 || Pf * 6 > CHOL_MAXN) return CUT3R_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long long HW = (long long)ht * wd;
-    const int nblk = (int)((HW + BA_BLOCK - 1) / BA_BLOCK), n = Pf * 6;
-    float* Hpart = workspace;
-    float* E = Hpart + (size_t)N * nblk * BA_HROW;
-    float* Cm = E + (size_t)Pf * M * 6 * HW;
-    float* wm = Cm + (size_t)M * HW;
-    float* H = wm + (size_t)M * HW + (size_t)M * HW;     // (third M*HW slot reserved)
-    float* v = H + (size_t)Pf * Pf * 36;
-    float* S = v + (size_t)Pf * 6;
-    float* vS = S + (size_t)n * n;
-    float* L = vS + n;
-    if (hipMemsetAsync(E, 0, sizeof(float) * (size_t)Pf * M * 6 * HW, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    const BaWs w = ba_ws(workspace, P, ht, wd, N, M, fixedp);
+    if (hipMemsetAsync(w.E, 0, sizeof(float) * (size_t)Pf * M * 6 * HW, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
     BaGeom g{P, ht, wd, N, M, fixedp};
-    hipLaunchKernelGGL(ba_edge_kernel, dim3(nblk, M), dim3(BA_BLOCK), 0, s, Gij, disps, intr, target, weight, ii, jj, src_ptr, src_edges,
-                       kx, g, Hpart, E, Cm, wm, eta);
-    hipLaunchKernelGGL(ba_reduce_H_kernel, dim3(Pf, Pf + 1), dim3(64), 0, s, Hpart, nblk, ii, jj, N, Pf, fixedp, H, v);
-    hipLaunchKernelGGL(ba_schur_kernel, dim3(Pf, Pf), dim3(256), 0, s, H, v, E, Cm, wm, present, Pf, M, (int)HW, ep, lm, S, vS);
+    hipLaunchKernelGGL(ba_edge_kernel, dim3(w.nblk, M), dim3(BA_BLOCK), 0, s, Gij, disps, intr, target, weight, ii, jj, src_ptr, src_edges,
+                       kx, g, w.Hpart, w.E, w.Cm, w.wm, eta);
+    hipLaunchKernelGGL(ba_reduce_H_kernel, dim3(Pf, Pf + 1), dim3(64), 0, s, w.Hpart, w.nblk, ii, jj, N, Pf, fixedp, w.H, w.v);
+    // undamped reduced system of THESE edges (motion only: no Schur correction, i.e. M = 0 for the reduction)
+    hipLaunchKernelGGL(ba_schur_kernel, dim3(Pf, Pf), dim3(256), 0, s, w.H, w.v, w.E, w.Cm, w.wm, present, Pf, motion_only ? 0 : M, (int)HW,
+                       0.f, 0.f, S_out, vS_out);
+    hipLaunchKernelGGL(ba_hdiag_kernel, dim3((w.n + 63) / 64), dim3(64), 0, s, w.H, Pf, hdiag_out);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_ba_solve(const float* S, const float* vS, const float* hdiag, int n, float ep, float lm, float* scratch, float* dx,
+                              int* flag, void* stream) {
+    if (!S || !vS || !hdiag || !scratch || !dx || !flag || n <= 0 || n > CHOL_MAXN) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ba_damp_kernel, dim3((n * n + 255) / 256), dim3(256), 0, s, S, hdiag, n, ep, lm, scratch);
     const size_t chol_lds = sizeof(float) * ((size_t)n * n + n);
     if (hipFuncSetAttribute((const void*)ba_chol_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds) != hipSuccess)
         return CUT3R_ERR_LAUNCH;
-    hipLaunchKernelGGL(ba_chol_solve_kernel, dim3(1), dim3(256), chol_lds, s, S, vS, n, dx, L, flag);
-    hipLaunchKernelGGL(ba_dz_kernel, dim3(nblk, M), dim3(256), 0, s, E, Cm, wm, dx, present, Pf, M, (int)HW, dz);
+    hipLaunchKernelGGL(ba_chol_solve_kernel, dim3(1), dim3(256), chol_lds, s, scratch, vS, n, dx, (float*)nullptr, flag);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_ba_backsub(float* workspace, const float* dx, const unsigned char* present, int P, int ht, int wd, int N, int M,
+                                int fixedp, float* dz, void* stream) {
+    if (!workspace || !dx || !present || !dz || P - fixedp <= 0 || M <= 0) return CUT3R_ERR_ARG;
+    const BaWs w = ba_ws(workspace, P, ht, wd, N, M, fixedp);
+    hipLaunchKernelGGL(ba_dz_kernel, dim3(w.nblk, M), dim3(256), 0, (hipStream_t)stream, w.E, w.Cm, w.wm, dx, present, P - fixedp, M, ht * wd, dz);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_ba_step(const float* Gij, const float* disps, const float* intr, const float* target, const float* weight,
+                             const float* eta, const int* ii, const int* jj, const int* src_ptr, const int* src_edges, const int* kx,
+                             const unsigned char* present, int P, int ht, int wd, int N, int M, int fixedp, float ep, float lm,
+                             float* workspace, float* dx, float* dz, int* flag, void* stream) {
+    if (!workspace || !eta) return CUT3R_ERR_ARG;
+    const BaWs w = ba_ws(workspace, P, ht, wd, N, M, fixedp);
+    int rc = cut3r_ba_assemble(Gij, disps, intr, target, weight, eta, ii, jj, src_ptr, src_edges, kx, present, P, ht, wd, N, M, fixedp, 0,
+                               workspace, w.S, w.vS, w.L, stream);                  // (hdiag in the first n floats of the L region)
+    if (rc != CUT3R_OK) return rc;
+    rc = cut3r_ba_solve(w.S, w.vS, w.L, w.n, ep, lm, w.L + w.n, dx, flag, stream);
+    if (rc != CUT3R_OK) return rc;
+    return cut3r_ba_backsub(workspace, dx, present, P, ht, wd, N, M, fixedp, dz, stream);
+}
+
+/* per-source depth normal equations with the poses held fixed (droid_backends.proj_trans, geom/ba.py:200): C = sum_e w Jz^2,
+ * w = sum_e w r Jz over the edges of each source frame (no eta) */
+extern "C" int cut3r_ba_proj_trans(const float* Gij, const float* disps, const float* intr, const float* target, const float* weight,
+                                   const int* ii, const int* jj, const int* src_ptr, const int* src_edges, const int* kx, int P, int ht,
+                                   int wd, int N, int M, float* workspace, float* C_out, float* w_out, void* stream) {
+    if (!Gij || !disps || !intr || !target || !weight || !ii || !jj || !src_ptr || !src_edges || !kx || !workspace || !C_out || !w_out)
+        return CUT3R_ERR_ARG;
+    if (P <= 0 || ht <= 0 || wd <= 0 || N <= 0 || M <= 0) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long long HW = (long long)ht * wd;
+    const int fixedp = P;                                   // every pose fixed: no E blocks are written (ip, jp < 0)
+    const int nblk = (int)((HW + BA_BLOCK - 1) / BA_BLOCK);
+    BaGeom g{P, ht, wd, N, M, fixedp};
+    hipLaunchKernelGGL(ba_edge_kernel, dim3(nblk, M), dim3(BA_BLOCK), 0, s, Gij, disps, intr, target, weight, ii, jj, src_ptr, src_edges, kx,
+                       g, workspace /* Hpart: N*nblk*120 floats */, (float*)nullptr, C_out, w_out, (const float*)nullptr);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_bi_inter(const float* scales, const float* grid, int M, int hs, int ws, int ht, int wd, float* vals, float* J,
+                              void* stream) {
+    if (!scales || !grid || !vals || !J || M <= 0 || hs <= 0 || ws <= 0 || ht <= 0 || wd <= 0) return CUT3R_ERR_ARG;
+    const size_t tot = (size_t)M * ht * wd;
+    hipLaunchKernelGGL(bi_inter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scales, grid, M, hs, ws, ht * wd,
+                       vals, J);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_altcorr_forward(const float* fmap1, const float* fmap2, const float* coords, int BN, int S, int H, int W, int H2, int W2,
+                                     int C, int radius, float* corr, void* stream) {
+    if (!fmap1 || !fmap2 || !coords || !corr || BN <= 0 || S <= 0 || H <= 0 || W <= 0 || H2 <= 0 || W2 <= 0 || C <= 0 || radius < 0)
+        return CUT3R_ERR_ARG;
+    const size_t tot = (size_t)BN * S * H * W;
+    if (tot > 0x7fffffffULL) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(altcorr_fwd_kernel, dim3((unsigned)tot), dim3(64), 0, (hipStream_t)stream, fmap1, fmap2, coords, BN, S, H, W, H2, W2, C,
+                       radius, corr);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_altcorr_backward(const float* fmap1, const float* fmap2, const float* coords, const float* grad_corr, int BN, int S,
+                                      int H, int W, int H2, int W2, int C, int radius, float* grad1, float* grad2, void* stream) {
+    if (!fmap1 || !fmap2 || !coords || !grad_corr || !grad1 || !grad2 || BN <= 0 || S <= 0 || H <= 0 || W <= 0 || C <= 0 || radius < 0)
+        return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t tot = (size_t)BN * S * H * W;
+    if (tot > 0x7fffffffULL) return CUT3R_ERR_ARG;
+    if (hipMemsetAsync(grad1, 0, sizeof(float) * (size_t)BN * H * W * C, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    if (hipMemsetAsync(grad2, 0, sizeof(float) * (size_t)BN * H2 * W2 * C, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    hipLaunchKernelGGL(altcorr_bwd_kernel, dim3((unsigned)tot), dim3(64), 0, s, fmap1, fmap2, coords, grad_corr, BN, S, H, W, H2, W2, C, radius,
+                       grad1, grad2);
     return cut3r_check_launch();
 }

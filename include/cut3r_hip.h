@@ -256,6 +256,36 @@ int cut3r_ba_step(const float* Gij, const float* disps, const float* intr, const
                   const int* ii, const int* jj, const int* src_ptr, const int* src_edges, const int* kx, const unsigned char* present,
                   int P, int ht, int wd, int N, int M, int fixedp, float ep, float lm, float* workspace, float* dx, float* dz, int* flag,
                   void* stream);
+/* The same step in three stages, so that EDGES CAN BE SHARDED by source frame over several GPUs (north_star: all-reduce of the
+ * normal-equation blocks): every rank assembles the UNDAMPED reduced system S = H - E C^-1 E^T, vS = v - E C^-1 w of ITS edges
+ * (each source frame m -- with its depth blocks C_m, w_m, E_.m -- lives on exactly one rank) plus diag(H); S, vS and the
+ * diagonal (6(P-fixedp))^2 + 2*6(P-fixedp) floats are summed over ranks; every rank then damps (S + (ep + lm*diag H) I,
+ * geom/chol.py:56-57), solves, and back-substitutes dz for its own source frames.  motion_only != 0 drops the Schur
+ * correction: the reduced system of MoBA (geom/ba.py:110-158).  S_out [n,n], vS_out [n], hdiag_out [n], n = 6(P-fixedp);
+ * scratch: n*n floats. */
+int cut3r_ba_assemble(const float* Gij, const float* disps, const float* intr, const float* target, const float* weight, const float* eta,
+                      const int* ii, const int* jj, const int* src_ptr, const int* src_edges, const int* kx, const unsigned char* present,
+                      int P, int ht, int wd, int N, int M, int fixedp, int motion_only, float* workspace, float* S_out, float* vS_out,
+                      float* hdiag_out, void* stream);
+int cut3r_ba_solve(const float* S, const float* vS, const float* hdiag, int n, float ep, float lm, float* scratch, float* dx, int* flag,
+                   void* stream);
+int cut3r_ba_backsub(float* workspace, const float* dx, const unsigned char* present, int P, int ht, int wd, int N, int M, int fixedp,
+                     float* dz, void* stream);
+/* droid_backends.proj_trans (call site hislam2/geom/ba.py:200): per-source depth normal equations with the poses held fixed,
+ * C [M,ht*wd] = sum_e w Jz^2, w [M,ht*wd] = sum_e w r Jz.  workspace: N * ceil(ht*wd/256) * 120 floats. */
+int cut3r_ba_proj_trans(const float* Gij, const float* disps, const float* intr, const float* target, const float* weight, const int* ii,
+                        const int* jj, const int* src_ptr, const int* src_edges, const int* kx, int P, int ht, int wd, int N, int M,
+                        float* workspace, float* C_out, float* w_out, void* stream);
+/* droid_backends.bi_inter (call site hislam2/geom/ba.py:167): bilinear interpolation of per-frame scale grids scales [M,hs,ws] at
+ * grid [M,ht,wd,2] (x, y) -> vals [M,ht,wd] and the dense Jacobian J [M,ht,wd,hs*ws] w.r.t. the grid nodes. */
+int cut3r_bi_inter(const float* scales, const float* grid, int M, int hs, int ws, int ht, int wd, float* vals, float* J, void* stream);
+/* droid_backends.altcorr_forward / altcorr_backward (call sites hislam2/modules/corr.py:79,87): on-the-fly correlation of fmap1
+ * [BN,H,W,C] with fmap2 [BN,H2,W2,C] sampled bilinearly in a (2r+1)^2 window around coords [BN,S,H,W,2] ->
+ * corr [BN,S,(2r+1)^2,H,W]; backward gives the gradients w.r.t. both feature maps (coords get none). */
+int cut3r_altcorr_forward(const float* fmap1, const float* fmap2, const float* coords, int BN, int S, int H, int W, int H2, int W2, int C,
+                          int radius, float* corr, void* stream);
+int cut3r_altcorr_backward(const float* fmap1, const float* fmap2, const float* coords, const float* grad_corr, int BN, int S, int H, int W,
+                           int H2, int W2, int C, int radius, float* grad1, float* grad2, void* stream);
 
 /* ---- stream preprocessing -------------------------------------------------------------------------------------------
  * replaces cv2.resize(image, (w1, h1)) of demo_s.py:72,83 (default INTER_LINEAR, 8-bit): OpenCV's fixed-point bilinear

@@ -106,3 +106,135 @@ def corr_lookup(volume, coords, r):
             s = F.grid_sample(v, grid.to(v.dtype), mode="bilinear", padding_mode="zeros", align_corners=True)
             out[:, i, j] = s.reshape(BN, h1, w1)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ round 2: MoBA / JDSA / alt-corr
+def _edge_jacobians(G, disps, intr, ii, jj, e, ht, wd, eps=1e-6):
+    """numerical Jacobians of the projected coordinates of edge e w.r.t. left perturbations of G_i, G_j and the disparity"""
+    HW = ht * wd
+    i, j = int(ii[e]), int(jj[e])
+
+    def coords(Gi, Gj, d):
+        return project(Gj @ torch.linalg.inv(Gi), d, intr[i], intr[j], ht, wd)
+
+    c0, valid = coords(G[i], G[j], disps[i])
+    Ji = torch.zeros(HW, 2, 6, dtype=DT)
+    Jj = torch.zeros(HW, 2, 6, dtype=DT)
+    for a in range(6):
+        da = np.zeros(6); da[a] = eps
+        Ep, Em = torch.from_numpy(LO.exp_matrix(1, da)), torch.from_numpy(LO.exp_matrix(1, -da))
+        Ji[:, :, a] = (coords(Ep @ G[i], G[j], disps[i])[0] - coords(Em @ G[i], G[j], disps[i])[0]) / (2 * eps)
+        Jj[:, :, a] = (coords(G[i], Ep @ G[j], disps[i])[0] - coords(G[i], Em @ G[j], disps[i])[0]) / (2 * eps)
+    Jz = (coords(G[i], G[j], disps[i] + eps)[0] - coords(G[i], G[j], disps[i] - eps)[0]) / (2 * eps)
+    return c0, valid, Ji, Jj, Jz
+
+
+def moba_dense(target, weight, poses7, disps, intr, ii, jj, fixedp, ep=0.1, lm=1e-4):
+    """Motion-only step (geom/ba.py:110-158 + chol.py:32-45): pose block only, damping H + (ep + lm H) I, dense fp64 solve."""
+    P, ht, wd = disps.shape
+    HW = ht * wd
+    G = se3_matrix(poses7)
+    Pf = P - fixedp
+    H = torch.zeros(Pf * 6, Pf * 6, dtype=DT)
+    g = torch.zeros(Pf * 6, dtype=DT)
+    for e in range(len(ii)):
+        c0, valid, Ji, Jj, _ = _edge_jacobians(G, disps, intr, ii, jj, e, ht, wd)
+        r = target[e].reshape(HW, 2).to(DT) - c0
+        w = 0.001 * valid[:, None] * weight[e].reshape(HW, 2).to(DT)
+        blocks = [(int(ii[e]) - fixedp, Ji), (int(jj[e]) - fixedp, Jj)]
+        for (p1, J1) in blocks:
+            if p1 < 0:
+                continue
+            g[p1 * 6:p1 * 6 + 6] += torch.einsum("kc,kca,kc->a", w, J1, r)
+            for (p2, J2) in blocks:
+                if p2 >= 0:
+                    H[p1 * 6:p1 * 6 + 6, p2 * 6:p2 * 6 + 6] += torch.einsum("kc,kca,kcb->ab", w, J1, J2)
+    idx = torch.arange(Pf * 6)
+    H[idx, idx] = H[idx, idx] + (ep + lm * H[idx, idx])
+    return torch.linalg.solve(H, g).reshape(Pf, 6)
+
+
+def proj_trans_dense(target, weight, poses7, disps, intr, ii, jj):
+    """C [M,HW] = sum_e w Jz^2, w [M,HW] = sum_e w r Jz per source frame (the quantities droid_backends.proj_trans returns)"""
+    P, ht, wd = disps.shape
+    HW = ht * wd
+    G = se3_matrix(poses7)
+    kx = np.unique(ii)
+    kk = {int(k): m for m, k in enumerate(kx)}
+    C = torch.zeros(len(kx), HW, dtype=DT)
+    wv = torch.zeros(len(kx), HW, dtype=DT)
+    for e in range(len(ii)):
+        c0, valid, _, _, Jz = _edge_jacobians(G, disps, intr, ii, jj, e, ht, wd)
+        r = target[e].reshape(HW, 2).to(DT) - c0
+        w = 0.001 * valid[:, None] * weight[e].reshape(HW, 2).to(DT)
+        m = kk[int(ii[e])]
+        C[m] += (w * Jz * Jz).sum(-1)
+        wv[m] += (w * r * Jz).sum(-1)
+    return C, wv, kx
+
+
+def bi_inter_ref(scales, grid):
+    """bilinear interpolation of scales [M,hs,ws] at grid [M,ht,wd,2] (x,y) and its dense Jacobian, by autograd (fp64)"""
+    import torch.nn.functional as F
+    M, hs, ws = scales.shape
+    s = scales.clone().to(DT).requires_grad_(True)
+    gx = 2 * grid[..., 0].to(DT) / max(ws - 1, 1) - 1
+    gy = 2 * grid[..., 1].to(DT) / max(hs - 1, 1) - 1
+    v = F.grid_sample(s[:, None], torch.stack([gx, gy], -1), mode="bilinear", padding_mode="zeros", align_corners=True)[:, 0]
+    J = torch.zeros(M, v.shape[1], v.shape[2], hs * ws, dtype=DT)
+    for m in range(M):
+        for y in range(v.shape[1]):
+            for x in range(v.shape[2]):
+                (g,) = torch.autograd.grad(v[m, y, x], s, retain_graph=True)
+                J[m, y, x] = g[m].reshape(-1)
+    return v.detach(), J
+
+
+def jdsa_dense(C, w, eta, disps_src, prior, scales, alpha, ep=0.1, lm=1e-4):
+    """Un-reduced solve of the JDSA normal equations (geom/ba.py:172-241 + chol.py:80-107): unknowns = the source frames'
+    disparities [M,HW] and their scale-grid nodes [M,D].  C, w from proj_trans; disps_src, prior [M,ht,wd]; scales [M,hs,ws].
+    Returns (dz [M,HW], dso [M,D])."""
+    M, ht, wd = disps_src.shape
+    HW = ht * wd
+    hs, ws = scales.shape[-2:]
+    D = hs * ws
+    yy, xx = torch.meshgrid(torch.linspace(0, hs - 1 - 1e-6, ht), torch.linspace(0, ws - 1 - 1e-6, wd), indexing="ij")
+    grid = torch.stack((xx, yy), -1)[None].expand(M, -1, -1, -1)
+    sbi, Jbi = bi_inter_ref(scales, grid)
+    m = (prior > 0).to(DT).reshape(M, HW)
+    rd = (disps_src.to(DT) - prior.to(DT) * sbi).reshape(M, HW)
+    Jso = -m[..., None] * prior.to(DT).reshape(M, HW, 1) * Jbi.reshape(M, HW, D)           # d rd / d scale nodes
+    n = M * HW + M * D
+    A = torch.zeros(n, n, dtype=DT)
+    b = torch.zeros(n, dtype=DT)
+    for k in range(M):
+        zi = torch.arange(k * HW, (k + 1) * HW)
+        si = torch.arange(M * HW + k * D, M * HW + (k + 1) * D)
+        Ck = C[k].to(DT) + m[k] * alpha + (1 - m[k]) * eta[k].reshape(-1).to(DT)
+        wk = w[k].to(DT) - m[k] * alpha * rd[k]
+        A[zi, zi] += Ck
+        b[zi] += wk
+        Hs = alpha * Jso[k].T @ Jso[k]
+        Hs = Hs + (ep + lm * Hs) * torch.eye(D, dtype=DT)
+        A[si[:, None], si[None]] += Hs
+        Es = alpha * Jso[k].T                                                                  # [D,HW] (Jd = 1)
+        A[si[:, None], zi[None]] += Es
+        A[zi[:, None], si[None]] += Es.T
+        b[si] += -alpha * Jso[k].T @ rd[k]
+    sol = torch.linalg.solve(A, b)
+    return sol[:M * HW].reshape(M, HW), sol[M * HW:].reshape(M, D)
+
+
+def altcorr_ref(fmap1, fmap2, coords, r):
+    """on-the-fly correlation == the lookup in the all-pairs volume (modules/corr.py:62-71 `CorrBlock.corr` without the /4, which
+    AltCorrBlock applies to the feature maps): fmap1 [BN,H,W,C], fmap2 [BN,H2,W2,C], coords [BN,S,H,W,2] -> [BN,S,(2r+1)^2,H,W]"""
+    BN, H, W, Cc = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    vol = torch.einsum("nyxc,nuvc->nyxuv", fmap1, fmap2)
+    S = coords.shape[1]
+    rd = 2 * r + 1
+    outs = []
+    for s in range(S):
+        c = coords[:, s].permute(0, 3, 1, 2)                       # [BN,2,H,W] (x,y)
+        outs.append(corr_lookup(vol, c, r).reshape(BN, rd * rd, H, W))
+    return torch.stack(outs, 1)

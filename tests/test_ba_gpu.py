@@ -86,3 +86,117 @@ def test_ba_step_matches_unreduced_dense_solve(P, ht, wd, fixedp):
     ref_d[torch.from_numpy(kx)] += dz_ref.reshape(-1, ht, wd)
     ref_d = torch.where(ref_d > 10, torch.zeros_like(ref_d), ref_d).clamp(min=0.001)
     np.testing.assert_allclose(nd.numpy(), ref_d.numpy(), atol=5e-3 * sz + 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ round 2: the rest of row A13
+def _f(a):
+    return torch.from_numpy(np.asarray(a)).float().to(DEV)
+
+
+def test_moba_matches_dense_pose_only_solve():
+    from cut3r_slam_amd.ba import MoBA
+    P, ht, wd, fixedp = 5, 8, 10, 1
+    poses, disps, intr, ii, jj, tgt, wgt, eta = _scene(P, ht, wd, 3)
+    dx_ref = BO.moba_dense(torch.from_numpy(tgt), torch.from_numpy(wgt), poses, torch.from_numpy(disps), intr, ii, jj, fixedp)
+    new_poses = MoBA(_f(tgt)[None], _f(wgt)[None], _f(eta), SE3(_f(poses)[None]), _f(disps)[None], _f(intr)[None], torch.from_numpy(ii),
+                     torch.from_numpy(jj), fixedp=fixedp)
+    torch.cuda.synchronize()
+    Mnew = new_poses.matrix()[0].cpu().double()
+    G = BO.se3_matrix(poses)
+    for p in range(P):
+        ref = G[p] if p < fixedp else torch.from_numpy(LO.exp_matrix(1, dx_ref[p - fixedp].numpy())) @ G[p]
+        np.testing.assert_allclose(Mnew[p].numpy(), ref.numpy(), atol=5e-4)
+    assert dx_ref.abs().max() > 1e-3                                # the step is not trivially zero
+
+
+def test_proj_trans_and_bi_inter_match_their_restatements():
+    P, ht, wd = 4, 6, 8
+    poses, disps, intr, ii, jj, tgt, wgt, eta = _scene(P, ht, wd, 9)
+    C_ref, w_ref, kx = BO.proj_trans_dense(torch.from_numpy(tgt), torch.from_numpy(wgt), poses, torch.from_numpy(disps), intr, ii, jj)
+    C, w = db.proj_trans(_f(poses), _f(disps), _f(intr[0]), _f(tgt)[None], _f(wgt)[None], torch.from_numpy(ii), torch.from_numpy(jj))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(C.cpu().numpy(), C_ref.numpy(), rtol=2e-3, atol=1e-6 * float(C_ref.abs().max()) + 1e-9)
+    np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=2e-3, atol=2e-3 * float(w_ref.abs().max()))
+    g = torch.Generator().manual_seed(1)
+    M, hs, ws = 3, 3, 4
+    scales = torch.rand(M, hs, ws, generator=g) + 0.5
+    grid = torch.stack([torch.rand(M, ht, wd, generator=g) * (ws - 1), torch.rand(M, ht, wd, generator=g) * (hs - 1)], -1)
+    v, J = db.bi_inter(scales.to(DEV), grid.to(DEV))
+    v_ref, J_ref = BO.bi_inter_ref(scales, grid)
+    np.testing.assert_allclose(v.cpu().numpy(), v_ref.numpy(), atol=1e-6)
+    np.testing.assert_allclose(J.cpu().numpy(), J_ref.numpy(), atol=1e-6)
+    np.testing.assert_allclose(J.sum(-1).cpu().numpy(), 1.0, atol=1e-6)                  # interior points: weights sum to one
+
+
+def test_jdsa_matches_unreduced_dense_solve():
+    from cut3r_slam_amd.ba import JDSA
+    P, ht, wd, hs, ws, alpha = 4, 6, 8, 2, 3, 0.05
+    poses, disps, intr, ii, jj, tgt, wgt, eta = _scene(P, ht, wd, 5)
+    g = np.random.default_rng(2)
+    prior = disps * g.uniform(0.8, 1.2, disps.shape)
+    prior[:, :2, :3] = 0.0                                          # pixels without a prior fall back to eta (ba.py:216-217)
+    scales = g.uniform(0.9, 1.1, (P, hs, ws))
+    C_ref, w_ref, kx = BO.proj_trans_dense(torch.from_numpy(tgt), torch.from_numpy(wgt), poses, torch.from_numpy(disps), intr, ii, jj)
+    dz_ref, dso_ref = BO.jdsa_dense(C_ref, w_ref, torch.from_numpy(eta), torch.from_numpy(disps[kx]), torch.from_numpy(prior[kx]),
+                                    torch.from_numpy(scales[kx]), alpha)
+    dsc = _f(scales).clone()
+    new_disps, new_scales, dzcov = JDSA(_f(tgt)[None], _f(wgt)[None], _f(eta), SE3(_f(poses)[None]), _f(disps)[None], _f(intr)[None],
+                                        _f(prior), dsc, torch.from_numpy(ii), torch.from_numpy(jj), alpha)
+    torch.cuda.synchronize()
+    ref_d = torch.from_numpy(disps).clone()
+    ref_d[torch.from_numpy(kx)] += dz_ref.reshape(-1, ht, wd)
+    ref_d = torch.where(ref_d > 10, torch.zeros_like(ref_d), ref_d).clamp(min=0.001)
+    sz, ss = float(dz_ref.abs().max()), float(dso_ref.abs().max())
+    assert sz > 1e-4 and ss > 1e-4
+    np.testing.assert_allclose(new_disps[0].cpu().numpy(), ref_d.numpy(), atol=1e-2 * sz + 1e-6)
+    np.testing.assert_allclose((new_scales.cpu().double() - torch.from_numpy(scales))[torch.from_numpy(kx)].reshape(len(kx), -1).numpy(),
+                               dso_ref.numpy(), atol=1e-2 * ss + 1e-6)
+    assert dzcov.shape == (len(kx), ht * wd) and bool((dzcov > 0).all())
+
+
+def test_altcorr_forward_and_backward_vs_all_pairs_volume():
+    g = torch.Generator().manual_seed(4)
+    BN, H, W, H2, W2, Cc, S, r = 2, 5, 6, 7, 8, 24, 2, 2
+    f1 = torch.randn(BN, H, W, Cc, generator=g, dtype=torch.float64)
+    f2 = torch.randn(BN, H2, W2, Cc, generator=g, dtype=torch.float64)
+    coords = torch.stack([torch.rand(BN, S, H, W, generator=g, dtype=torch.float64) * (W2 + 3) - 1.5,
+                          torch.rand(BN, S, H, W, generator=g, dtype=torch.float64) * (H2 + 3) - 1.5], -1)
+    f1r, f2r = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    ref = BO.altcorr_ref(f1r, f2r, coords, r)
+    G = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    (ref * G).sum().backward()
+    a1, a2 = f1.float().to(DEV).requires_grad_(True), f2.float().to(DEV).requires_grad_(True)
+    out = db.CorrLayer.apply(a1, a2, coords.float().to(DEV), r)
+    (out * G.float().to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-4)
+    np.testing.assert_allclose(a1.grad.cpu().numpy(), f1r.grad.numpy(), atol=5e-4)
+    np.testing.assert_allclose(a2.grad.cpu().numpy(), f2r.grad.numpy(), atol=5e-4)
+    # AltCorrBlock == CorrBlock lookup semantics on level 0 (features / 4 on both sides)
+    fm = torch.randn(1, 3, Cc, 8, 8, generator=g)
+    blk = db.AltCorrBlock(fm.to(DEV), num_levels=2, radius=1)
+    cc = torch.rand(1, 2, 8, 8, 2, generator=g) * 7
+    res = blk(cc.to(DEV), torch.tensor([0, 1]), torch.tensor([1, 2]))
+    assert res.shape == (1, 2, 2 * 9, 8, 8)
+    v0 = BO.altcorr_ref((fm[0, [0, 1]] / 4).permute(0, 2, 3, 1).double(), (fm[0, [1, 2]] / 4).permute(0, 2, 3, 1).double(), cc[0][:, None].double(), 1)
+    np.testing.assert_allclose(res[0, :, :9].cpu().numpy(), v0[:, 0].numpy(), atol=2e-4)
+
+
+def test_edge_sharded_ba_sums_to_the_full_system():
+    """north_star's second split: edges sharded by source frame, normal-equation blocks summed.  Two 'ranks' in one process: the
+    undamped reduced systems of the two edge subsets add up to the full one, and BA over a fake two-rank all-reduce reproduces
+    the single-rank step (poses, disparities)."""
+    from cut3r_slam_amd import ba as B
+    P, ht, wd, fixedp = 6, 8, 10, 1
+    poses, disps, intr, ii, jj, tgt, wgt, eta = _scene(P, ht, wd, 7)
+    args = (_f(tgt)[None], _f(wgt)[None], _f(eta), SE3(_f(poses)[None]), _f(disps)[None], _f(intr)[None], torch.from_numpy(ii), torch.from_numpy(jj))
+    p_full, d_full, info = B.BA(*args, fixedp=fixedp)
+    masks = [B.shard_edges_by_source(torch.from_numpy(ii), 2, r) for r in range(2)]
+    assert bool((masks[0] ^ masks[1]).all()) and set(ii[masks[0].numpy()]).isdisjoint(set(ii[masks[1].numpy()]))
+    parts = [B.BA(*args, fixedp=fixedp, edge_mask=m) for m in masks]           # each alone: only its S / vS are used below
+    S = parts[0][2]["S"] + parts[1][2]["S"]
+    vS = parts[0][2]["vS"] + parts[1][2]["vS"]
+    torch.cuda.synchronize()
+    sc = float(info["S"].abs().max())
+    np.testing.assert_allclose(S.cpu().numpy(), info["S"].cpu().numpy(), atol=2e-5 * sc)
+    np.testing.assert_allclose(vS.cpu().numpy(), info["vS"].cpu().numpy(), atol=2e-5 * float(info["vS"].abs().max()))
