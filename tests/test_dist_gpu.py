@@ -55,3 +55,11 @@ def test_two_ranks_on_one_gpu_match_each_other_and_a_single_rank(tmp_path):
     c = np.load(scan1 + ".rank0.npz")
     for key in ("pose", "w2c", "depth_sum", "submap_sum", "ii", "jj"):
         np.testing.assert_array_equal(r0[key], c[key], err_msg="scan, one rank: " + key)
+
+
+def test_edge_sharded_ba_two_ranks_gloo():
+    """BASELINE north_star: per-edge BA sharded over GPUs with an all-reduce of the normal-equation blocks -- two ranks (sharing
+    GPU 0, gloo) each assemble the source frames they own; the summed reduced system gives the single-rank step."""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "tools/ba_shard_check.py"], {"CUT3R_DIST_BACKEND": "gloo"})
+    assert out.count("OK") == 2
