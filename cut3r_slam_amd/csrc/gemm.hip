@@ -916,6 +916,7 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         else if (d->stages == 8) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 4>), grid, dim3(512), 0, s, g);   // 8 waves
         else if (d->stages == 9) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);   // 8 waves
         else if (d->stages == 10) hipLaunchKernelGGL((gemm_kernel<128, 128, 3, 4, 2>), grid, dim3(512), 0, s, g);
+        else if (d->stages == 14) hipLaunchKernelGGL((gemm_kernel<128, 128, 4, 4, 2>), grid, dim3(512), 0, s, g);      // 128 KiB ring, one workgroup per CU
         else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<128, 128, 2>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
     } else if (tile == 128192) {       // 128 x 192 (four 48-wide or three 64-wide heads per tile), 8 waves (32 x 96 per wave), 80 KB LDS
@@ -925,10 +926,12 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     } else if (tile == 192128) {       // 192 x 128, 8 waves (48 x 64 per wave), 80 KB LDS: two workgroups per CU
         dim3 grid(((d->N + 127) / 128) * ((d->M + 191) / 192), 1, batch);
         g.swz = 1;
-        hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
+        if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<192, 128, 3, 4, 2>), grid, dim3(512), 0, s, g);                 // 120 KiB ring
+        else hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
     } else if (tile == 256128) {
         dim3 grid((d->N + 127) / 128, (d->M + 255) / 256, batch);
-        hipLaunchKernelGGL((gemm_kernel<256, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
+        if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<256, 128, 3, 4, 2>), grid, dim3(512), 0, s, g);                 // 144 KiB ring
+        else hipLaunchKernelGGL((gemm_kernel<256, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
     } else if (tile == 12864) {
         dim3 grid((d->N + 63) / 64, (d->M + 127) / 128, batch);
         if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<128, 64, 3>), grid, dim3(256), 0, s, g);
