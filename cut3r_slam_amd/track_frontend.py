@@ -335,21 +335,24 @@ class TrackFrontend:
         h, w = kf.submap_ds.shape[2:4]
         n = len(ranges)
         i0, i1 = own
-        per = []
-        # ---- host scan: scale and chained poses of every window of the step
-        for k, (t0, t1) in enumerate(ranges):
-            V = t1 - t0
-            L0, L5 = float(scal[k, 0]), float(scal[k, 1])
-            host = np.asarray(scal[k, 2:2 + 7 * V], np.float64).reshape(V, 7).astype(np.float32)
-            poses = gh.pose_encoding_to_camera(host)
-            first_w2c = gh.inv4(poses[0])
-            lsum = chain["log_s"] * (H * W) + chain["L5"] - L0
+        # ---- host scan: scale and chained poses of every window of the step (geom_host.chain_windows: one pose composition and
+        #      one quaternion conversion per window in sequence, the other views batched)
+        V = ranges[0][1] - ranges[0][0]
+        if any(t1 - t0 != V for t0, t1 in ranges):
+            raise NotImplementedError("sharded tracking: windows of equal length")
+        scal = np.asarray(scal, np.float64)
+
+        def scale_of(k):
+            lsum = chain["log_s"] * (H * W) + chain["L5"] - float(scal[k, 0])
             align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
-            prev_c2w = gh.pose_vec_to_matrix(kf.pose[t0].numpy()[None])[0]
-            chained = [gh.chain_pose(first_w2c, poses[v], prev_c2w[:3, :3], prev_c2w[:3, 3], align_s) for v in range(V)]
-            rows = kf.set_poses(t0, gh.matrices_to_pose_vecs(np.stack(chained)), upload=False)
-            chain["log_s"], chain["L5"] = math.log(float(align_s)), L5
-            per.append((chained, align_s, rows))
+            chain["log_s"], chain["L5"] = math.log(float(align_s)), float(scal[k, 1])
+            return align_s
+
+        encs = scal[:, 2:2 + 7 * V].reshape(n, V, 7).astype(np.float32)
+        chained_all, s_all, vecs, rows_all = gh.chain_windows(encs, scale_of, kf.pose[ranges[0][0]].numpy())
+        for k, (t0, t1) in enumerate(ranges):                 # later windows overwrite the shared keyframe, as track() does
+            kf.pose[t0:t1] = torch.from_numpy(vecs[k])
+        per = [(chained_all[k], s_all[k], rows_all[k]) for k in range(n)]
         # device mirror of every new world->camera row (other ranks' windows included: the forward counts need all cameras)
         ta, tb = ranges[0][0], ranges[-1][1]
         allrows = np.zeros((tb - ta, 12), np.float32)
