@@ -135,17 +135,24 @@ def git_sha():
         return None
 
 
+PMC_KEYS = {128: "gemm_kernel<128, 128, 2, 4, 2>", 256: "gemm256_kernel<false, false>"}
+
+
 def traffic_from_profile(tile, launches_in_run):
-    """HBM-side bytes per launch of the dominant GEMM from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of this same command, tools/pmc_traffic.py).  NOT measured in this run: emitted with its provenance,
-    and dropped (null) when the profile belongs to another kernel build."""
-    for rnd in ("r02", "r01"):
-        pj = os.path.join(ROOT, "profiles", rnd, f"pmc_traffic_gemm{tile}.json")
-        if os.path.isfile(pj):
-            j = json.load(open(pj))
-            return {"bytes_per_launch": j.get("traffic_bytes_per_launch"), "source": os.path.relpath(pj, ROOT),
-                    "profile_launches": j.get("launches"), "profile_git_sha": j.get("git_sha"), "run_launches": launches_in_run,
-                    "note": "separate rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE); not measured in this run"}
+    """HBM-side bytes per launch of the dominant GEMM from the committed rocprofv3 --pmc passes of this same command (separate
+    FETCH_SIZE / WRITE_SIZE runs, reduced on the GPU box by tools/pmc_reduce.py: 2 x FETCH_SIZE KiB + WRITE_SIZE KiB, the gfx950
+    correction of MI355X_MICROARCH.md).  PMC counters need the profiler, so this is never measured inside the run itself: it is
+    emitted with its provenance.  FETCH_SIZE counts what the 8 per-XCD L2s request from the fabric, so operands every XCD reads
+    (the weight panel) count 8 times although the Infinity Cache serves them."""
+    pj = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+    if os.path.isfile(pj):
+        j = json.load(open(pj))
+        k = j.get("kernels", {}).get(PMC_KEYS.get(tile, ""))
+        if k:
+            return {"bytes_per_launch": k.get("traffic_bytes_per_launch"), "source": os.path.relpath(pj, ROOT),
+                    "profile_launches": k.get("launches"), "profile_git_sha": j.get("git_sha"), "run_launches": launches_in_run,
+                    "note": "separate rocprofv3 --pmc passes of `bench.py --steps 2` (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE), averaged over "
+                            "every launch of this kernel in the step; not measured in this run"}
     return None
 
 
@@ -425,6 +432,7 @@ def main():
                 dom = max(gem, key=lambda tk: gem[tk][1])          # the GEMM kernel with the largest total time in this workload
                 n, ms, fl, by = gem[dom]
                 ach = fl / (ms * 1e-3) / 1e12
+                tfp = traffic_from_profile(dom, n)
                 tot_ms = sum(v[1] for v in gem.values())
                 others = []
                 for tk, (n2, ms2, fl2, by2) in gem.items():
@@ -437,7 +445,7 @@ def main():
                                    "bound": "mfma", "launches": n2, "avg_launch_us": round(ms2 * 1e3 / n2, 2), "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2),
                                    "peak": PEAK_F16, "unit": "TFLOP/s", "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / PEAK_F16, 4), "flops_per_launch": fl2 / n2})
                 roofline = {"bound": "mfma", "kernel": KernelProbe.GEMM[dom], "achieved": round(ach, 2), "peak": PEAK_F16, "unit": "TFLOP/s",
-                            "frac": round(ach / PEAK_F16, 4), "traffic": None, "traffic_from_profile": traffic_from_profile(dom, n),
+                            "frac": round(ach / PEAK_F16, 4), "traffic": (tfp or {}).get("bytes_per_launch"), "traffic_from_profile": tfp,
                             "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n,
                             "algorithmic_bytes_per_launch": by / n, "share_of_large_gemm_time": round(ms / tot_ms, 3),
                             "second_kernel": others[0] if others else None, "other_kernels": others}

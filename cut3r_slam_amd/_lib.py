@@ -43,6 +43,8 @@ SIGNATURES = {
     "cut3r_rope2d": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_ll, c_ll, c_ll, c_float, c_float, c_void_p],
     "cut3r_rope2d_qk": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_ll, c_ll, c_ll, c_ll, c_float, c_float,
                         c_void_p],
+    "cut3r_rope2d_tab": [c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p, c_ll, c_ll, c_int, c_int, c_void_p, c_int, c_int, c_float,
+                         c_float, c_void_p],
     "cut3r_layernorm": [c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                         c_void_p, c_void_p, c_void_p],
     "cut3r_layernorm_dual": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int,

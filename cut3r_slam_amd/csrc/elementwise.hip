@@ -58,6 +58,69 @@ __global__ __launch_bounds__(256) void rope2d_kernel(T* __restrict__ tok, T* __r
     }
 }
 
+// Table-driven form for the network's own launches: cos/sin come from the table of rope2d_table_kernel (same expressions, so the
+// same bits), there is no per-token workgroup, no transcendental and no barrier: one thread rotates VE (u, v) pairs with
+// 8/16-byte accesses, a launch covers TWO token ranges (q and k of a self-attention; q of one token stream and k of the other in
+// a cross-attention).  Positions outside the table are evaluated in place by the expressions of rope2d_kernel.
+struct RopeSeg {
+    h16* p;
+    const int64_t* pos;
+    long long sTok;         // token stride in elements (head stride = D)
+};
+
+template <int VE> struct alignas(2 * VE) HVec { h16 v[VE]; };
+
+template <int VE>
+__global__ __launch_bounds__(256) void rope2d_tab_kernel(RopeSeg a, RopeSeg b, long long work_a, long long work_total, int H, int D,
+                                                         const float* __restrict__ table, int pmin, int npos, float base, float fwd) {
+    long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= work_total) return;
+    RopeSeg s = a;
+    if (w >= work_a) { w -= work_a; s = b; }
+    const int Q = D >> 2, QV = Q / VE, per_tok = H * 2 * QV;
+    const long long t = w / per_tok;
+    int r = (int)(w - t * per_tok);
+    const int h = r / (2 * QV);
+    r -= h * 2 * QV;
+    const int X = r / QV, c = r - X * QV;
+    h16* pu = s.p + t * s.sTok + (long long)h * D + X * 2 * Q + VE * c;
+    h16* pv = pu + Q;
+    const HVec<VE> u = *reinterpret_cast<const HVec<VE>*>(pu);
+    const HVec<VE> v = *reinterpret_cast<const HVec<VE>*>(pv);
+    const long long pp = s.pos[t * 2 + X];
+    const long long pi = pp - pmin;
+    float co[VE], si[VE];
+    if (pi >= 0 && pi < npos) {
+        const float* tc = table + pi * Q + VE * c;
+        const float* ts = tc + (long long)npos * Q;
+#pragma unroll
+        for (int e = 0; e < VE; e += 4) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(tc + e), s4 = *reinterpret_cast<const f32x4*>(ts + e);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { co[e + j] = c4[j]; si[e + j] = s4[j]; }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < VE; e++) {
+            const float inv = fwd / powf(base, (float)(VE * c + e) / (float)Q);
+            const float fr = (float)pp * inv;
+            co[e] = cosf(fr);
+            si[e] = sinf(fr);
+        }
+    }
+    HVec<VE> ou, ov;
+#pragma unroll
+    for (int e = 0; e < VE; e++) {
+        const float uf = (float)u.v[e], vf = (float)v.v[e];
+        float t1 = vf * si[e], t2 = uf * si[e];
+        asm volatile("" : "+v"(t1), "+v"(t2));
+        ou.v[e] = (h16)rope_rot(uf, co[e], -t1);
+        ov.v[e] = (h16)rope_rot(vf, co[e], t2);
+    }
+    *reinterpret_cast<HVec<VE>*>(pu) = ou;
+    *reinterpret_cast<HVec<VE>*>(pv) = ov;
+}
+
 // cos / sin of every (position, frequency) pair for a quarter head dimension Q, by the expressions of rope2d_kernel
 __global__ void rope2d_table_kernel(float* __restrict__ table, int pmin, int npos, int Q, float base, float fwd) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,6 +621,27 @@ extern "C" int cut3r_rope2d_table(float* table, int pmin, int npos, int Q, float
 extern "C" int cut3r_rope2d(void* tokens, int dtype, const int64_t* positions, int B, int N, int H, int D, long long sB,
                             long long sN, long long sH, float base, float fwd, void* stream) {
     return launch_rope(tokens, nullptr, dtype, positions, B, N, H, D, sB, sN, sH, 0, 0, base, fwd, stream);
+}
+
+extern "C" int cut3r_rope2d_tab(void* t0, const int64_t* pos0, long long ntok0, long long stride0, void* t1, const int64_t* pos1,
+                                long long ntok1, long long stride1, int H, int D, const float* table, int pmin, int npos, float base,
+                                float fwd, void* stream) {
+    if (!t0 || !pos0 || !table || ntok0 <= 0 || H <= 0 || D <= 0 || (D & 15) || D > 256 || npos < 1) return CUT3R_ERR_ARG;
+    if (t1 && (!pos1 || ntok1 <= 0)) return CUT3R_ERR_ARG;
+    const int Q = D >> 2;
+    const int VE = (Q % 8 == 0) ? 8 : 4;
+    const long long am = VE - 1;                                    // 16-byte (VE = 8) or 8-byte vectors
+    if ((stride0 & am) || (t1 && (stride1 & am)) || ((uintptr_t)t0 & (2 * VE - 1)) || (t1 && ((uintptr_t)t1 & (2 * VE - 1)))) return CUT3R_ERR_ARG;
+    if (stride0 < (long long)H * D || (t1 && stride1 < (long long)H * D)) return CUT3R_ERR_ARG;
+    const long long per_tok = (long long)H * 2 * (Q / VE);
+    const long long wa = ntok0 * per_tok, wt = wa + (t1 ? ntok1 * per_tok : 0);
+    RopeSeg a{(h16*)t0, pos0, stride0}, b{(h16*)(t1 ? t1 : t0), t1 ? pos1 : pos0, t1 ? stride1 : stride0};
+    dim3 grid((unsigned)((wt + 255) / 256)), block(256);
+    if (VE == 8)
+        hipLaunchKernelGGL((rope2d_tab_kernel<8>), grid, block, 0, (hipStream_t)stream, a, b, wa, wt, H, D, table, pmin, npos, base, fwd);
+    else
+        hipLaunchKernelGGL((rope2d_tab_kernel<4>), grid, block, 0, (hipStream_t)stream, a, b, wa, wt, H, D, table, pmin, npos, base, fwd);
+    return cut3r_check_launch();
 }
 
 extern "C" int cut3r_rope2d_qk(void* q, void* k, int dtype, const int64_t* positions, int B, int N, int H, int D, long long q_sB,

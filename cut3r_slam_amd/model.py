@@ -171,6 +171,9 @@ class Cut3rModel:
         w = cfg.state_width
         i = torch.arange(cfg.state_size)
         self.state_pos = torch.stack([i // w, i % w], -1)[None].to(dev).contiguous()       # int64 [1,S,2]
+        for hd in {cfg.enc_embed_dim // cfg.enc_num_heads, cfg.dec_embed_dim // cfg.dec_num_heads, cfg.dec_embed_dim // cfg.state_dec_num_heads}:
+            if hd % 16 == 0:
+                ops.rope_table(dev, cfg.rope_freq, 1.0, hd)        # cos|sin tables of the RoPE launches: filled before any graph capture
         h = "downstream_head"
         lin(h + ".pose_head.mlp.fc1"); lin(h + ".pose_head.mlp.fc2")
         if cfg.head_type == "dpt":
@@ -258,7 +261,7 @@ class Cut3rModel:
         ops.layernorm(x, g, b, self.cfg.ln_eps, out16, out32, mod[0] if mod else None, mod[1] if mod else None)
 
     def _rope(self, t, pos):
-        ops.rope_2d(t, pos, self.cfg.rope_freq, 1.0)
+        ops.rope_2d_pair(t, pos, None, None, self.cfg.rope_freq, 1.0)
 
     def _self_attn(self, tag, x_ln16, B, N, heads, pos, p, out, res):
         """x_ln16 fp16 [B*N,C] -> out(fp32) = res + proj(attn(qkv(x)))"""
@@ -271,7 +274,7 @@ class Cut3rModel:
         v5 = qkv.view(B, N, 3, heads, D)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
         if pos is not None and not fuse:
-            ops.rope_2d_qk(q, k, pos, self.cfg.rope_freq, 1.0)
+            ops.rope_2d_pair(q, pos, k, pos, self.cfg.rope_freq, 1.0)
         a = self.buf(tag + ".attn", (B, N, heads, D), F16)
         ops.attention(q, k, v, a, D ** -0.5)
         self._linear(a.view(B * N, Cc), p + ".proj", out, res1=res, skinny=sk)
@@ -451,7 +454,7 @@ class Cut3rModel:
         def self_attn(sd):
             v5 = sd["qkv"].view(Wn, sd["Nx"], 3, sd["heads"], sd["D"])
             q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
-            ops.rope_2d_qk(q, k, sd["xpos"], cfg.rope_freq, 1.0)
+            ops.rope_2d_pair(q, sd["xpos"], k, sd["xpos"], cfg.rope_freq, 1.0)
             ops.attention(q, k, v, sd["att"], sd["D"] ** -0.5)
         both(self_attn)
         self._linear_pair(S["att"].view(Wn * Ns, Cc), ps + ".attn.proj", S["out"], I["att"].view(Wn * Ni, Cc), pi + ".attn.proj", I["out"],
@@ -464,8 +467,7 @@ class Cut3rModel:
         def cross_attn(sd):
             kv4 = sd["kv"].view(Wn, sd["Ny"], 2, sd["heads"], sd["D"])
             k, v = kv4[:, :, 0], kv4[:, :, 1]
-            self._rope(sd["q"], sd["xpos"])
-            self._rope(k, sd["ypos"])
+            ops.rope_2d_pair(sd["q"], sd["xpos"], k, sd["ypos"], cfg.rope_freq, 1.0)
             ops.attention(sd["q"], k, v, sd["catt"], sd["D"] ** -0.5)
         both(cross_attn)
         self._linear_pair(S["catt"].view(Wn * Ns, Cc), ps + ".cross_attn.proj", S["out"], I["catt"].view(Wn * Ni, Cc), pi + ".cross_attn.proj", I["out"],

@@ -89,6 +89,34 @@ def rope_2d_qk(q, k, positions, base, fwd):
                               float(base), float(fwd), _stream()), "cut3r_rope2d_qk")
 
 
+def _rope_seg(t, pos):
+    """(B,N,H,D) fp16 view with head stride D and a uniform token stride -> (ptr, pos ptr, tokens, token stride)"""
+    if t.dim() != 4 or t.dtype != F16 or not t.is_cuda or t.stride(3) != 1 or t.stride(2) != t.size(3):
+        raise RuntimeError("tokens are not contiguous")
+    B, N = t.shape[:2]
+    if B > 1 and t.stride(0) != N * t.stride(1):
+        raise RuntimeError("rope_2d_pair: the token stride must be uniform over the batch")
+    if pos.shape != (B, N, 2) or pos.dtype != torch.int64 or not pos.is_contiguous() or not pos.is_cuda:
+        raise RuntimeError("positions must be contiguous int64 [B,N,2]")
+    return _p(t), _p(pos), B * N, t.stride(1)
+
+
+def rope_2d_pair(t0, pos0, t1, pos1, base, fwd=1.0):
+    """rope_2d(t0, pos0) and rope_2d(t1, pos1) in ONE table-driven launch (fp16; results are bit-identical to rope_2d): q and k of a
+    self-attention (pos1 is pos0) or of a cross-attention (two token streams).  t1 may be None."""
+    H, D = t0.shape[2:]
+    if D % 16 != 0:
+        raise RuntimeError("cut3r_slam_amd.rope_2d: head dims that are multiples of 16 only (CUT3R uses 16/32/48/64)")
+    if t1 is not None and tuple(t1.shape[2:]) != (H, D):
+        raise RuntimeError("rope_2d_pair: both tensors must have the same heads and head dim")
+    a = _rope_seg(t0, pos0)
+    b = _rope_seg(t1, pos1) if t1 is not None else (None, None, 0, 0)
+    tab = rope_table(t0.device, base, fwd, D)
+    lib = _lib.load()
+    check(lib.cut3r_rope2d_tab(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], H, D, _p(tab), ROPE_PMIN, ROPE_NPOS, float(base), float(fwd),
+                               _stream()), "cut3r_rope2d_tab")
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm
 def layernorm(x, gamma, beta, eps=1e-6, out16=None, out32=None, mod_scale=None, mod_shift=None):
     _cuda(x, gamma, beta, out16, out32, mod_scale, mod_shift)

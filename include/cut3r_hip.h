@@ -29,6 +29,14 @@ int cut3r_rope2d(void* tokens, int dtype, const int64_t* positions, int B, int N
 int cut3r_rope2d_qk(void* q, void* k, int dtype, const int64_t* positions, int B, int N, int H, int D, long long q_sB,
                     long long q_sN, long long k_sB, long long k_sN, float base, float fwd, void* stream);
 
+/* the same rotation driven by the cos|sin table of cut3r_rope2d_table (identical bits: the table is filled by the expressions of
+ * cut3r_rope2d), for fp16 tokens with head stride D: ONE launch rotates two token ranges -- q and k of a self-attention, or q of
+ * one token stream and k of the other in a cross-attention (dust3r/blocks.py:118-119,226-227).  t_i: ntok_i tokens, token stride
+ * stride_i elements (multiple of 8 when D % 32 == 0, else of 4), pos_i int64 [ntok_i,2]; t1 may be NULL.  Positions outside
+ * [pmin, pmin+npos) are evaluated in place. */
+int cut3r_rope2d_tab(void* t0, const int64_t* pos0, long long ntok0, long long stride0, void* t1, const int64_t* pos1, long long ntok1,
+                     long long stride1, int H, int D, const float* table, int pmin, int npos, float base, float fwd, void* stream);
+
 /* ---- LayerNorm (+adaLN modulation) -------------------------------------------------------------------------
  * replaces nn.LayerNorm(eps=1e-6) calls in croco/models/blocks.py:187-190, dust3r/blocks.py:292-297 and
  * ModLN (dust3r/blocks.py:356-379: y = LN(x)*(1+scale)+shift).  x fp32 [M,C] (row stride ldx).  Writes any of:

@@ -274,6 +274,43 @@ def test_rope_strided_half_view_like_the_model():
         ops.rope_2d(dev[:, :, 0].transpose(1, 2), pos.to(DEV), 100.0, 1.0)    # reference's stride check
 
 
+@pytest.mark.parametrize("H,D", [(12, 64), (16, 48), (3, 32), (5, 16), (2, 128)])
+def test_rope_table_launch_gives_the_bits_of_the_reference_shaped_kernel(H, D):
+    """the network's RoPE launches (ops.rope_2d_pair: table-driven, two token ranges per launch) against ops.rope_2d (the curope
+    drop-in, one workgroup per token): identical bits, on the strided q / k views of a qkv buffer, for a cross-attention pair with
+    different token counts, for the pose token's position -1 and for positions beyond the table (evaluated in place)."""
+    g = torch.Generator().manual_seed(H * 100 + D)
+    B, N, N2 = 3, 257, 64
+    qkv = torch.randn(B, N, 3, H, D, generator=g).half().to(DEV)
+    pos = torch.randint(-1, 40, (B, N, 2), generator=g)
+    pos[0, 0] = -1
+    pos[1, 5, 0], pos[1, 6, 1], pos[2, 7, 0] = 300, 100000, -7             # outside the table [-1, 256]
+    pos = pos.to(DEV)
+    ref = qkv.clone()
+    ops.rope_2d(ref[:, :, 0], pos, 100.0, 1.0)
+    ops.rope_2d(ref[:, :, 1], pos, 100.0, 1.0)
+    ops.rope_2d_pair(qkv[:, :, 0], pos, qkv[:, :, 1], pos, 100.0, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv, ref)
+    assert not torch.equal(qkv[:, :, 0], qkv[:, :, 2])
+    q = torch.randn(B, N, H, D, generator=g).half().to(DEV)
+    kv = torch.randn(B, N2, 2, H, D, generator=g).half().to(DEV)
+    pos2 = torch.randint(0, 16, (B, N2, 2), generator=g).to(DEV)
+    rq, rkv = q.clone(), kv.clone()
+    ops.rope_2d(rq, pos, 100.0, 1.0)
+    ops.rope_2d(rkv[:, :, 0], pos2, 100.0, 1.0)
+    ops.rope_2d_pair(q, pos, kv[:, :, 0], pos2, 100.0, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(q, rq) and torch.equal(kv, rkv)
+    one = rq.clone()
+    ops.rope_2d(rq, pos, 100.0, 1.0)
+    ops.rope_2d_pair(one, pos, None, None, 100.0, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(one, rq)
+    with pytest.raises(RuntimeError):
+        ops.rope_2d_pair(q.transpose(1, 2), pos, None, None, 100.0, 1.0)
+
+
 @pytest.mark.parametrize("M,C", [(768, 1024), (769, 768), (5, 48), (256, 1536), (1, 1536)])
 def test_layernorm_and_adaln(M, C):
     g = torch.Generator().manual_seed(C)
