@@ -140,21 +140,28 @@ __global__ __launch_bounds__(NW * 64, (D <= 64 && NW == 4) ? 3 : 1) void attn_ke
     for (int t = 0; t < ntiles; t++) {
         __syncthreads();
         store_kv();
+        // every prefetched register has been consumed: say so on ALL paths (the guarded staging writes are branches whose
+        // skipped side keeps the loads "pending" for the compiler's wait-count pass, which then makes the first MFMAs of the
+        // tile wait for the NEXT tile's loads -- the prefetch would hide nothing)
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
         __syncthreads();
         if (t + 1 < ntiles) load_kv(t + 1);
         if (!active) continue;
 
         // ---- S^T = K Q^T for the two 32-key sub-tiles
         f32x16 st[2];
+        half8_t kf[2][DQ];                        // every K fragment of the tile is requested before the first MFMA
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; kt2++)
+#pragma unroll
+            for (int s = 0; s < DQ; s++) kf[kt2][s] = *reinterpret_cast<const half8_t*>(&Ks[(kt2 * 32 + r) * KS_LD + 16 * s + 8 * hh]);
+        __builtin_amdgcn_sched_barrier(0);        // (the scheduler would sink each read to its MFMA: read, wait, MFMA, eight times)
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; kt2++) {
 #pragma unroll
             for (int i = 0; i < 16; i++) st[kt2][i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < DQ; s++) {
-                half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[(kt2 * 32 + r) * KS_LD + 16 * s + 8 * hh]);
-                st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[kt2], 0, 0, 0);
-            }
+            for (int s = 0; s < DQ; s++) st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt2][s], qf[s], st[kt2], 0, 0, 0);
         }
         // ---- online softmax (per query column == per lane; partner lane^32 holds the other 32 keys)
         const int kbase = extra + t * KT;

@@ -89,6 +89,9 @@ def rope_2d_qk(q, k, positions, base, fwd):
                               float(base), float(fwd), _stream()), "cut3r_rope2d_qk")
 
 
+_ROPE_TABLE_LAUNCH = os.environ.get("CUT3R_ROPE_TABLE", "1") != "0"
+
+
 def _rope_seg(t, pos):
     """(B,N,H,D) fp16 view with head stride D and a uniform token stride -> (ptr, pos ptr, tokens, token stride)"""
     if t.dim() != 4 or t.dtype != F16 or not t.is_cuda or t.stride(3) != 1 or t.stride(2) != t.size(3):
@@ -107,6 +110,13 @@ def rope_2d_pair(t0, pos0, t1, pos1, base, fwd=1.0):
     H, D = t0.shape[2:]
     if D % 16 != 0:
         raise RuntimeError("cut3r_slam_amd.rope_2d: head dims that are multiples of 16 only (CUT3R uses 16/32/48/64)")
+    if not _ROPE_TABLE_LAUNCH:            # A/B knob: the one-workgroup-per-token kernel (same bits)
+        if t1 is not None and pos1 is pos0 and t1.shape == t0.shape:
+            return rope_2d_qk(t0, t1, pos0, base, fwd)
+        rope_2d(t0, pos0, base, fwd)
+        if t1 is not None:
+            rope_2d(t1, pos1, base, fwd)
+        return
     if t1 is not None and tuple(t1.shape[2:]) != (H, D):
         raise RuntimeError("rope_2d_pair: both tensors must have the same heads and head dim")
     a = _rope_seg(t0, pos0)

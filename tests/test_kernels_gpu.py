@@ -433,6 +433,64 @@ def test_overlap_counts_bit_exact(n, H, W):
         np.testing.assert_array_equal(cnt2[:i].cpu().numpy(), G.overlap_bwd(pm[:i], w2c[i], K4, W, H))
 
 
+@pytest.mark.parametrize("W,H,K4", [(512, 384, (256.0, 211.8, 255.8, 191.6)), (64, 48, (60.0, 59.0, 31.5, 23.5)), (333, 77, (410.3, 95.7, 170.21, 33.33))])
+def test_overlap_counts_on_the_image_border_bit_exact(W, H, K4):
+    """the division-free form of the projection test (geometry.hip proj_valid) must take the reference's literal test for points
+    within rounding of a bound: points are placed ON the four borders (u = -0.5, W - 0.5, v = -0.5, H - 0.5: the round-half-even
+    ties), a few ulp either side and up to 1e-2 px away, under cameras of depth 0.05 .. 50 and the z <= 1e-5 clamp; counts and
+    per-point decisions must equal oracle_geom.c"""
+    g = np.random.default_rng(W)
+    fx, fy, cx, cy = K4
+    n = 4096
+    zc = np.exp(g.uniform(np.log(0.05), np.log(50.0), n)).astype(np.float32)
+    zc[:64] = g.uniform(-1e-5, 2e-5, 64).astype(np.float32)            # around the clamp
+    side = g.integers(0, 4, n)
+    off = np.where(g.random(n) < 0.5, 0.0, g.normal(0, 1, n) * np.exp(g.uniform(np.log(1e-7), np.log(1e-2), n)))
+    u = np.where(side == 0, -0.5, np.where(side == 1, W - 0.5, g.uniform(-3, W + 3, n))) + np.where(side < 2, off, 0)
+    v = np.where(side == 2, -0.5, np.where(side == 3, H - 0.5, g.uniform(-3, H + 3, n))) + np.where(side >= 2, off, 0)
+    zd = np.maximum(zc.astype(np.float64), 1e-5)
+    pc = np.stack([(u - cx) * zd / fx, (v - cy) * zd / fy, zc.astype(np.float64)], -1)      # camera-space points
+    for k in range(1, 9):                                              # nudge the in-plane coordinates by whole ulps
+        sl = slice(k * 256, (k + 1) * 256)
+        pc32 = pc[sl].astype(np.float32)
+        pc[sl, 0] = np.nextafter(pc32[:, 0], np.float32(np.inf if k % 2 else -np.inf)).astype(np.float64) if k < 5 else pc32[:, 0]
+        pc[sl, 1] = np.nextafter(pc32[:, 1], np.float32(np.inf if k % 2 else -np.inf)).astype(np.float64) if k >= 5 else pc32[:, 1]
+    pm = pc.astype(np.float32)
+    ident = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32)
+    cams, sets = [ident], [pm]
+    for _ in range(5):                 # general cameras, each with ITS OWN border set (the fp32 world->camera chain scatters it
+        c2w, _, _ = _scene(2, 8, 8, int(g.integers(1 << 30)))          # a few 1e-5 px around the bounds: the critical zone)
+        cams.append(G.w2c_rows(c2w)[1])
+        sets.append((pc @ c2w[1, :3, :3].T + c2w[1, :3, 3]).astype(np.float32))
+    w2c = np.stack(cams).astype(np.float32)
+    pm_all = np.concatenate(sets)
+    for clamp in (True, False):
+        cnt = torch.full((len(w2c),), -1, dtype=torch.int32, device=DEV)
+        ops.overlap_fwd(torch.from_numpy(pm_all).to(DEV), torch.from_numpy(w2c).to(DEV), K4, W, H, cnt, clamp_z=clamp)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(cnt.cpu().numpy(), G.overlap_fwd(pm_all, w2c, K4, W, H, clamp_z=clamp))
+    for clamp in (True, False):
+        cnt = torch.full((len(w2c),), -1, dtype=torch.int32, device=DEV)
+        ops.overlap_fwd(torch.from_numpy(pm).to(DEV), torch.from_numpy(w2c).to(DEV), K4, W, H, cnt, clamp_z=clamp)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(cnt.cpu().numpy(), G.overlap_fwd(pm, w2c, K4, W, H, clamp_z=clamp))
+    # per-point decisions under the identity camera (one point per launch row would be slow: 64-point slices instead)
+    ref = np.array([G.overlap_fwd(pm[i:i + 1], w2c[:1], K4, W, H)[0] for i in range(n)])
+    assert 0.1 < ref.mean() < 0.9                                      # the borders split the set
+    got = torch.zeros(n // 64, dtype=torch.int32, device=DEV)
+    pmd = torch.from_numpy(pm).to(DEV)
+    one = torch.from_numpy(w2c[:1]).to(DEV)
+    for i in range(n // 64):
+        ops.overlap_fwd(pmd[i * 64:(i + 1) * 64].contiguous(), one, K4, W, H, got[i:i + 1])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy(), ref.reshape(-1, 64).sum(1))
+    if n % 4 == 0:                                                     # backward form (no clamp), all points as one pointmap
+        cb = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.overlap_bwd(pmd.view(1, n, 3), one[0].contiguous(), K4, W, H, cb, B=1, N=n)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(cb.cpu().numpy(), G.overlap_bwd(pm[None], w2c[0], K4, W, H))
+
+
 def test_overlap_matches_reference_golden_decisions():
     f = np.load(os.path.join(GOLD, "graph.npz"))
     pm, c2w, K = f["pointmaps"], f["c2w"], f["K"]

@@ -18,6 +18,7 @@ import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None, help="alternative build of the C-ABI library (only the GEMM entry points are bound)")
 ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--wb", type=int, default=8, help="window batch: decoder M = wb x 768|769")
 ap.add_argument("--cases", default="", help="comma-separated substrings selecting cases")
 ap.add_argument("variants", nargs="*")
 args = ap.parse_args()
@@ -33,9 +34,9 @@ F16, F32 = torch.float16, torch.float32
 CASES = [  # M, N, K, act, residual, out dtype, label
     (30720, 3072, 1024, 0, False, F16, "enc qkv"), (30720, 1024, 1024, 0, True, F32, "enc proj+res"),
     (30720, 4096, 1024, 1, False, F16, "enc fc1 gelu"), (30720, 1024, 4096, 0, True, F32, "enc fc2+res"),
-    (6152, 768, 768, 0, True, F32, "dec proj+res"), (6152, 768, 768, 0, False, F16, "dec projq"),
-    (6144, 1536, 768, 0, False, F16, "dec projkv"), (6152, 2304, 768, 0, False, F16, "dec qkv"),
-    (6152, 3072, 768, 1, False, F16, "dec fc1 gelu"), (6152, 768, 3072, 0, True, F32, "dec fc2+res"),
+    (args.wb * 769, 768, 768, 0, True, F32, "dec proj+res"), (args.wb * 769, 768, 768, 0, False, F16, "dec projq"),
+    (args.wb * 768, 1536, 768, 0, False, F16, "dec projkv"), (args.wb * 769, 2304, 768, 0, False, F16, "dec qkv"),
+    (args.wb * 769, 3072, 768, 1, False, F16, "dec fc1 gelu"), (args.wb * 769, 768, 3072, 0, True, F32, "dec fc2+res"),
     (2048, 1536, 1536, 0, True, F32, "mem proj+res"), (2048, 4608, 1536, 0, False, F16, "mem qkv"),
     (2048, 6144, 1536, 1, False, F16, "mem fc1"), (2048, 1536, 6144, 0, True, F32, "mem fc2+res"),
     (768, 768, 768, 0, True, F32, "dec proj W1"), (769, 3072, 768, 1, False, F16, "dec fc1 W1"), (769, 768, 3072, 0, True, F32, "dec fc2 W1"),
