@@ -56,6 +56,26 @@ def synth_frames(n, H, W, device, seed=0):
     return frames
 
 
+class FrameLoop:
+    """a resident recording of `base.shape[0]` frames read as an endless stream: frame f is base[f % period] (slices may not wrap:
+    the drivers read single frames and short runs)"""
+
+    def __init__(self, base, virtual_len):
+        self.base, self.period = base, base.shape[0]
+        self.shape = (int(virtual_len),) + tuple(base.shape[1:])
+        self.is_cuda, self.device, self.dtype = base.is_cuda, base.device, base.dtype
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            a = 0 if key.start is None else key.start
+            b = self.shape[0] if key.stop is None else key.stop
+            s = a % self.period
+            if key.step not in (None, 1) or s + (b - a) > self.period:
+                raise IndexError("FrameLoop: contiguous slices inside one period only")
+            return self.base[s:s + (b - a)]
+        return self.base[int(key) % self.period]
+
+
 class KernelProbe:
     """HIP-event timing, on the launch stream, of every launch of the large-tile GEMM kernels and of the fused attention
     kernels (the C-ABI entry points are wrapped; events bracket live launches of an eager pass, never a graph replay)."""
@@ -157,17 +177,24 @@ def traffic_from_profile(tile, launches_in_run):
 
 
 # ------------------------------------------------------------------------------------------------------------------ legs
-def fixed_cadence_leg(model, slam_cls, cdist, dev, wb, steps, warmup, world=1, rank=0, dist_on=False, emu=0, probe_steps=0, barrier=None):
-    """buffered fixed-cadence schedule (kf_every=10) through the pipelined ShardedTracker; returns dict of results"""
+def fixed_cadence_leg(model, slam_cls, cdist, dev, wb, steps, warmup, world=1, rank=0, dist_on=False, emu=0, probe_steps=0, barrier=None,
+                      seq_windows=0):
+    """buffered fixed-cadence schedule (kf_every=10) through the pipelined ShardedTracker; returns dict of results.  seq_windows > 0:
+    the stream is a succession of sequences of that many windows (TrackFrontend.sequence_windows), 0: one endless sequence"""
     total_steps = warmup + steps
     n_kf = 7 + WIN * wb * world * (total_steps + probe_steps) + 2
     config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": KF_EVERY},
-                           "frontend": {"iteration": 0, "window_batch": 1}}}
-    slam = slam_cls(model, config, (H, W), buffer=n_kf + 8, device=dev)
+                           "frontend": {"iteration": 0, "window_batch": 1, "sequence_windows": int(seq_windows)}}}
+    # encoder features: only the windows in flight are ever read again in this mode (no loop closure): a ring of two steps
+    slam = slam_cls(model, config, (H, W), buffer=n_kf + 8, device=dev, feat_buffer=max(64, 2 * (WIN * wb * world + 1)))
     intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])  # calib/replica.txt scaled
     runner = cdist.ShardedTracker(slam, world, rank, wb=wb, pipelined=os.environ.get("CUT3R_PIPELINE", "1") == "1", force_collective=dist_on)
     runner.emulate_gather = emu > 1
-    frames = synth_frames(runner.frames_needed(total_steps + probe_steps, KF_EVERY, WIN), H, W, dev, seed=0)
+    need = runner.frames_needed(total_steps + probe_steps, KF_EVERY, WIN)
+    if seq_windows > 0:      # the sequences repeat one synthetic recording: a period of frames resident, indexed modulo the period
+        frames = FrameLoop(synth_frames(seq_windows * WIN * KF_EVERY, H, W, dev, seed=0), need)
+    else:
+        frames = synth_frames(need, H, W, dev, seed=0)
     t = 0
     while not slam.keyframes.is_initialized:          # prologue (untimed): the 6-keyframe initialisation window
         slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
@@ -334,7 +361,9 @@ def main():
     ap.add_argument("--no-operating-points", action="store_true")
     ap.add_argument("--no-trajectory-parity", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: tiny network (NOT a valid benchmark line)")
-    ap.add_argument("--window-batch", type=int, default=8, help="tracking windows pushed through the decoder together "
+    ap.add_argument("--sequence-windows", type=int, default=40, help="windows per sequence and GPU (40 = a Replica-shaped 2000-frame "
+                    "sequence at kf_every=10; multiplied by the number of GPUs); 0 = one endless stream")
+    ap.add_argument("--window-batch", type=int, default=28, help="tracking windows pushed through the decoder together "
                     "(buffered-stream throughput mode; 1 = the reference's one-window-at-a-time schedule)")
     args = ap.parse_args()
 
@@ -388,7 +417,9 @@ def main():
     single = rank == 0 and world == 1 and emu <= 1 and not dist_on
     probe_steps = args.steps if (single and not args.no_roofline) else 0
     log("fixed-cadence leg: initialisation window, warmup, timed region")
-    leg = fixed_cadence_leg(model, Cut3rSlam, cdist, dev, WB, args.steps, args.warmup, world, rank, dist_on, emu, probe_steps, barrier)
+    SEQ = max(0, args.sequence_windows) * world        # weak scaling: the sequence grows with the job (Replica room0 x world frames)
+    leg = fixed_cadence_leg(model, Cut3rSlam, cdist, dev, WB, args.steps, args.warmup, world, rank, dist_on, emu, probe_steps, barrier,
+                            seq_windows=SEQ)
     elapsed, slam, runner, frames, t, intr = (leg[k] for k in ("elapsed", "slam", "runner", "frames", "t", "intr"))
     frames_per_step = leg["frames_per_step"]
     if dist_on:
@@ -406,7 +437,7 @@ def main():
     dump = os.environ.get("CUT3R_DUMP_STATE")
     if dump:                               # tests: the replicated result of every rank
         k = slam.tracker.t1
-        ii, jj, age = slam.graph.edges_numpy()
+        ii, jj = slam.graph.edges_absolute()
         # (depth of the last keyframe: written by the owner of the last window only until the next window rewrites it)
         np.savez(f"{dump}.rank{rank}.npz", pose=slam.keyframes.pose[:k].numpy(), depth_sum=slam.keyframes.depth[:k - 1].double().sum(dim=(1, 2)).cpu().numpy(),
                  submap_sum=slam.keyframes.submap_ds[:(k - 1) // 5].double().sum(dim=(2, 3, 4)).cpu().numpy(),
@@ -458,6 +489,15 @@ def main():
             "config": "kf_every=10, window_batch=1: the reference's one-window-at-a-time schedule (50 frames of buffering)",
             "frames_per_s": round(16 * l1["frames_per_step"] / l1["elapsed"], 1), "ms_per_window": round(1e3 * l1["elapsed"] / 16, 3), "windows": 16}
         del l1
+        if SEQ > 0:
+            log("operating points: the same schedule over ONE endless stream (covisibility tests against every earlier keyframe)")
+            le = fixed_cadence_leg(model, Cut3rSlam, cdist, dev, WB, args.steps, args.warmup, barrier=barrier, seq_windows=0)
+            op_points["endless_stream"] = {
+                "config": f"kf_every=10, window_batch={WB}, no sequence cuts: one stream of {(args.steps + args.warmup) * le['frames_per_step']} frames; every new keyframe "
+                          "is tested against ALL earlier ones (factor_graph.py:148-197), so the step time grows with the stream",
+                "frames_per_s": round(args.steps * le["frames_per_step"] / le["elapsed"], 1), "ms_per_step": round(1e3 * le["elapsed"] / args.steps, 3),
+                "keyframes_at_end": int(le["slam"].tracker.t1)}
+            del le
         log("operating points: overlap mode (kf_every=-1, skip=5, thresh=0.9)")
         op_points["overlap_mode"] = overlap_mode_leg(model, Cut3rSlam, dev)
     if single and not args.no_trajectory_parity:
@@ -474,14 +514,17 @@ def main():
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"BUFFERED FIXED-CADENCE mode: Replica-shaped 640x480 stream -> 384x512 tracking res; kf_every=10; step = {WB} window(s) "
+            "config": {"workload": f"BUFFERED FIXED-CADENCE mode: Replica-shaped 640x480 sequences -> 384x512 tracking res; kf_every=10; "
+                                   + (f"a sequence = {SEQ} windows = {SEQ * 50} frames (Replica room0: 2000 frames, x{world} GPUs), sequences follow each other without "
+                                      "a gap (the last keyframe of one is keyframe 0 of the next: initialisation window, empty graph); " if SEQ > 0 else "ONE endless stream; ")
+                                   + f"step = {WB} window(s) "
                                    f"= {frames_per_step} frames ({frames_per_step} frames of buffering): each new keyframe through the ViT-L encoder once (batched), "
                                    "6-view recurrent decoder + DPT head per window (windows batched through the decoder), "
                                    "log-depth/pose chaining + covisibility-graph update per keyframe; "
                                    "ViT-L/24 enc, 768/12 dual decoder, DPT head, random init; GS backend off; the reference's own "
                                    "schedules (one window at a time; overlap mode) are in `operating_points`"
                                    + (" [DEBUG --small]" if args.small else ""),
-                       "frames_per_step": frames_per_step, "window_views": 6, "window_batch": WB, "parallelism": f"window-sharded x{world}"},
+                       "frames_per_step": frames_per_step, "window_views": 6, "window_batch": WB, "sequence_windows": SEQ, "parallelism": f"window-sharded x{world}"},
             "roofline": roofline, "cpu_baseline": cpu_base, "operating_points": op_points, "trajectory_parity": traj,
             "ate_rmse_m": (traj or {}).get("fixed_cadence_kf_every_2", {}).get("ate_rmse_m"),
             "build_s": round(t_build, 1), "git_sha": git_sha(),

@@ -74,6 +74,7 @@ class FactorGraph:
         self._epoch = 0
         self._eset = set()
         self._cache = None
+        self.base, self.closed = 0, []                  # sequence cuts (begin_sequence); base 0 and no cut = the reference's graph
         self.backend = backend if backend is not None else HipOverlapBackend(device)
 
     @property
@@ -138,6 +139,25 @@ class FactorGraph:
 
     def clear_edges(self):
         self.rm_factors(np.ones(len(self._ii), bool))
+
+    def begin_sequence(self, base):
+        """Throughput drivers that cut one long stream into consecutive sequences (TrackFrontend.sequence_windows): the edges of the
+        finished sequence are archived with ABSOLUTE keyframe indices and the graph starts empty; from here on this graph's indices
+        are relative to keyframe `base` (the cut keyframe = index 0 of the new sequence)."""
+        ii, jj, age = self.edges_numpy()
+        self.closed.append((self.base, ii + self.base, jj + self.base, age))
+        self._ii, self._jj, self._born = [], [], []
+        self._eset = set()
+        self._epoch = 0
+        self._cache = None
+        self.base = int(base)
+
+    def edges_absolute(self):
+        """(ii, jj) of every sequence so far, absolute keyframe indices, in insertion order"""
+        ii, jj, _ = self.edges_numpy()
+        parts_i = [c[1] for c in self.closed] + [ii + self.base]
+        parts_j = [c[2] for c in self.closed] + [jj + self.base]
+        return np.concatenate(parts_i), np.concatenate(parts_j)
 
     def add_neighborhood_factors(self, t0, t1, r=3):
         """factor_graph.py:109-117 (row-major meshgrid order)."""

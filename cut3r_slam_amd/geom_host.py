@@ -89,11 +89,12 @@ def compose_chain(A: np.ndarray, s, rel: np.ndarray) -> np.ndarray:
     return out
 
 
-def chain_windows(encs: np.ndarray, scales_fn, pose_t0: np.ndarray):
+def chain_windows(encs: np.ndarray, scales_fn, pose_t0: np.ndarray, reset=None):
     """Host scan over consecutive windows (multi-GPU replay): encs [n,V,7] raw pose encodings (t, q_wxyz); scales_fn(k) -> the
     window's fp32 scale (called in order); pose_t0 [7] the stored pose (t, q_xyzw) of the first window's first keyframe.
     Sequential work per window: ONE pose composition and ONE matrix->quaternion conversion (the shared keyframe); everything else
-    is batched over all n*V views.  Returns (chained [n,V,4,4], scales [n] fp32, pose_vecs [n,V,7], w2c_rows [n,V,12])."""
+    is batched over all n*V views.  reset[k] true: window k starts a new sequence (TrackFrontend.sequence_windows): it is chained to
+    the identity pose (scales_fn returns 1 for it).  Returns (chained [n,V,4,4], scales [n] fp32, pose_vecs [n,V,7], w2c_rows [n,V,12])."""
     encs = np.asarray(encs, np.float32)
     n, V = encs.shape[:2]
     poses = pose_encoding_to_camera(encs.reshape(-1, 7)).reshape(n, V, 4, 4)
@@ -108,6 +109,8 @@ def chain_windows(encs: np.ndarray, scales_fn, pose_t0: np.ndarray):
     prev = [float(np.float32(v)) for v in np.asarray(pose_t0, np.float64).reshape(7)]
     relv = rel[:, V - 1].astype(np.float64).tolist()
     for k in range(n):
+        if reset is not None and reset[k]:
+            prev = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]
         x, y, z, w = prev[3:]
         nq = math.sqrt(x * x + y * y + z * z + w * w)
         x, y, z, w = x / nq, y / nq, z / nq, w / nq

@@ -13,8 +13,28 @@ import torch
 from . import geom_host as gh
 
 
+class _FeatValid:
+    """`feat_valid[i]`: does the feature store hold keyframe i?  Full store: one flag per keyframe; ring: row tags."""
+
+    def __init__(self, buffer, rows):
+        self.rows = rows
+        self.flags = [False] * buffer if not rows else None
+        self.tags = [-1] * rows if rows else None
+
+    def __getitem__(self, i):
+        return self.flags[i] if self.flags is not None else self.tags[i % self.rows] == i
+
+    def __setitem__(self, i, v):
+        if self.flags is not None:
+            self.flags[i] = bool(v)
+        elif v:
+            self.tags[i % self.rows] = i
+        elif self.tags[i % self.rows] == i:
+            self.tags[i % self.rows] = -1
+
+
 class KeyFrame:
-    def __init__(self, config, image_size, buffer, downsample_ratio, device="cuda:0", feat_dim=1024, patch=16):
+    def __init__(self, config, image_size, buffer, downsample_ratio, device="cuda:0", feat_dim=1024, patch=16, feat_buffer=0):
         self.ht = ht = int(image_size[0])
         self.wd = wd = int(image_size[1])
         self.buffer = int(buffer)
@@ -35,9 +55,43 @@ class KeyFrame:
         self.conf_ds = torch.zeros(nsub, 6, ht // ds, wd // ds, device=dev, dtype=torch.float)
         self.depth = torch.ones(buffer, ht, wd, device=dev, dtype=torch.float)
         n = (ht // patch) * (wd // patch)
-        self.featI = torch.zeros(buffer, n, feat_dim, dtype=torch.float, device=dev)
-        self.pos = torch.zeros(buffer, n, 2, dtype=torch.int64, device=dev)
-        self.feat_valid = [False] * buffer            # host flags: featI[i] holds the encoder features of keyframe i
+        # encoder features: one row per keyframe like the reference (keyframe.py:36) -- or, for throughput drivers that only ever
+        # need the features of the windows in flight (no loop closure), a RING of `feat_buffer` rows: keyframe i lives in row
+        # i % feat_buffer, rows 0..5 are mirrored behind the end so that any 6-keyframe window is one contiguous slice
+        self.feat_rows = int(feat_buffer) if 0 < int(feat_buffer) < buffer else 0
+        self.featI = torch.zeros(self.feat_rows + 6 if self.feat_rows else buffer, n, feat_dim, dtype=torch.float, device=dev)
+        self.pos = torch.zeros(buffer if not self.feat_rows else 1, n, 2, dtype=torch.int64, device=dev)
+        self.feat_valid = _FeatValid(buffer, self.feat_rows)   # host flags: the store holds the encoder features of keyframe i
+
+    def feat_store(self, a: int, b: int, feats) -> None:
+        """features of keyframes a..b-1 (one batch of the encoder) into the store"""
+        R = self.feat_rows
+        if not R:
+            self.featI[a:b] = feats
+        else:
+            if b - a > R:
+                raise ValueError("feature ring smaller than one encoder batch")
+            i = a
+            while i < b:                                   # contiguous pieces up to the wrap
+                r = i % R
+                m = min(b - i, R - r)
+                self.featI[r:r + m] = feats[i - a:i - a + m]
+                if r < 6:                                  # mirror of rows 0..5
+                    k = min(m, 6 - r)
+                    self.featI[R + r:R + r + k] = feats[i - a:i - a + k]
+                i += m
+        for i in range(a, b):
+            self.feat_valid[i] = True
+
+    def feat_slice(self, t0: int, t1: int):
+        """features of keyframes t0..t1-1 (at most 6 in ring mode) as one contiguous slice"""
+        R = self.feat_rows
+        if not R:
+            return self.featI[t0:t1]
+        if t1 - t0 > 6:
+            raise ValueError("feature ring: windows of at most 6 keyframes")
+        r = t0 % R
+        return self.featI[r:r + (t1 - t0)]
 
     # the reference exposes an mp.Value; single-process here, same `.counter.value` spelling
     class _Counter:
@@ -98,7 +152,6 @@ class KeyFrame:
         else:
             self.intrinsic[i] = self.intrinsic[0].clone()
         if feat is not None:
-            self.featI[i].copy_(feat)
-            self.feat_valid[i] = True
-        if pos is not None:
+            self.feat_store(i, i + 1, feat[None] if feat.dim() == 2 else feat)
+        if pos is not None and not self.feat_rows:
             self.pos[i].copy_(pos.reshape(self.pos[i].shape))

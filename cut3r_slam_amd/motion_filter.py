@@ -83,7 +83,7 @@ class MotionFilter:
             forced[0] = True
             feat_last = feats[0]
         else:
-            feat_last = kf.featI[kf.counter.value - 1]
+            feat_last = kf.feat_slice(kf.counter.value - 1, kf.counter.value)[0]
         need = (B + 1) * (N - 1) * C + N
         if self._chain_ws is None or self._chain_ws[0].numel() < need or self._chain_ws[1].numel() < 2 * B + 1:
             self._chain_ws = (torch.empty(need, device=self.device), torch.zeros(2 * B + 1, dtype=torch.int32, device=self.device))
@@ -134,7 +134,7 @@ class MotionFilter:
                     kf.append(tstamp, image[0], pose, None, depth, None, intrinsics, feat1, self._pos_grid)
                 self._consume(tstamp, took)
                 return took
-            feat0 = kf.featI[kf.counter.value - 1]
+            feat0 = kf.feat_slice(kf.counter.value - 1, kf.counter.value)[0]
             feat1, pos1 = self.encode(image[:1])
             overlap_ratio = self.last_ratio = self.overlap_ratio(feat0, feat1)
         elif not compute_overlap and tstamp % self.kf_every == 0:

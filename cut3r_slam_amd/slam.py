@@ -26,7 +26,7 @@ DEFAULT_CONFIG = {
 
 
 class Cut3rSlam:
-    def __init__(self, model, config=None, image_size=(384, 512), buffer=512, device="cuda:0"):
+    def __init__(self, model, config=None, image_size=(384, 512), buffer=512, device="cuda:0", feat_buffer=0):
         self.model = model
         self.config = config or DEFAULT_CONFIG
         self.device = device
@@ -35,7 +35,7 @@ class Cut3rSlam:
         self.use_gt = False
         self.downsample_ratio = 2
         self.keyframes = KeyFrame(self.config, image_size, buffer, self.downsample_ratio, device,
-                                  feat_dim=model.cfg.enc_embed_dim, patch=model.cfg.patch_size)
+                                  feat_dim=model.cfg.enc_embed_dim, patch=model.cfg.patch_size, feat_buffer=feat_buffer)
         self.graph = FactorGraph(self.keyframes, device=device, max_factors=48)
         self.filterx = MotionFilter(model, self.keyframes, self.config["Tracking"]["motion_filter"], device)
         self.tracker = TrackFrontend(self, self.keyframes, self.config["Tracking"]["frontend"], device)

@@ -53,6 +53,8 @@ class TrackBackend:
         cameras) + 0.2 * patch-feature overlap (compute_feature_overlap_batch, :328-341).  Returned on the host."""
         kf = self.keyframes
         h, w = kf.submap_ds.shape[2], kf.submap_ds.shape[3]
+        if kf.feat_rows:
+            raise RuntimeError("loop closure needs the full keyframe feature store (KeyFrame feat_buffer = 0)")
         ids = torch.as_tensor(np.asarray(ids_matched), dtype=torch.long)
         pm_matched = kf.submap_ds[ids // 5, ids % 5].contiguous()                       # [B,h,w,3]
         pm_cur = kf.submap_ds[idx_current // 5, idx_current % 5].contiguous()

@@ -56,6 +56,13 @@ class TrackFrontend:
         # keyframes and push them through the decoder TOGETHER (windows are independent network evaluations; the chaining
         # below stays sequential).  Trades latency (window_batch*5 keyframes) for MFMA-bound decoder GEMMs.
         self.window_batch = int(config.get("window_batch", 1))
+        # throughput knob (not in the reference, default 0 = one endless sequence): cut the stream into consecutive SEQUENCES of
+        # `sequence_windows` windows.  The cut keyframe (view 0 of the first window of a sequence = last keyframe of the previous
+        # one) becomes keyframe 0 of a new run: that window is handled exactly like the reference's initialisation window
+        # (track_frontend.py:181-200: no chaining, scale 1), the covisibility graph starts empty and the overlap tests only see
+        # the keyframes of the current sequence -- the results of a sequence equal a fresh run over its frames (tested).  A
+        # Replica-shaped 2000-frame sequence at kf_every = 10 is 40 windows.
+        self.sequence_windows = int(config.get("sequence_windows", 0))
         self._lsum = torch.zeros(1, dtype=torch.float64, device=device)     # kept at 0 between windows (window_update resets it)
         self._lsum_host = torch.zeros(1, dtype=torch.float64).pin_memory()
         self._counts = None
@@ -84,11 +91,9 @@ class TrackFrontend:
             feats = self.model.encode_batch(imgs)
             o = 0
             for a, b in runs:
-                kf.featI[a:b] = feats[o:o + b - a]
+                kf.feat_store(a, b, feats[o:o + b - a])
                 o += b - a
-            for i in missing:
-                kf.feat_valid[i] = True
-        return kf.featI[t0:t1]
+        return kf.feat_slice(t0, t1) if (not kf.feat_rows or t1 - t0 <= 6) else None
 
     def infer(self, imgs_u8=None, t0=None, t1=None):
         """model outputs consumed by SLAM (track_frontend.py:81-100 keeps only these three)."""
@@ -137,10 +142,20 @@ class TrackFrontend:
             outputs = self.infer(t0=t0, t1=t1)
         self.track_many([(t0, t1)], [outputs], init=init)
 
-    def _decide(self, t0, t1, init, done):
+    def seq_base(self, t0):
+        """first keyframe of the sequence the window starting at keyframe t0 belongs to (0 without sequence cuts)"""
+        S = 5 * self.sequence_windows
+        return (t0 // S) * S if S > 0 else 0
+
+    def _decide(self, t0, t1, init, done, base=0):
         """decision half of a window, in the reference's order: neighbourhood factors of keyframe i, then its overlap
-        factors (track_frontend.py:246-261 -> factor_graph.py:109-117, 170-197).  Host only."""
+        factors (track_frontend.py:246-261 -> factor_graph.py:109-117, 170-197).  Host only.  t0, t1 and the tickets are
+        relative to `base`, the first keyframe of the window's sequence."""
         graph = self.graph
+        if init:
+            if base != graph.base:
+                graph.begin_sequence(base)
+            graph.add_neighborhood_factors(0, 3, r=3)
         for i in range(t0, t1):
             if not init:
                 graph.add_neighborhood_factors(i - 3, i + 1, r=3)
@@ -180,21 +195,21 @@ class TrackFrontend:
         all_counts = torch.zeros(len(ranges), 6, 2, L, dtype=torch.int32) if exchange is not None else None
         if self._ev is None:
             self._ev = torch.cuda.Event()
-        if init:
-            graph.add_neighborhood_factors(0, 3, r=3)
-        pending = None                    # (t0, t1, init, done) of the previous window: its decisions are still to be made
+        pending = None                    # (t0, t1, init, done, base) of the previous window: its decisions are still to be made
         lsum_next = None                  # log-depth sum of the coming window when the previous round trip brought it back
         h, w = kf.submap_ds.shape[2:4]
         for k, ((t0, t1), (pts, conf, pose_enc)) in enumerate(zip(ranges, outputs)):
             V, H, W, _ = pts.shape
-            if k == 0 and first_event is not None and not init:
+            b0 = self.seq_base(t0)                      # first keyframe of this window's sequence
+            init_k = init or (b0 == t0 and t0 > 0)      # a cut: this window starts a sequence like an initialisation window
+            if k == 0 and first_event is not None and not init_k:
                 tic = time.perf_counter()
                 first_event.synchronize()                                 # issued by prefetch_logdepth before the network pass
                 lsum_next = float(self._lsum_host[0])
                 TIMING["sync1_s"] += time.perf_counter() - tic
             if pose_enc.is_cuda and lsum_next is None:
                 self._pose_host[:V].copy_(pose_enc.detach(), non_blocking=True)
-            if not init and lsum_next is None:
+            if not init_k and lsum_next is None:
                 tic = time.perf_counter()
                 ops.logdepth_accum(kf.depth[t0], pts[0], self._lsum)     # window k's view 0 == previous window's last KF
                 self._lsum_host.copy_(self._lsum, non_blocking=True)
@@ -202,7 +217,7 @@ class TrackFrontend:
                 self._ev.synchronize()                                    # extra round trip: first window of a call only
                 lsum_next = float(self._lsum_host[0])
                 TIMING["sync1_s"] += time.perf_counter() - tic
-            elif init and pose_enc.is_cuda:
+            elif init_k and pose_enc.is_cuda and lsum_next is None:
                 self._ev.record()
                 self._ev.synchronize()
             host = (self._pose_host[:V] if pose_enc.is_cuda else pose_enc).numpy().copy()
@@ -211,23 +226,24 @@ class TrackFrontend:
             first_w2c = gh.inv4(poses[0])
             sub_num = t0 // 5
             align = None
-            if not init:
+            if not init_k:
                 align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
                 prev_c2w = gh.pose_vec_to_matrix(kf.pose[t0].numpy()[None])[0]
                 align = (prev_c2w[:3, :3], prev_c2w[:3, 3], align_s)
             # host: chained pose of every view, one vectorised matrix->quaternion conversion (the reference converts and
             # stores per keyframe, track_frontend.py:236-245); the world->camera rows travel as kernel arguments
-            if init:
+            if init_k:
                 chained, s_win = [gh.chain_pose(first_w2c, poses[v]) for v in range(V)], np.float32(1.0)
             else:
                 chained, s_win = [gh.chain_pose(first_w2c, poses[v], *align) for v in range(V)], align[2]
             w2c_rows = kf.set_poses(t0, gh.matrices_to_pose_vecs(np.stack(chained)), upload=False)
-            centres = kf.pose[:t1, :3].numpy()                              # zero-copy view of the host pose table
+            centres = kf.pose[b0:t1, :3].numpy()                            # zero-copy view of the host pose table
             # device: ONE fused call stores every view (downsampled chained pointmap, confidence, depth) and counts the
             # forward / backward overlaps of every keyframe of the window (the reference re-uploads all previous pointmaps
-            # and reads ratios back per keyframe, track_frontend.py:248-259)
-            if self._counts is None or self._counts.shape[-1] < t1:
-                self._counts = torch.zeros(6, 2, max(256, 2 * t1), dtype=torch.int32, device=self.device)
+            # and reads ratios back per keyframe, track_frontend.py:248-259).  Indices are relative to the sequence's first
+            # keyframe b0 (a multiple of 5: submap slots stay aligned): the tests see the cameras / pointmaps b0..i-1
+            if self._counts is None or self._counts.shape[-1] < t1 - b0:
+                self._counts = torch.zeros(6, 2, max(256, 2 * (t1 - b0)), dtype=torch.int32, device=self.device)
                 self._counts_host = torch.zeros(6, 2, self._counts.shape[-1], dtype=torch.int32).pin_memory()
             intr = kf.intrinsic[t0:t1].numpy()
             # one call per run of keyframes with equal intrinsics (a sequence has ONE calibration: normally one call)
@@ -240,12 +256,12 @@ class TrackFrontend:
             counting = count_mask is None or bool(count_mask[k])
             for (a, b) in groups:
                 ops.window_update(pts[a:b], conf[a:b], np.concatenate([c[:3, :4].reshape(-1) for c in chained[a:b]]), float(s_win), ds,
-                                  kf.submap_ds[sub_num, a:b], kf.conf_ds[sub_num, a:b], kf.depth[t0 + a:t0 + b], kf.submap_ds, kf.w2c,
-                                  t0 + a, 3 if counting else (1 << 30), [float(x) for x in intr[a]], self._counts[a:b],
+                                  kf.submap_ds[sub_num, a:b], kf.conf_ds[sub_num, a:b], kf.depth[t0 + a:t0 + b], kf.submap_ds[b0 // 5:],
+                                  kf.w2c[b0:], t0 + a - b0, 3 if counting else (1 << 30), [float(x) for x in intr[a]], self._counts[a:b],
                                   w2c_new=w2c_rows[a:b].reshape(-1), lsum_reset=self._lsum)
             if counting:
                 self._counts_host[:V].copy_(self._counts[:V], non_blocking=True)
-            prefetch = (not init) and k + 1 < len(ranges)
+            prefetch = k + 1 < len(ranges)
             if prefetch:                 # the next window's log-depth sum (and poses) ride on the same round trip
                 nt0, (npts, _, npose) = ranges[k + 1][0], outputs[k + 1]
                 ops.logdepth_accum(kf.depth[nt0], npts[0], self._lsum)
@@ -255,36 +271,38 @@ class TrackFrontend:
             self._ev.record()
             if pending is not None:      # host-only decisions of the previous window while the device works on this one
                 self._decide(*pending)
+                pending = None
             self._ev.synchronize()                                        # THE round trip of the window
             TIMING["sync2_s"] += time.perf_counter() - tic
             TIMING["windows"] += 1
             if prefetch:
                 lsum_next = float(self._lsum_host[0])
+            r0, r1 = t0 - b0, t1 - b0                                     # the window in its sequence's own numbering
             if deferred is not None:
                 if counting:
-                    all_counts[k, :V, :, :t1] = self._counts_host[:V, :, :t1]
-                deferred.append((t0, t1, groups, centres[:t1].copy(), H * W))
+                    all_counts[k, :V, :, :r1] = self._counts_host[:V, :, :r1]
+                deferred.append((r0, r1, groups, centres[:r1].copy(), H * W, init_k, b0))
                 continue
             done = {}
             host_counts = self._counts_host.numpy()
             for (a, b) in groups:
-                if t0 + b - 1 >= 3:
-                    for tk, cf, cb in graph.window_tickets(t0 + a, t0 + b, centres, host_counts[a:b], H * W, h * w):
+                if r0 + b - 1 >= 3:
+                    for tk, cf, cb in graph.window_tickets(r0 + a, r0 + b, centres, host_counts[a:b], H * W, h * w):
                         done[tk["idx"]] = (tk, cf.copy(), cb.copy())
-            pending = (t0, t1, init, done)
+            pending = (r0, r1, init_k, done, b0)
         if pending is not None:
             self._decide(*pending)
         if deferred is not None:
             total = exchange(all_counts).numpy()
 
             def finish():
-                for k, (t0, t1, groups, centres, npix) in enumerate(deferred):
+                for k, (r0, r1, groups, centres, npix, init_k, b0) in enumerate(deferred):
                     done = {}
                     for (a, b) in groups:
-                        if t0 + b - 1 >= 3:
-                            for tk, cf, cb in graph.window_tickets(t0 + a, t0 + b, centres, total[k, a:b], npix, h * w):
+                        if r0 + b - 1 >= 3:
+                            for tk, cf, cb in graph.window_tickets(r0 + a, r0 + b, centres, total[k, a:b], npix, h * w):
                                 done[tk["idx"]] = (tk, cf.copy(), cb.copy())
-                    self._decide(t0, t1, init, done)
+                    self._decide(r0, r1, init_k, done, b0)
             if defer_decisions:
                 return finish
             finish()
@@ -342,16 +360,24 @@ class TrackFrontend:
             raise NotImplementedError("sharded tracking: windows of equal length")
         scal = np.asarray(scal, np.float64)
 
+        bases = [self.seq_base(t0) for t0, _ in ranges]
+        cut = [b0 == t0 and t0 > 0 for b0, (t0, _) in zip(bases, ranges)]      # window starts a new sequence: identity pose, scale 1
+
         def scale_of(k):
+            if cut[k]:
+                chain["log_s"], chain["L5"] = 0.0, float(scal[k, 1])
+                return np.float32(1.0)
             lsum = chain["log_s"] * (H * W) + chain["L5"] - float(scal[k, 0])
             align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
             chain["log_s"], chain["L5"] = math.log(float(align_s)), float(scal[k, 1])
             return align_s
 
         encs = scal[:, 2:2 + 7 * V].reshape(n, V, 7).astype(np.float32)
-        chained_all, s_all, vecs, rows_all = gh.chain_windows(encs, scale_of, kf.pose[ranges[0][0]].numpy())
+        chained_all, s_all, vecs, rows_all = gh.chain_windows(encs, scale_of, kf.pose[ranges[0][0]].numpy(), reset=cut)
+        cent = []
         for k, (t0, t1) in enumerate(ranges):                 # later windows overwrite the shared keyframe, as track() does
             kf.pose[t0:t1] = torch.from_numpy(vecs[k])
+            cent.append(kf.pose[bases[k]:t1, :3].numpy().copy())      # camera centres of the window's sequence as track() sees them
         per = [(chained_all[k], s_all[k], rows_all[k]) for k in range(n)]
         # device mirror of every new world->camera row (other ranks' windows included: the forward counts need all cameras)
         ta, tb = ranges[0][0], ranges[-1][1]
@@ -376,9 +402,9 @@ class TrackFrontend:
             intr = intr_all[t0 - ta:t1 - ta]
             if not all(np.array_equal(intr[v], intr[0]) for v in range(V)):
                 raise NotImplementedError("sharded tracking assumes one calibration per window")
-            sub = t0 // 5
+            sub, b0 = t0 // 5, bases[k]
             ops.window_update(pts, conf, np.concatenate([c[:3, :4].reshape(-1) for c in chained]), float(s_win), ds,
-                              kf.submap_ds[sub, :V], kf.conf_ds[sub, :V], kf.depth[t0:t1], kf.submap_ds, kf.w2c, t0,
+                              kf.submap_ds[sub, :V], kf.conf_ds[sub, :V], kf.depth[t0:t1], kf.submap_ds[b0 // 5:], kf.w2c[b0:], t0 - b0,
                               3 if counting else (1 << 30), [float(x) for x in intr[0]], self._counts_many[k - i0, :V], w2c_new=rows.reshape(-1))
 
         # ---- phase A: align + store the own windows; phase B: complete the stores; phase C: count for the own windows
@@ -399,17 +425,18 @@ class TrackFrontend:
         self._ev.synchronize()                                    # THE round trip of the step's replay
         for k in range(i0, i1):
             t0, t1 = ranges[k]
-            all_counts[k, :t1 - t0, :, :t1] = self._counts_many_host[k - i0, :t1 - t0, :, :t1]
+            all_counts[k, :t1 - t0, :, :t1 - bases[k]] = self._counts_many_host[k - i0, :t1 - t0, :, :t1 - bases[k]]
         total = exchange_counts(all_counts).numpy()
-        centres = kf.pose[:tb, :3].numpy()
 
         def finish():
             for k, (t0, t1) in enumerate(ranges):
+                b0 = bases[k]
+                r0, r1 = t0 - b0, t1 - b0
                 done = {}
-                if t1 - 1 >= 3:
-                    for tk, cf, cb in graph.window_tickets(t0, t1, centres, total[k, :t1 - t0], H * W, h * w):
+                if r1 - 1 >= 3:
+                    for tk, cf, cb in graph.window_tickets(r0, r1, cent[k], total[k, :t1 - t0], H * W, h * w):
                         done[tk["idx"]] = (tk, cf.copy(), cb.copy())
-                self._decide(t0, t1, False, done)
+                self._decide(r0, r1, cut[k], done, b0)
         if defer_decisions:
             return finish
         finish()

@@ -31,14 +31,16 @@ def _run(cmd, env, timeout=900):
 
 
 def test_two_ranks_on_one_gpu_match_each_other_and_a_single_rank(tmp_path):
+    # sequence cuts every 6 windows of the job (--sequence-windows is per GPU): windows 6 and 12 of the 13 start new sequences, one
+    # as the first window of a rank's batch, one inside it
     common = ["--small", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
     two = str(tmp_path / "two")
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--window-batch", "2"] + common,
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--window-batch", "2", "--sequence-windows", "3"] + common,
                {"CUT3R_DIST_BACKEND": "gloo", "CUT3R_DUMP_STATE": two, "CUT3R_REPLICATE_DEPTH": "1"})
     assert '"n_gpus": 2' in out
     one = str(tmp_path / "one")
-    _run([sys.executable, "bench.py", "--window-batch", "4"] + common, {"CUT3R_DUMP_STATE": one})
+    _run([sys.executable, "bench.py", "--window-batch", "4", "--sequence-windows", "6"] + common, {"CUT3R_DUMP_STATE": one})
     r0, r1, s = np.load(two + ".rank0.npz"), np.load(two + ".rank1.npz"), np.load(one + ".rank0.npz")
     assert int(r0["k"]) == int(r1["k"]) == int(s["k"]) == 6 + 5 * 4 * 3            # 3 steps of 4 windows
     for key in ("pose", "w2c", "depth_sum", "submap_sum", "ii", "jj"):
@@ -51,7 +53,7 @@ def test_two_ranks_on_one_gpu_match_each_other_and_a_single_rank(tmp_path):
     assert len(r0["ii"]) > 100
     # the scan form on ONE rank (CUT3R_SCAN=1) is bit-identical to the two-rank result: same scalars, same host scan
     scan1 = str(tmp_path / "scan1")
-    _run([sys.executable, "bench.py", "--window-batch", "4"] + common, {"CUT3R_DUMP_STATE": scan1, "CUT3R_SCAN": "1"})
+    _run([sys.executable, "bench.py", "--window-batch", "4", "--sequence-windows", "6"] + common, {"CUT3R_DUMP_STATE": scan1, "CUT3R_SCAN": "1"})
     c = np.load(scan1 + ".rank0.npz")
     for key in ("pose", "w2c", "depth_sum", "submap_sum", "ii", "jj"):
         np.testing.assert_array_equal(r0[key], c[key], err_msg="scan, one rank: " + key)

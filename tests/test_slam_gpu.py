@@ -208,6 +208,75 @@ def test_pipelined_driver_equals_the_frame_by_frame_loop():
     np.testing.assert_array_equal(e_got[1], e_ref[1][keep])
 
 
+@pytest.mark.parametrize("driver", ["frame_by_frame_wb2", "pipelined_wb2", "pipelined_scan_wb2"])
+def test_sequence_cuts_equal_fresh_runs(driver):
+    """TrackFrontend.sequence_windows = 3: the stream is cut every 3 windows (15 keyframes); the cut keyframe starts a new
+    sequence whose first window is an initialisation window, with an empty covisibility graph and overlap tests that only see
+    the sequence's own keyframes.  Every sequence must equal a FRESH Cut3rSlam run over the frames from its cut keyframe on:
+    poses, depths, stride-2 stores, ordered edge lists (relative numbering).  Cuts fall on the first and on the second window
+    of a decoder batch; the pipelined driver is checked in both replay forms."""
+    from cut3r_slam_amd import dist as cdist
+    kf_every, S, nseq = 2, 3, 3
+    per = 5 * S                                               # keyframes per sequence (the cut keyframe is shared)
+    n = 2 * (per * nseq + 1 + 6) + 12
+    frames = _frames(n, seed=7).to(DEV)
+    intr = torch.tensor([40.0, 40.0, 23.5, 15.5])
+    fe = {"iteration": 0, "sequence_windows": S}
+    cfgd = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 1, "kf_every": kf_every}, "frontend": dict(fe)}}
+    if driver == "frame_by_frame_wb2":
+        cfgd["Tracking"]["frontend"]["window_batch"] = 2
+        slam = Cut3rSlam(_model(), cfgd, (H, W), buffer=80, device=DEV)
+        for t in range(n):
+            slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+            if slam.tracker.t1 >= per * nseq + 1:
+                break
+    else:
+        slam = Cut3rSlam(_model(), cfgd, (H, W), buffer=80, device=DEV)
+        t = 0
+        while not slam.keyframes.is_initialized:
+            slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+            t += 1
+        runner = cdist.ShardedTracker(slam, 1, 0, wb=2, pipelined=True)
+        runner.scan = driver == "pipelined_scan_wb2"
+        for _ in range(4):
+            t = runner.step(frames, t, kf_every, 5, intr)
+        runner.flush()
+    torch.cuda.synchronize()
+    k = slam.tracker.t1
+    assert k >= per * (nseq - 1) + 11, k                      # at least two windows into the third sequence
+    kf, g = slam.keyframes, slam.graph
+    assert len(g.closed) == nseq - 1 and g.base == per * (nseq - 1)
+    tol = dict(atol=1e-5) if driver != "pipelined_scan_wb2" else dict(atol=2e-4)      # (scan form: log s + log d vs log(s d))
+    for sq in range(nseq):
+        b0 = per * sq
+        last = min(k, b0 + per + 1) - b0                      # keyframes of this sequence tracked so far (relative end)
+        fresh = Cut3rSlam(_model(), {"Tracking": {"motion_filter": cfgd["Tracking"]["motion_filter"], "frontend": {"iteration": 0}}},
+                          (H, W), buffer=40, device=DEV)
+        t = 0
+        while fresh.tracker.t1 < last and 2 * b0 + t < n:
+            fresh.run(t, frames[2 * b0 + t:2 * b0 + t + 1], intr, frames[2 * b0 + t:2 * b0 + t + 1], intr)
+            t += 1
+        assert fresh.tracker.t1 == last, (sq, fresh.tracker.t1, last)
+        own = last - 1 if (sq < nseq - 1) else last           # the cut keyframe's pose / depth rows belong to the NEXT sequence afterwards
+        np.testing.assert_allclose(kf.pose[b0:b0 + own].numpy(), fresh.keyframes.pose[:own].numpy(), err_msg=f"pose seq {sq}", **tol)
+        np.testing.assert_allclose(kf.depth[b0:b0 + own].cpu().numpy(), fresh.keyframes.depth[:own].cpu().numpy(), rtol=2e-4, atol=2e-5,
+                                   err_msg=f"depth seq {sq}")
+        nsub = (last - 1) // 5
+        np.testing.assert_allclose(kf.submap_ds[b0 // 5:b0 // 5 + nsub].cpu().numpy(), fresh.keyframes.submap_ds[:nsub].cpu().numpy(),
+                                   rtol=2e-4, atol=2e-4 if "scan" in driver else 2e-5, err_msg=f"submaps seq {sq}")
+        if sq < nseq - 1:
+            _, ii, jj, _ = g.closed[sq]
+            ii, jj = ii - b0, jj - b0
+        else:
+            ii, jj, _ = g.edges_numpy()
+        fi, fj, _ = fresh.graph.edges_numpy()
+        np.testing.assert_array_equal(ii, fi, err_msg=f"edges seq {sq}")
+        np.testing.assert_array_equal(jj, fj, err_msg=f"edges seq {sq}")
+        assert len(ii) > 20
+    ai, aj = g.edges_absolute()
+    assert len(ai) == sum(len(c[1]) for c in g.closed) + len(g.edges_numpy()[0]) and ai.max() < k
+
+
 def test_sharded_overlap_counting_two_ranks_in_one_process():
     """Multi-GPU replay (dist.ShardedTracker): every rank chains and stores every window, the overlap counting of a window
     runs only on its owner and the owners' counts are summed before the decisions.  Two trackers play the two ranks here
