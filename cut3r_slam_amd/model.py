@@ -89,6 +89,8 @@ class Cut3rModel:
         # DPT head of view i (all windows) on a third stream while the recurrent decoder works on view i+1: the decoder's
         # mid-size kernels leave matrix and memory pipes idle that the head's large convolutions can use
         self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "1") != "0"
+        # windows per DPT-head pass of a view (the head's convolutions at the coarse pyramid levels have few output tiles)
+        self.head_chunk = max(1, int(_os.environ.get("CUT3R_HEAD_CHUNK", "28")))      # measured at 28 windows: 8 -> 4806, 14 -> 4867, 28 -> 4932 frames/s
         self._head_stream = None
         self._side = None
         self._head_side = None
@@ -744,8 +746,8 @@ class Cut3rModel:
                 cur = torch.cuda.current_stream()
                 self._head_stream.wait_stream(cur)
                 with torch.cuda.stream(self._head_stream):
-                    for c0 in range(0, Wn, 8):
-                        c1 = min(Wn, c0 + 8)
+                    for c0 in range(0, Wn, self.head_chunk):
+                        c1 = min(Wn, c0 + self.head_chunk)
                         nb = c1 - c0
                         tk = []
                         for name, src, dim in (("f", feat16, E), ("t1", tok1, D), ("t2", tok2, D), ("t3", tok3, D)):

@@ -18,7 +18,7 @@ model = Cut3rModel(cfg, synth_state_dict(cfg, 0), dev, minimal=True)
 model.use_graphs = False
 os.environ["CUT3R_DUAL_STREAM"] = "0"
 conf = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "kf_every": 10}, "frontend": {"iteration": 0}}}
-slam = Cut3rSlam(model, conf, (384, 512), buffer=100, device=dev)
+slam = Cut3rSlam(model, conf, (384, 512), buffer=32 + 10 * WB, device=dev)
 runner = cdist.ShardedTracker(slam, 1, 0, wb=WB, pipelined=False)
 frames = synth_frames(runner.frames_needed(2, 10, 5), 384, 512, dev)
 intr = torch.tensor([256.0, 338.8, 255.8, 191.7])
