@@ -6,14 +6,19 @@ Headline `value` (BASELINE configs[1], "Replica room0 640x480: ViT pointmap + fa
 synthetic 640x480 stream -> tracking resolution 384x512 (demo_s.py:69-73), production-shape network (ViT-L encoder, 768-d
 dual decoder, DPT head; seeded random weights -- no checkpoint exists), BUFFERED FIXED-CADENCE mode: kf_every=10
 (hislam2/motion_filter.py:83,109,124; SURVEY 8(d) names it the throughput schedule because its keyframes do not depend on
-feature numerics), `--window-batch` (default 8) tracking windows pushed through the decoder together.  One STEP =
+feature numerics), `--window-batch` (default 28) tracking windows pushed through the decoder together.  One STEP =
 window_batch steady-state windows = window_batch*50 frames: each new keyframe through the encoder once, 6-view recurrent
 decoder + DPT head per window, chaining/alignment + covisibility-graph update per keyframe (hislam2/hi2.py:101-133 without
-the GS mapper).  Frames are resident in HBM before the timed region.  value = frames of all ranks / max-over-ranks time.
+the GS mapper).  The stream is a succession of Replica-shaped SEQUENCES (`--sequence-windows`, default 40 windows = 2000 frames,
+times the number of GPUs): the last keyframe of a sequence is keyframe 0 of the next one, whose first window is handled like the
+reference's initialisation window, with an empty covisibility graph (TrackFrontend.sequence_windows: every sequence equals a
+fresh run over its frames, tests/test_slam_gpu.py).  One resident recording is read cyclically; frames are in HBM before the
+timed region.  value = frames of all ranks / max-over-ranks time.
 
 Beside it, in the same JSON line (rank 0, N = 1):
   operating_points   the reference's own schedules on the same network: fixed cadence with ONE window at a time
-                     (window_batch=1), and the maintained configs' OVERLAP mode (kf_every=-1, skip=5, thresh=0.9,
+                     (window_batch=1), the default batch over ONE endless stream (no sequence cuts: every keyframe is tested
+                     against all earlier ones), and the maintained configs' OVERLAP mode (kf_every=-1, skip=5, thresh=0.9,
                      config/scannet_config.yaml:20-25): encoder + patch-overlap test every 5th frame, one window at a time,
                      through Cut3rSlam.run -- frame by frame, and with the batched look-ahead of the buffered driver
   trajectory_parity  the metric's second half: Cut3rSlam on HIP vs the CPU restatement of the reference loop
@@ -23,8 +28,9 @@ Beside it, in the same JSON line (rank 0, N = 1):
   cpu_baseline       the oracle timed on the host cores on a bounded sample of the same loop
 
 N > 1 (one process per GPU, torch.distributed/RCCL): windows are sharded across ranks (every window re-initialises the
-recurrent state, src/dust3r/model.py:819-822); the consumed outputs are all-gathered over xGMI and the cheap sequential
-chaining + graph update runs replicated.  Per-GPU work is fixed => "scaling": "weak".
+recurrent state, src/dust3r/model.py:819-822); per window 352 bytes of scalars are all-gathered, the chain is a replicated host
+scan, the stride-2 stores are completed by in-place all-gathers and the overlap counts by one all-reduce (cut3r_slam_amd/dist.py).
+Per-GPU work is fixed => "scaling": "weak".
 """
 import argparse
 import json
