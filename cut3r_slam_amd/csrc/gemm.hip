@@ -426,7 +426,7 @@ __global__ CUT3R_TILE_BOUNDS void gemm_pair_kernel(const GemmPairArgs a) {
 #ifndef EPI_UNROLL
 #define EPI_UNROLL 1
 #endif
-template <bool CONV3, bool RELU_IN>
+template <bool CONV3, bool RELU_IN, bool FAST_DMA = false>
 DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     constexpr int UNIT = 128 * BK * 2;      // 16 KiB: 128 rows x 64 halfs
     constexpr int BUF = 4 * UNIT;
@@ -476,9 +476,37 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
         }
 
     const int nt = (K + BK - 1) / BK;
+    // Plain operands with whole K-tiles (every Linear of the network): a DMA piece is ONE instruction with a scalar base (the
+    // K-tile's column of A or W, advanced on the scalar unit) and a per-lane 32-bit byte offset computed once -- no per-piece
+    // vector address arithmetic in the loop.  (Timed with s_memtime: the load segments of a K-tile, not its MFMAs, set the pace of
+    // the two wave groups; a piece with 64-bit per-lane addresses, two selects and a readfirstlane costs ~70 cycles of wave time.)
+    // Rows beyond M / N read the last valid row instead of zeros: those accumulators are never stored.
+    // (FAST_DMA is chosen at launch: gemm256_fast_ok)
+    constexpr bool fast_dma = FAST_DMA && !CONV3;
+    unsigned a_off[2][2], b_off[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int u = (wave + 8 * i) * 8 + lrow;
+            const int gm = min(m0 + (u >> 6) * 128 + q * 64 + (u & 63), M - 1);
+            const int gn = min(n0 + (u >> 5) * 64 + q * 32 + (u & 31), N - 1);
+            a_off[q][i] = (unsigned)(((size_t)gm * g.lda + csrc * 8) * 2);
+            b_off[q][i] = (unsigned)(((size_t)gn * g.ldb + csrc * 8) * 2);
+        }
+    auto issue_fast = [&](const h16* mat, const unsigned (&off)[2], int kt, int unit) {
+        const char* base = reinterpret_cast<const char*>(mat) + (size_t)kt * (BK * 2);       // wave-uniform
+        unsigned char* slot = smem + (kt & 1) * BUF + unit * UNIT;
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);        // (scalar: the LDS destination goes to M0)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + (wave_s + 8 * i) * 1024), 16, 0, 0);
+    };
     // unit U of K-tile kt -> LDS-DMA (skipped past the last tile; the vmcnt below accounts for that)
     auto issue_a = [&](int q, int kt, int unit) {
         if (kt >= nt) return;
+        if constexpr (fast_dma) { issue_fast(A, a_off[q], kt, unit); return; }
         unsigned char* slot = smem + (kt & 1) * BUF + unit * UNIT;
         const int k = kt * BK + csrc * 8;
         const bool kok = k < K;
@@ -504,6 +532,7 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     };
     auto issue_b = [&](int q, int kt, int unit) {
         if (kt >= nt) return;
+        if constexpr (fast_dma) { issue_fast(Bm, b_off[q], kt, unit); return; }
         unsigned char* slot = smem + (kt & 1) * BUF + unit * UNIT;
         const int k = kt * BK + csrc * 8;
         const bool kok = k < K;
@@ -555,6 +584,46 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
         __builtin_amdgcn_s_setprio(0);                                                                           \
     } while (0)
 
+#ifndef CUT3R_G256_PHASES
+#define CUT3R_G256_PHASES 2
+#endif
+#if CUT3R_G256_PHASES == 2
+    // ---- TWO phases per K-tile (one per 64-row half of the wave's 128 rows): phase A reads A-half 0 (U0) and both B halves (U1, U2)
+    // and runs 32 MFMAs, phase B reads A-half 1 (U3) and runs the other 32 -- four barriers per K-tile, 32 MFMAs per barrier pair.
+    // A slot is refilled as soon as both wave groups have read it: U0..U2 of K-tile t+2 go into the CURRENT buffer during phase B
+    // (they were last read in phase A, by the lagging group one barrier later), U3 of K-tile t+1 into the other buffer during
+    // phase A.  In flight behind the unit a phase needs: 4 units = 8 DMA instructions per wave (one counted wait per phase).
+    issue_a(0, 0, 0); issue_b(0, 0, 1); issue_b(1, 0, 2); issue_a(1, 0, 3);
+    issue_a(0, 1, 0); issue_b(0, 1, 1); issue_b(1, 1, 2);
+    if (nt > 1) wait_vmcnt<6>(); else wait_vmcnt<0>();
+    CUT3R_BARRIER();
+    if (wr == 1) CUT3R_BARRIER();          // stagger: the second wave group runs one barrier behind the first
+
+    for (int t = 0; t < nt; t++) {
+        const unsigned char* buf = smem + (t & 1) * BUF;
+        // phase A: rows 0..63 of the wave tile
+        read_a(buf);
+        read_b(buf + UNIT, fb0);
+        read_b(buf + 2 * UNIT, fb1);
+        issue_a(1, t + 1, 3);
+        if (t + 1 < nt) wait_vmcnt<8>(); else wait_vmcnt<0>();      // U3 of K-tile t has landed
+        // this phase's fragments are in registers before the barrier: the other group refills these slots right after it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CUT3R_BARRIER();
+        CUT3R_QUADRANT(0, 0, fb0);
+        CUT3R_QUADRANT(0, 2, fb1);
+        CUT3R_BARRIER();
+        // phase B: rows 64..127
+        read_a(buf + 3 * UNIT);
+        issue_a(0, t + 2, 0); issue_b(0, t + 2, 1); issue_b(1, t + 2, 2);
+        if (t + 2 < nt) wait_vmcnt<8>(); else if (t + 1 < nt) wait_vmcnt<2>(); else wait_vmcnt<0>();      // U0..U2 of K-tile t+1 have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CUT3R_BARRIER();
+        CUT3R_QUADRANT(4, 0, fb0);
+        CUT3R_QUADRANT(4, 2, fb1);
+        CUT3R_BARRIER();
+    }
+#else
     // ---- prologue: K-tile 0 complete, U0/U1 of K-tile 1 in flight
     issue_a(0, 0, 0); issue_b(0, 0, 1); issue_b(1, 0, 2); issue_a(1, 0, 3);
     issue_a(0, 1, 0); issue_b(0, 1, 1);
@@ -590,6 +659,7 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
         CUT3R_QUADRANT(4, 0, fb0);
         CUT3R_BARRIER();
     }
+#endif
     if (wr == 0) CUT3R_BARRIER();          // re-join the two groups: every ds_read of the workgroup has been consumed
 #undef CUT3R_QUADRANT
 
@@ -694,8 +764,13 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
 #undef CUT3R_BARRIER
 }
 
-template <bool CONV3, bool RELU_IN>
-__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) { gemm256_body<CONV3, RELU_IN>(g, blockIdx.x, blockIdx.z); }
+template <bool CONV3, bool RELU_IN, bool FAST_DMA = false>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) { gemm256_body<CONV3, RELU_IN, FAST_DMA>(g, blockIdx.x, blockIdx.z); }
+
+// plain operands, whole K-tiles, 32-bit byte offsets: the one-instruction DMA pieces of gemm256_body
+static bool gemm256_fast_ok(const GemmArgs& g) {
+    return g.conv_k == 0 && (g.K % BK) == 0 && (size_t)g.M * g.lda * 2 < 0xFFFF0000ull && (size_t)g.N * g.ldb * 2 < 0xFFFF0000ull;
+}
 
 __global__ __launch_bounds__(512) void gemm256_pair_kernel(const GemmPairArgs a) {
     const int sel = (int)blockIdx.x >= a.nblk0 ? 1 : 0;
@@ -904,6 +979,7 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         if (d->conv_k == 3 && d->relu_in) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, dim3(512), 0, s, g);
         else if (d->conv_k == 3) hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, dim3(512), 0, s, g);
         else if (d->relu_in) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, dim3(512), 0, s, g);
+        else if (gemm256_fast_ok(g)) hipLaunchKernelGGL((gemm256_kernel<false, false, true>), grid, dim3(512), 0, s, g);
         else hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, dim3(512), 0, s, g);
     } else if (tile == 128) {
         dim3 grid((d->N + 127) / 128, (d->M + 127) / 128, batch);
