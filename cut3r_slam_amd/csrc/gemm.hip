@@ -161,7 +161,12 @@ DEVINL void xcd_tile(int orig, int npm, int npn, int& pid_m, int& pid_n) {
 // conflict-free is applied to the per-lane SOURCE chunk (lane l sits at row l>>3, chunk l&7 of its 8-row group and
 // fetches chunk (l&7)^(l>>3)), and again on the read side.  NSTAGE-deep ring, counted vmcnt, ONE raw s_barrier per
 // K-tile: NSTAGE-2 tiles stay in flight across the barrier.
-template <int BM, int BN, int NSTAGE, int WAVES_M, int WAVES_N>
+// ADDR: how a DMA piece gets its source address.  0: generic (any K, any convolution; per-lane tap decoding and bounds tests per
+// piece).  1: plain operands with whole K-tiles -- a per-lane pointer computed once plus the scalar K offset.  2: 3x3 convolution
+// with Cin a power of two >= 64 -- the tap of a K-tile is wave-uniform (shift), a per-lane pointer to the pixel's top-left
+// neighbour plus a scalar offset, the nine padding tests folded into a per-lane bit mask.  (s_memtime on the 256x256 kernel: the
+// load segments set the pace of a K-tile, and the vector address arithmetic was most of them.)
+template <int BM, int BN, int NSTAGE, int WAVES_M, int WAVES_N, int ADDR = 0>
 DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const int bz) {
     constexpr int NWAVE = WAVES_M * WAVES_N;
     constexpr int NTHR = 64 * NWAVE;
@@ -228,7 +233,55 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
         b_base[i] = Bm + (size_t)(b_ok[i] ? gn : 0) * g.ldb;
     }
 
+    // ---- ADDR 1 / 2: per-lane source pointers (and the padding mask of the nine taps), computed once
+    const h16* a_p[A_CH];
+    const h16* b_p[B_CH];
+    unsigned a_mask[A_CH];
+    if (ADDR != 0) {
+#pragma unroll
+        for (int i = 0; i < A_CH; i++) {
+            a_mask[i] = 0;
+            if (ADDR == 2) {
+                a_p[i] = a_base[i] + ((ptrdiff_t)a_oy[i] * g.W + a_ox[i]) * g.Cin + csrc * 8;      // (may lie outside the image: masked)
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    const int iy = a_oy[i] + t / 3, ix = a_ox[i] + t % 3;
+                    if (a_ok[i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) a_mask[i] |= 1u << t;
+                }
+            } else {
+                a_p[i] = A + (size_t)min(m0 + (wave + NWAVE * i) * 8 + lrow, M - 1) * g.lda + csrc * 8;   // rows >= M: never stored
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; i++) b_p[i] = Bm + (size_t)min(n0 + (wave + NWAVE * i) * 8 + lrow, N - 1) * g.ldb + csrc * 8;
+    }
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int cin_shift = 31 - __builtin_clz((unsigned)(g.Cin > 0 ? g.Cin : 1));
+
     auto issue_tile = [&](int kt, int stage) {
+        if constexpr (ADDR != 0) {
+            unsigned char* sa = smem + stage * STAGE_BYTES;
+            unsigned char* sb = sa + BM * BK * 2;
+            const int k0 = kt * BK;                                   // wave-uniform
+            int tap = 0, delta = k0;
+            if (ADDR == 2) {
+                tap = k0 >> cin_shift;
+                const int dy = (tap >= 3) + (tap >= 6), dx = tap - 3 * dy;
+                delta = (dy * g.W + dx) * g.Cin + (k0 & (g.Cin - 1));
+            }
+#pragma unroll
+            for (int i = 0; i < A_CH; i++) {
+                const h16* src = a_p[i] + delta;
+                if (ADDR == 2 && !((a_mask[i] >> tap) & 1)) src = zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(sa + (wave_s + NWAVE * i) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < B_CH; i++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_p[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(sb + (wave_s + NWAVE * i) * 1024), 16, 0, 0);
+            return;
+        }
         const int k = kt * BK + csrc * 8;
         const bool kok = k < K;
         unsigned char* sa = smem + stage * STAGE_BYTES;
@@ -386,9 +439,17 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
 
 // (8-wave tiles whose LDS lets two workgroups share a CU are held to 128 VGPRs: 4 waves per SIMD)
 #define CUT3R_TILE_BOUNDS __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8 && (BM + BN) * BK * 2 * NSTAGE <= 81920) ? 4 : 1)
-template <int BM, int BN, int NSTAGE, int WAVES_M = 2, int WAVES_N = 2>
+template <int BM, int BN, int NSTAGE, int WAVES_M = 2, int WAVES_N = 2, int ADDR = 0>
 __global__ CUT3R_TILE_BOUNDS void gemm_kernel(const GemmArgs g) {
-    gemm_tile_body<BM, BN, NSTAGE, WAVES_M, WAVES_N>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+    gemm_tile_body<BM, BN, NSTAGE, WAVES_M, WAVES_N, ADDR>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// the addressing mode of gemm_tile_body a problem qualifies for (0: generic)
+static int tile_addr_mode(const GemmArgs& g) {
+    static const bool off = [] { const char* e = getenv("CUT3R_GEMM_FASTADDR"); return e && atoi(e) == 0; }();
+    if (off || (g.K % BK) != 0) return 0;
+    if (g.conv_k == 3) return (g.Cin >= 64 && (g.Cin & (g.Cin - 1)) == 0 && g.K == 9 * g.Cin) ? 2 : 0;
+    return 1;
 }
 
 // TWO independent problems in one launch (1-D grid: the first nblk0 workgroups belong to problem 0): the state-side and the
@@ -482,8 +543,27 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     // the two wave groups; a piece with 64-bit per-lane addresses, two selects and a readfirstlane costs ~70 cycles of wave time.)
     // Rows beyond M / N read the last valid row instead of zeros: those accumulators are never stored.
     // (FAST_DMA is chosen at launch: gemm256_fast_ok)
-    constexpr bool fast_dma = FAST_DMA && !CONV3;
+    constexpr bool fast_dma = FAST_DMA;
     unsigned a_off[2][2], b_off[2][2];
+    // 3x3 convolution with Cin a power of two >= 64 (ADDR 2 of gemm_tile_body): wave-uniform tap, per-lane pointer + padding mask
+    const h16* a_pc[2][2];
+    unsigned a_msk[2][2];
+    const int cin_shift = 31 - __builtin_clz((unsigned)(g.Cin > 0 ? g.Cin : 1));
+    if (FAST_DMA && CONV3) {
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                a_pc[q][i] = a_ptr[q][i] + ((ptrdiff_t)a_oy[q][i] * g.W + a_ox[q][i]) * g.Cin + csrc * 8;
+                unsigned mk = 0;
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    const int iy = a_oy[q][i] + t / 3, ix = a_ox[q][i] + t % 3;
+                    if (a_ok[q][i] && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) mk |= 1u << t;
+                }
+                a_msk[q][i] = mk;
+            }
+    }
 #pragma unroll
     for (int q = 0; q < 2; q++)
 #pragma unroll
@@ -506,7 +586,22 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     // unit U of K-tile kt -> LDS-DMA (skipped past the last tile; the vmcnt below accounts for that)
     auto issue_a = [&](int q, int kt, int unit) {
         if (kt >= nt) return;
-        if constexpr (fast_dma) { issue_fast(A, a_off[q], kt, unit); return; }
+        if constexpr (fast_dma && !CONV3) { issue_fast(A, a_off[q], kt, unit); return; }
+        if constexpr (fast_dma && CONV3) {
+            const int k0 = kt * BK;
+            const int tap = k0 >> cin_shift;
+            const int dy = (tap >= 3) + (tap >= 6), dx = tap - 3 * dy;
+            const int delta = (dy * g.W + dx) * g.Cin + (k0 & (g.Cin - 1));
+            unsigned char* slot = smem + (kt & 1) * BUF + unit * UNIT;
+            const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const h16* src = ((a_msk[q][i] >> tap) & 1) ? a_pc[q][i] + delta : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(slot + (wave_s + 8 * i) * 1024), 16, 0, 0);
+            }
+            return;
+        }
         unsigned char* slot = smem + (kt & 1) * BUF + unit * UNIT;
         const int k = kt * BK + csrc * 8;
         const bool kok = k < K;
@@ -769,7 +864,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) { gemm25
 
 // plain operands, whole K-tiles, 32-bit byte offsets: the one-instruction DMA pieces of gemm256_body
 static bool gemm256_fast_ok(const GemmArgs& g) {
-    return g.conv_k == 0 && (g.K % BK) == 0 && (size_t)g.M * g.lda * 2 < 0xFFFF0000ull && (size_t)g.N * g.ldb * 2 < 0xFFFF0000ull;
+    static const bool off = [] { const char* e = getenv("CUT3R_GEMM_FASTADDR"); return e && atoi(e) == 0; }();
+    if (off || (g.K % BK) != 0 || (size_t)g.N * g.ldb * 2 >= 0xFFFF0000ull) return false;
+    if (g.conv_k == 3) return g.Cin >= 64 && (g.Cin & (g.Cin - 1)) == 0 && g.K == 9 * g.Cin;
+    return (size_t)g.M * g.lda * 2 < 0xFFFF0000ull;
 }
 
 __global__ __launch_bounds__(512) void gemm256_pair_kernel(const GemmPairArgs a) {
@@ -976,10 +1074,13 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
 #undef CUT3R_SKINNY
     } else if (tile == 256) {
         dim3 grid(((d->N + 255) / 256) * ((d->M + 255) / 256), 1, batch);
-        if (d->conv_k == 3 && d->relu_in) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, dim3(512), 0, s, g);
+        const bool fast = gemm256_fast_ok(g);
+        if (d->conv_k == 3 && d->relu_in && fast) hipLaunchKernelGGL((gemm256_kernel<true, true, true>), grid, dim3(512), 0, s, g);
+        else if (d->conv_k == 3 && fast) hipLaunchKernelGGL((gemm256_kernel<true, false, true>), grid, dim3(512), 0, s, g);
+        else if (d->conv_k == 3 && d->relu_in) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, dim3(512), 0, s, g);
         else if (d->conv_k == 3) hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, dim3(512), 0, s, g);
         else if (d->relu_in) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, dim3(512), 0, s, g);
-        else if (gemm256_fast_ok(g)) hipLaunchKernelGGL((gemm256_kernel<false, false, true>), grid, dim3(512), 0, s, g);
+        else if (fast) hipLaunchKernelGGL((gemm256_kernel<false, false, true>), grid, dim3(512), 0, s, g);
         else hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, dim3(512), 0, s, g);
     } else if (tile == 128) {
         dim3 grid((d->N + 127) / 128, (d->M + 127) / 128, batch);
@@ -994,7 +1095,12 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         else if (d->stages == 10) hipLaunchKernelGGL((gemm_kernel<128, 128, 3, 4, 2>), grid, dim3(512), 0, s, g);
         else if (d->stages == 14) hipLaunchKernelGGL((gemm_kernel<128, 128, 4, 4, 2>), grid, dim3(512), 0, s, g);      // 128 KiB ring, one workgroup per CU
         else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<128, 128, 2>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
+        else {
+            const int am = tile_addr_mode(g);
+            if (am == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 1>), grid, dim3(512), 0, s, g);
+            else if (am == 2) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 2>), grid, dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
+        }
     } else if (tile == 128192) {       // 128 x 192 (four 48-wide or three 64-wide heads per tile), 8 waves (32 x 96 per wave), 80 KB LDS
         dim3 grid(((d->N + 191) / 192) * ((d->M + 127) / 128), 1, batch);
         g.swz = 1;
@@ -1003,7 +1109,12 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         dim3 grid(((d->N + 127) / 128) * ((d->M + 191) / 192), 1, batch);
         g.swz = 1;
         if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<192, 128, 3, 4, 2>), grid, dim3(512), 0, s, g);                 // 120 KiB ring
-        else hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
+        else {
+            const int am = tile_addr_mode(g);
+            if (am == 1) hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2, 1>), grid, dim3(512), 0, s, g);
+            else if (am == 2) hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2, 2>), grid, dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
+        }
     } else if (tile == 256128) {
         dim3 grid((d->N + 127) / 128, (d->M + 255) / 256, batch);
         if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<256, 128, 3, 4, 2>), grid, dim3(512), 0, s, g);                 // 144 KiB ring
