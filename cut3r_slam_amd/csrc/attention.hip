@@ -106,28 +106,42 @@ __global__ __launch_bounds__(NW * 64, (D <= 64 && NW == 4) ? 3 : 1) void attn_ke
     }
 
     half8_t rk[NCH], rv[NCH];
+    // this thread's chunks of a K / V tile: the pointers are computed once and advanced by one tile per call (s_memtime: the
+    // per-tile 64-bit address arithmetic, bounds tests and zero fills of four loads cost 470 of a tile's 2750 cycles); only a
+    // ragged LAST tile takes the bounds-tested form
+    const h16* kptr[NCH];
+    const h16* vptr[NCH];
+    int kkey[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int id = tid + c * NTHR;
+        const int key = id / (D / 8), ch = id - key * (D / 8);
+        kkey[c] = key;
+        kptr[c] = kp + (size_t)(extra + key) * a.k_sn + ch * 8;
+        vptr[c] = vp + (size_t)(extra + key) * a.v_sn + ch * 8;
+    }
     auto load_kv = [&](int t) {
         const int kbase = extra + t * KT;
+        const bool full = kbase + KT <= a.Nk;          // wave-uniform
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            int id = tid + c * NTHR;
             half8_t zk = {0, 0, 0, 0, 0, 0, 0, 0}, zv = zk;
-            if (id < CHUNKS) {
-                int key = id / (D / 8), ch = id - key * (D / 8);
-                int gk = kbase + key;
-                if (gk < a.Nk) {
-                    zk = *reinterpret_cast<const half8_t*>(kp + (size_t)gk * a.k_sn + ch * 8);
-                    zv = *reinterpret_cast<const half8_t*>(vp + (size_t)gk * a.v_sn + ch * 8);
+            if (NCH * NTHR == CHUNKS || tid + c * NTHR < CHUNKS) {
+                if (full || kbase + kkey[c] < a.Nk) {
+                    zk = *reinterpret_cast<const half8_t*>(kptr[c]);
+                    zv = *reinterpret_cast<const half8_t*>(vptr[c]);
                 }
             }
             rk[c] = zk; rv[c] = zv;
+            kptr[c] += (size_t)KT * a.k_sn;
+            vptr[c] += (size_t)KT * a.v_sn;
         }
     };
     auto store_kv = [&]() {
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             int id = tid + c * NTHR;
-            if (id < CHUNKS) {
+            if (NCH * NTHR == CHUNKS || id < CHUNKS) {
                 int key = id / (D / 8), ch = id - key * (D / 8);
                 *reinterpret_cast<half8_t*>(&Ks[key * KS_LD + ch * 8]) = rk[c];
                 *reinterpret_cast<half8_t*>(&Vs[key * V_LD + ch * 8]) = rv[c];
