@@ -161,7 +161,7 @@ def git_sha():
         return None
 
 
-PMC_KEYS = {128: "gemm_kernel<128, 128, 2, 4, 2>", 256: "gemm256_kernel<false, false>"}
+PMC_KEYS = {128: "gemm_kernel<128, 128, 2, 4, 2", 256: "gemm256_kernel<false, false"}       # prefixes: the instance with most launches
 
 
 def traffic_from_profile(tile, launches_in_run):
@@ -173,7 +173,8 @@ def traffic_from_profile(tile, launches_in_run):
     pj = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
     if os.path.isfile(pj):
         j = json.load(open(pj))
-        k = j.get("kernels", {}).get(PMC_KEYS.get(tile, ""))
+        cand = [(v.get("launches", 0), n) for n, v in j.get("kernels", {}).items() if tile in PMC_KEYS and n.startswith(PMC_KEYS[tile])]
+        k = j["kernels"][max(cand)[1]] if cand else None
         if k:
             return {"bytes_per_launch": k.get("traffic_bytes_per_launch"), "source": os.path.relpath(pj, ROOT),
                     "profile_launches": k.get("launches"), "profile_git_sha": j.get("git_sha"), "run_launches": launches_in_run,
