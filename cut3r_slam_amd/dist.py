@@ -85,6 +85,7 @@ class ShardedTracker:
         self.scan = world > 1 or force_collective or os.environ.get("CUT3R_SCAN", "0") == "1"
         self.replicate_depth = os.environ.get("CUT3R_REPLICATE_DEPTH", "0") == "1"
         self._chain = None
+        slam.tracked_only = True          # trajectory writers stop at the last TRACKED keyframe (the look-ahead registers more)
         self.stats = {"append_s": 0.0, "issue_s": 0.0, "issue_enc_s": 0.0, "replay_s": 0.0, "replay_wait_s": 0.0, "exchange_s": 0.0, "steps": 0}     # host wall-clock per phase
 
     def frames_needed(self, total_steps: int, kf_every: int, win: int) -> int:
@@ -276,6 +277,8 @@ class ShardedTracker:
                 torch.cuda.current_stream().wait_event(ev_enc)
                 feats.record_stream(torch.cuda.current_stream())
             else:
+                if self._ahead is not None:      # a look-ahead pass for other windows may still be writing the feature store
+                    torch.cuda.current_stream().wait_event(self._ahead[2])
                 feats = self._encode(mine)
             self._ahead = None
             self.stats["issue_s"] += time.perf_counter() - tic

@@ -46,6 +46,9 @@ class Cut3rSlam:
         # (frames stay on the device, 0.6 MB each at 384x512): demo.py switches it on when --add_kf semantics are wanted
         self.keep_images = False
         self.images = {}
+        # dist.ShardedTracker registers keyframes ahead of the tracker (encoder look-ahead): it sets this, and the trajectory writers
+        # then stop at tracker.t1 instead of the reference's counter - 1 (demo_s.py:97-100)
+        self.tracked_only = False
 
     @torch.no_grad()
     def run(self, tstamp, image, intrinsics, image_ds, intrinsics_ds, second_last_frame=False, last_frame=False):
@@ -129,6 +132,8 @@ class Cut3rSlam:
     def trajectory(self):
         """(tstamps [t], poses [t,7] c2w (t, q_xyzw)) of the tracked keyframes (demo_s.py:97-100)."""
         t = self.keyframes.counter.value - 1
+        if self.tracked_only:
+            t = min(t, self.tracker.t1)
         return self.keyframes.tstamp[:t].numpy().copy(), self.keyframes.pose[:t].numpy().copy()
 
     def save_trajectory(self, path, tstamps_full=None):

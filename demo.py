@@ -96,7 +96,7 @@ def main(argv=None):
         if slam is None:
             slam = Cut3rSlam(model, cfg, (image_ds.shape[2], image_ds.shape[3]), buffer=buffer, device=args.device)
         slam.run(t, image, intr[0].float(), image_ds, intr_ds[0].float(), second_last_frame=(t + args.start == n_files - 2),
-                 last_frame=is_last or (t + args.start == n_files - 1))
+                 last_frame=(t + args.start == n_files - 1))      # demo_s.py:158-159: a --length cut does NOT flush the tail window
         nframes += 1
     if slam is None:
         raise SystemExit(f"{args.imagedir}: no frames")
