@@ -487,7 +487,12 @@ __global__ CUT3R_TILE_BOUNDS void gemm_pair_kernel(const GemmPairArgs a) {
 #ifndef EPI_UNROLL
 #define EPI_UNROLL 1
 #endif
-template <bool CONV3, bool RELU_IN, bool FAST_DMA = false>
+// EPI: compile-time epilogue.  0 = every case at run time (activation, one or two residuals of either type, either output type,
+// pixel shuffle, RoPE): ~50 vector instructions, scalar branches and spill reloads between two stores (s_memtime: 400-560 of an
+// iteration's 650-800 cycles).  1 = fp16 out + bias; 2 = fp16 out + bias + GELU; 3 = fp32 out + bias + fp32 residual: the three
+// epilogues of the network's Linear layers; 4 = fp16 out + bias + ReLU, 5 = fp16 out + bias + one or two fp16 residuals: the DPT
+// convolutions.  Straight-line; same per-element arithmetic, same order (bias, activation, residuals).
+template <bool CONV3, bool RELU_IN, bool FAST_DMA = false, int EPI = 0>
 DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     constexpr int UNIT = 128 * BK * 2;      // 16 KiB: 128 rows x 64 halfs
     constexpr int BUF = 4 * UNIT;
@@ -768,7 +773,93 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     const float* bias = g.bias ? g.bias + (size_t)z * g.sBias : nullptr;
     const bool plain = !g.shuf && g.rope_cols == 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    if (plain && g.out_f16 && !g.res2 && (N & 7) == 0 && (g.ldc & 7) == 0) {
+    if constexpr (EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5) {
+        const int er = lane >> 3, ec = (lane & 7) * 8;
+        const int gn = n0 + wc * 64 + ec;
+        const bool col_ok = gn + 8 <= N;               // (every lane stages its accumulators; only the readers are column-bounded)
+        const int gnc = col_ok ? gn : 0;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + gnc), b1 = *reinterpret_cast<const f32x4*>(bias + gnc + 4);
+        h16* crow = (h16*)g.C + (size_t)z * g.sC + (size_t)(m0 + wr * 128 + er) * g.ldc + gnc;
+        const size_t step8 = (size_t)8 * g.ldc;
+#pragma unroll
+        for (int mp = 0; mp < 4; mp++) {
+            f32x4 ra[4], rb[4], sa[4], sb[4];           // EPI 5: the residual rows of the band, loaded before it is staged
+            if (EPI == 5) {
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const size_t gm = (size_t)min(m0 + wr * 128 + mp * 32 + it * 8 + er, M - 1);
+                    const half8_t h1 = *reinterpret_cast<const half8_t*>((const h16*)g.res1 + (size_t)z * g.sR1 + gm * g.ldr1 + gnc);
+                    ra[it] = f32x4{(float)h1[0], (float)h1[1], (float)h1[2], (float)h1[3]};
+                    rb[it] = f32x4{(float)h1[4], (float)h1[5], (float)h1[6], (float)h1[7]};
+                    if (g.res2) {
+                        const half8_t h2 = *reinterpret_cast<const half8_t*>((const h16*)g.res2 + (size_t)z * g.sR2 + gm * g.ldr2 + gnc);
+                        sa[it] = f32x4{(float)h2[0], (float)h2[1], (float)h2[2], (float)h2[3]};
+                        sb[it] = f32x4{(float)h2[4], (float)h2[5], (float)h2[6], (float)h2[7]};
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) cs[(i * 16 + fq * 4 + e) * CP + j * 16 + fr] = acc[mp * 2 + i][j][e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int rr = it * 8 + er;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec) + b0;
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + 4) + b1;
+                if (EPI == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { v0[e] = gelu_fast(v0[e]); v1[e] = gelu_fast(v1[e]); }
+                }
+                if (EPI == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                }
+                if (EPI == 5) {
+                    v0 += ra[it]; v1 += rb[it];
+                    if (g.res2) { v0 += sa[it]; v1 += sb[it]; }
+                }
+                const half8_t o = {(h16)v0[0], (h16)v0[1], (h16)v0[2], (h16)v0[3], (h16)v1[0], (h16)v1[1], (h16)v1[2], (h16)v1[3]};
+                if (col_ok && m0 + wr * 128 + mp * 32 + rr < M) *reinterpret_cast<half8_t*>(crow + (size_t)(mp * 4 + it) * step8) = o;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else if constexpr (EPI == 3) {
+        const int er = lane >> 4, ec = (lane & 15) * 4;
+        const int gn = n0 + wc * 64 + ec;
+        const bool col_ok = gn < N;
+        const int gnc = col_ok ? gn : 0;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + gnc);
+        const float* rrow = (const float*)g.res1 + (size_t)z * g.sR1 + gnc;
+        float* crow = (float*)g.C + (size_t)z * g.sC + gnc;
+#pragma unroll
+        for (int mp = 0; mp < 4; mp++) {
+            f32x4 r1v[8];
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int gm = min(m0 + wr * 128 + mp * 32 + it * 4 + er, M - 1);
+                r1v[it] = *reinterpret_cast<const f32x4*>(rrow + (size_t)gm * g.ldr1);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) cs[(i * 16 + fq * 4 + e) * CP + j * 16 + fr] = acc[mp * 2 + i][j][e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int rr = it * 4 + er;
+                const int gm = m0 + wr * 128 + mp * 32 + rr;
+                const f32x4 v = (*reinterpret_cast<const f32x4*>(cs + rr * CP + ec) + b4) + r1v[it];
+                if (col_ok && gm < M) *reinterpret_cast<f32x4*>(crow + (size_t)gm * g.ldc) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else if (plain && g.out_f16 && !g.res2 && (N & 7) == 0 && (g.ldc & 7) == 0) {
         const int er = lane >> 3, ec = (lane & 7) * 8;
         const int gn = n0 + wc * 64 + ec;
         const bool col_ok = gn + 8 <= N;
@@ -859,8 +950,24 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
 #undef CUT3R_BARRIER
 }
 
-template <bool CONV3, bool RELU_IN, bool FAST_DMA = false>
-__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) { gemm256_body<CONV3, RELU_IN, FAST_DMA>(g, blockIdx.x, blockIdx.z); }
+template <bool CONV3, bool RELU_IN, bool FAST_DMA = false, int EPI = 0>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) { gemm256_body<CONV3, RELU_IN, FAST_DMA, EPI>(g, blockIdx.x, blockIdx.z); }
+
+// which compile-time epilogue of gemm256_body a plain Linear qualifies for (0: the run-time one)
+static int gemm256_epi_mode(const GemmArgs& g) {
+    static const bool off = [] { const char* e = getenv("CUT3R_GEMM_EPI"); return e && atoi(e) == 0; }();
+    if (off || g.shuf || g.rope_cols || !g.bias || ((uintptr_t)g.bias & 15) || (g.sBias & 3)) return 0;
+    if (g.out_f16 && !g.res1 && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (g.sC & 7) == 0 && ((uintptr_t)g.C & 15) == 0)
+        return g.act == 1 ? 2 : (g.act == 2 ? 4 : 1);
+    if (g.out_f16 && g.res1 && g.res1_f16 && g.act == 0 && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (g.sC & 7) == 0 && ((uintptr_t)g.C & 15) == 0 &&
+        (g.ldr1 & 7) == 0 && (g.sR1 & 7) == 0 && ((uintptr_t)g.res1 & 15) == 0 &&
+        (!g.res2 || (g.res2_f16 && (g.ldr2 & 7) == 0 && (g.sR2 & 7) == 0 && ((uintptr_t)g.res2 & 15) == 0)))
+        return 5;
+    if (!g.out_f16 && g.res1 && !g.res2 && !g.res1_f16 && g.act == 0 && (g.N & 3) == 0 && (g.ldc & 3) == 0 && (g.ldr1 & 3) == 0 && (g.sC & 3) == 0 &&
+        (g.sR1 & 3) == 0 && (((uintptr_t)g.C | (uintptr_t)g.res1) & 15) == 0)
+        return 3;
+    return 0;
+}
 
 // plain operands, whole K-tiles, 32-bit byte offsets: the one-instruction DMA pieces of gemm256_body
 static bool gemm256_fast_ok(const GemmArgs& g) {
@@ -1075,12 +1182,24 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     } else if (tile == 256) {
         dim3 grid(((d->N + 255) / 256) * ((d->M + 255) / 256), 1, batch);
         const bool fast = gemm256_fast_ok(g);
-        if (d->conv_k == 3 && d->relu_in && fast) hipLaunchKernelGGL((gemm256_kernel<true, true, true>), grid, dim3(512), 0, s, g);
+        const int epi = fast ? gemm256_epi_mode(g) : 0;
+        if (d->conv_k == 3 && d->relu_in && fast && epi == 4) hipLaunchKernelGGL((gemm256_kernel<true, true, true, 4>), grid, dim3(512), 0, s, g);
+        else if (d->conv_k == 3 && !d->relu_in && fast && epi == 5) hipLaunchKernelGGL((gemm256_kernel<true, false, true, 5>), grid, dim3(512), 0, s, g);
+        else if (d->conv_k == 3 && !d->relu_in && fast && epi == 1) hipLaunchKernelGGL((gemm256_kernel<true, false, true, 1>), grid, dim3(512), 0, s, g);
+        else if (d->conv_k == 3 && !d->relu_in && fast && epi == 4) hipLaunchKernelGGL((gemm256_kernel<true, false, true, 4>), grid, dim3(512), 0, s, g);
+        else if (d->conv_k == 3 && d->relu_in && fast) hipLaunchKernelGGL((gemm256_kernel<true, true, true>), grid, dim3(512), 0, s, g);
         else if (d->conv_k == 3 && fast) hipLaunchKernelGGL((gemm256_kernel<true, false, true>), grid, dim3(512), 0, s, g);
         else if (d->conv_k == 3 && d->relu_in) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, dim3(512), 0, s, g);
         else if (d->conv_k == 3) hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, dim3(512), 0, s, g);
         else if (d->relu_in) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, dim3(512), 0, s, g);
-        else if (fast) hipLaunchKernelGGL((gemm256_kernel<false, false, true>), grid, dim3(512), 0, s, g);
+        else if (fast) {
+            switch (epi) {
+                case 1: hipLaunchKernelGGL((gemm256_kernel<false, false, true, 1>), grid, dim3(512), 0, s, g); break;
+                case 2: hipLaunchKernelGGL((gemm256_kernel<false, false, true, 2>), grid, dim3(512), 0, s, g); break;
+                case 3: hipLaunchKernelGGL((gemm256_kernel<false, false, true, 3>), grid, dim3(512), 0, s, g); break;
+                default: hipLaunchKernelGGL((gemm256_kernel<false, false, true>), grid, dim3(512), 0, s, g);
+            }
+        }
         else hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, dim3(512), 0, s, g);
     } else if (tile == 128) {
         dim3 grid((d->N + 127) / 128, (d->M + 127) / 128, batch);
