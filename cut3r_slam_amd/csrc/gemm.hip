@@ -166,7 +166,7 @@ DEVINL void xcd_tile(int orig, int npm, int npn, int& pid_m, int& pid_n) {
 // with Cin a power of two >= 64 -- the tap of a K-tile is wave-uniform (shift), a per-lane pointer to the pixel's top-left
 // neighbour plus a scalar offset, the nine padding tests folded into a per-lane bit mask.  (s_memtime on the 256x256 kernel: the
 // load segments set the pace of a K-tile, and the vector address arithmetic was most of them.)
-template <int BM, int BN, int NSTAGE, int WAVES_M, int WAVES_N, int ADDR = 0>
+template <int BM, int BN, int NSTAGE, int WAVES_M, int WAVES_N, int ADDR = 0, int EPI = 0>
 DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const int bz) {
     constexpr int NWAVE = WAVES_M * WAVES_N;
     constexpr int NTHR = 64 * NWAVE;
@@ -383,6 +383,72 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 b4 = zero4;
     if (bias && col_ok && plain) b4 = *reinterpret_cast<const f32x4*>(bias + gn);
+    if constexpr (EPI != 0) {
+        // compile-time epilogue (the EPI codes of gemm256_body): plain row-major output, bias present, vector-aligned rows
+        constexpr bool F16OUT = EPI != 3, RES = (EPI == 3 || EPI == 5);
+        const int gnc = col_ok ? gn : 0;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + gnc);
+#pragma unroll
+        for (int p = 0; p < EPI_PASSES; p++) {
+            f32x4 rv[ITER], sv[ITER];
+            if (RES) {
+#pragma unroll
+                for (int i = 0; i < ITER; i++) {
+                    const size_t gm = (size_t)min(m0 + p * EPI_ROWS + r0 + i * RPP, M - 1);
+                    if (EPI == 3) {
+                        rv[i] = *reinterpret_cast<const f32x4*>((const float*)g.res1 + (size_t)z * g.sR1 + gm * g.ldr1 + gnc);
+                    } else {
+                        const half4_t h1 = *reinterpret_cast<const half4_t*>((const h16*)g.res1 + (size_t)z * g.sR1 + gm * g.ldr1 + gnc);
+                        rv[i] = f32x4{(float)h1[0], (float)h1[1], (float)h1[2], (float)h1[3]};
+                        if (g.res2) {
+                            const half4_t h2 = *reinterpret_cast<const half4_t*>((const h16*)g.res2 + (size_t)z * g.sR2 + gm * g.ldr2 + gnc);
+                            sv[i] = f32x4{(float)h2[0], (float)h2[1], (float)h2[2], (float)h2[3]};
+                        }
+                    }
+                }
+            }
+            if (p > 0) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = wm * WM + i * 16 + fq * 4 + e - p * EPI_ROWS;
+                        const int c = wn * WN + j * 16 + fr;
+                        if (EPI_PASSES == 1 || (r >= 0 && r < EPI_ROWS)) cs[r * CPAD + c] = acc[i][j][e];
+                    }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < ITER; i++) {
+                const int r = r0 + i * RPP;
+                const int gm = m0 + p * EPI_ROWS + r;
+                if (col_ok && r < EPI_ROWS && gm < M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4) + bb;
+                    if (EPI == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = gelu_fast(v[e]);
+                    }
+                    if (EPI == 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (RES) {
+                        v += rv[i];
+                        if (EPI == 5 && g.res2) v += sv[i];
+                    }
+                    const size_t off = (size_t)z * g.sC + (size_t)gm * g.ldc + gn;
+                    if (F16OUT) {
+                        const half4_t o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                        *reinterpret_cast<half4_t*>((h16*)g.C + off) = o;
+                    } else {
+                        *reinterpret_cast<f32x4*>((float*)g.C + off) = v;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < EPI_PASSES; p++) {
         f32x4 r1v[PF];
@@ -439,9 +505,9 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
 
 // (8-wave tiles whose LDS lets two workgroups share a CU are held to 128 VGPRs: 4 waves per SIMD)
 #define CUT3R_TILE_BOUNDS __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 8 && (BM + BN) * BK * 2 * NSTAGE <= 81920) ? 4 : 1)
-template <int BM, int BN, int NSTAGE, int WAVES_M = 2, int WAVES_N = 2, int ADDR = 0>
+template <int BM, int BN, int NSTAGE, int WAVES_M = 2, int WAVES_N = 2, int ADDR = 0, int EPI = 0>
 __global__ CUT3R_TILE_BOUNDS void gemm_kernel(const GemmArgs g) {
-    gemm_tile_body<BM, BN, NSTAGE, WAVES_M, WAVES_N, ADDR>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+    gemm_tile_body<BM, BN, NSTAGE, WAVES_M, WAVES_N, ADDR, EPI>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // the addressing mode of gemm_tile_body a problem qualifies for (0: generic)
@@ -1215,8 +1281,11 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         else if (d->stages == 14) hipLaunchKernelGGL((gemm_kernel<128, 128, 4, 4, 2>), grid, dim3(512), 0, s, g);      // 128 KiB ring, one workgroup per CU
         else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<128, 128, 2>), grid, dim3(256), 0, s, g);
         else {
-            const int am = tile_addr_mode(g);
-            if (am == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 1>), grid, dim3(512), 0, s, g);
+            const int am = tile_addr_mode(g), ep = gemm256_epi_mode(g);
+            if (am == 1 && ep == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 1, 1>), grid, dim3(512), 0, s, g);
+            else if (am == 1 && ep == 2) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 1, 2>), grid, dim3(512), 0, s, g);
+            else if (am == 1 && ep == 3) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 1, 3>), grid, dim3(512), 0, s, g);
+            else if (am == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 1>), grid, dim3(512), 0, s, g);
             else if (am == 2) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 2>), grid, dim3(512), 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
         }
@@ -1229,8 +1298,10 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         g.swz = 1;
         if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<192, 128, 3, 4, 2>), grid, dim3(512), 0, s, g);                 // 120 KiB ring
         else {
-            const int am = tile_addr_mode(g);
-            if (am == 1) hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2, 1>), grid, dim3(512), 0, s, g);
+            const int am = tile_addr_mode(g), ep = gemm256_epi_mode(g);
+            if (am == 2 && ep == 1) hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2, 2, 1>), grid, dim3(512), 0, s, g);
+            else if (am == 2 && ep == 4) hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2, 2, 4>), grid, dim3(512), 0, s, g);
+            else if (am == 1) hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2, 1>), grid, dim3(512), 0, s, g);
             else if (am == 2) hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2, 2>), grid, dim3(512), 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<192, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
         }
