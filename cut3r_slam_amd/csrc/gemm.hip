@@ -717,11 +717,7 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     const int a_base = wr * 64 * 128;              // this wave's 64 rows inside an A unit
     const int b_base = wc * 32 * 128;              // this wave's 32 rows inside a B unit
 
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[8][4];           // (zeroed after the prologue's DMA has been issued: 128 moves under the first memory latency)
     half8_t fa[4][2], fb0[2][2], fb1[2][2];
 
     auto read_a = [&](const unsigned char* unit) {
@@ -761,6 +757,10 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     // phase A.  In flight behind the unit a phase needs: 4 units = 8 DMA instructions per wave (one counted wait per phase).
     issue_a(0, 0, 0); issue_b(0, 0, 1); issue_b(1, 0, 2); issue_a(1, 0, 3);
     issue_a(0, 1, 0); issue_b(0, 1, 1); issue_b(1, 1, 2);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (nt > 1) wait_vmcnt<6>(); else wait_vmcnt<0>();
     CUT3R_BARRIER();
     if (wr == 1) CUT3R_BARRIER();          // stagger: the second wave group runs one barrier behind the first
@@ -793,6 +793,10 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     // ---- prologue: K-tile 0 complete, U0/U1 of K-tile 1 in flight
     issue_a(0, 0, 0); issue_b(0, 0, 1); issue_b(1, 0, 2); issue_a(1, 0, 3);
     issue_a(0, 1, 0); issue_b(0, 1, 1);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (nt > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
     CUT3R_BARRIER();
     if (wr == 1) CUT3R_BARRIER();          // stagger: the second wave group runs one barrier behind the first
