@@ -1,0 +1,69 @@
+"""CPU: host-side pieces of the throughput driver -- the keyframe feature ring, the cyclic frame source of bench.py, the covisibility
+graph's sequence cuts.  (Their use on the GPU path is covered by tests/test_slam_gpu.py::test_sequence_cuts_equal_fresh_runs and
+tests/test_dist_gpu.py.)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cut3r_slam_amd.factor_graph import FactorGraph  # noqa: E402
+from cut3r_slam_amd.keyframe import KeyFrame  # noqa: E402
+
+
+def test_feature_ring_keeps_every_window_contiguous():
+    """KeyFrame(feat_buffer=R): keyframe i lives in row i % R, rows 0..5 are mirrored behind the end, so any 6-keyframe window is
+    one slice; validity is per keyframe (a row taken over by a later keyframe invalidates the earlier one)."""
+    R, n, C = 20, 4, 8
+    kf = KeyFrame({}, (32, 64), 200, 2, device="cpu", feat_dim=C, patch=16, feat_buffer=R)
+    assert kf.feat_rows == R and kf.featI.shape[0] == R + 6
+    feat = lambda i: torch.full((n * 2, C), float(i))          # (32/16) x (64/16) = 8 tokens
+    assert kf.featI.shape[1] == 8
+    a = 0
+    for step in range(9):                                      # batches of 11 keyframes: 0..10, 10..20 (shared first), ...
+        b = a + 11
+        kf.feat_store(a if step == 0 else a + 1, b, torch.stack([feat(i) for i in range(a if step == 0 else a + 1, b)]))
+        for t0 in range(a, b - 5, 5):                          # the windows of the batch
+            w = kf.feat_slice(t0, t0 + 6)
+            assert w.shape[0] == 6 and all(kf.feat_valid[i] for i in range(t0, t0 + 6))
+            np.testing.assert_array_equal(w[:, 0, 0].numpy(), np.arange(t0, t0 + 6, dtype=np.float32))
+        a = b - 1
+    assert not kf.feat_valid[0] and not kf.feat_valid[a - R]    # overwritten long ago
+    kf.feat_valid[a] = False
+    assert not kf.feat_valid[a]
+    full = KeyFrame({}, (32, 64), 30, 2, device="cpu", feat_dim=C, patch=16)           # default: one row per keyframe
+    full.feat_store(3, 5, torch.ones(2, 8, C))
+    assert full.feat_rows == 0 and full.feat_valid[3] and full.feat_valid[4] and not full.feat_valid[5]
+    assert full.feat_slice(3, 5).shape == (2, 8, C)
+
+
+def test_frame_loop_reads_one_recording_cyclically():
+    import bench
+    base = torch.arange(10, dtype=torch.uint8).view(10, 1, 1, 1).expand(10, 3, 2, 2).contiguous()
+    fl = bench.FrameLoop(base, 1000)
+    assert fl.shape == (1000, 3, 2, 2)
+    for f in (0, 9, 10, 25, 999):
+        assert int(fl[f:f + 1][0, 0, 0, 0]) == f % 10 and int(fl[f][0, 0, 0]) == f % 10
+    assert fl[12:15].shape[0] == 3 and int(fl[12:15][2, 0, 0, 0]) == 4
+    try:
+        fl[8:13]
+        assert False, "a slice across the period must be refused"
+    except IndexError:
+        pass
+
+
+def test_graph_sequence_cuts_archive_absolute_edges():
+    g = FactorGraph(None, device="cpu", max_factors=-1, backend=object())
+    g.add_neighborhood_factors(0, 3, r=3)
+    g.add_factors([4, 5], [1, 2])
+    n0 = len(g.edges_numpy()[0])
+    g.begin_sequence(15)
+    assert g.base == 15 and len(g.edges_numpy()[0]) == 0 and len(g.closed) == 1
+    g.add_neighborhood_factors(0, 3, r=3)                      # indices relative to keyframe 15 from here on
+    ii, jj = g.edges_absolute()
+    assert len(ii) == n0 + 6
+    assert set(zip(ii[:n0].tolist(), jj[:n0].tolist())) >= {(4, 1), (5, 2), (0, 1)}
+    assert set(zip(ii[n0:].tolist(), jj[n0:].tolist())) == {(15, 16), (15, 17), (16, 15), (16, 17), (17, 15), (17, 16)}
