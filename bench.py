@@ -161,7 +161,7 @@ def git_sha():
         return None
 
 
-PMC_KEYS = {128: "gemm_kernel<128, 128, 2, 4, 2", 256: "gemm256_kernel<false, false"}       # prefixes: the instance with most launches
+PMC_KEYS = {128: "gemm_kernel<128, 128, 2, 4, 2", 256: "gemm256_kernel<"}       # prefixes: launch-weighted mean over the instances
 
 
 def traffic_from_profile(tile, launches_in_run):
@@ -173,8 +173,11 @@ def traffic_from_profile(tile, launches_in_run):
     pj = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
     if os.path.isfile(pj):
         j = json.load(open(pj))
-        cand = [(v.get("launches", 0), n) for n, v in j.get("kernels", {}).items() if tile in PMC_KEYS and n.startswith(PMC_KEYS[tile])]
-        k = j["kernels"][max(cand)[1]] if cand else None
+        cand = [v for n, v in j.get("kernels", {}).items() if tile in PMC_KEYS and n.startswith(PMC_KEYS[tile]) and v.get("launches")]
+        k = None
+        if cand:
+            n_l = sum(v["launches"] for v in cand)
+            k = {"launches": n_l, "traffic_bytes_per_launch": sum(v["traffic_bytes_per_launch"] * v["launches"] for v in cand) / n_l}
         if k:
             return {"bytes_per_launch": k.get("traffic_bytes_per_launch"), "source": os.path.relpath(pj, ROOT),
                     "profile_launches": k.get("launches"), "profile_git_sha": j.get("git_sha"), "run_launches": launches_in_run,

@@ -191,7 +191,7 @@ class TrackFrontend:
         device work first."""
         kf, graph, ds = self.keyframes, self.graph, self.downsample_ratio
         deferred = [] if exchange is not None else None     # (t0, t1, groups, centres) per window, decisions after the exchange
-        L = ((ranges[-1][1] + 63) // 64) * 64
+        L = ((max(t1 - self.seq_base(t0) for t0, t1 in ranges) + 63) // 64) * 64      # widest count row: keyframes of a window's sequence
         all_counts = torch.zeros(len(ranges), 6, 2, L, dtype=torch.int32) if exchange is not None else None
         if self._ev is None:
             self._ev = torch.cuda.Event()
@@ -388,7 +388,7 @@ class TrackFrontend:
             self._rows_pinned = torch.zeros(max(64, tb - ta), 12).pin_memory()
         self._rows_pinned[:tb - ta].copy_(torch.from_numpy(allrows))
         kf.w2c[ta:tb].copy_(self._rows_pinned[:tb - ta], non_blocking=True)
-        L = ((tb + 63) // 64) * 64
+        L = ((max(t1 - b0 for (t0, t1), b0 in zip(ranges, bases)) + 63) // 64) * 64      # widest count row (sequence-relative)
         nown = i1 - i0
         cm = getattr(self, "_counts_many", None)
         if cm is None or cm.shape[0] < nown or cm.shape[-1] < L:
