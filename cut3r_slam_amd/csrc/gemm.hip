@@ -557,7 +557,9 @@ __global__ CUT3R_TILE_BOUNDS void gemm_pair_kernel(const GemmPairArgs a) {
 // pixel shuffle, RoPE): ~50 vector instructions, scalar branches and spill reloads between two stores (s_memtime: 400-560 of an
 // iteration's 650-800 cycles).  1 = fp16 out + bias; 2 = fp16 out + bias + GELU; 3 = fp32 out + bias + fp32 residual: the three
 // epilogues of the network's Linear layers; 4 = fp16 out + bias + ReLU, 5 = fp16 out + bias + one or two fp16 residuals: the DPT
-// convolutions.  Straight-line; same per-element arithmetic, same order (bias, activation, residuals).
+// convolutions; 6 = fp16 out + bias + 2-D RoPE of the 64-wide heads in columns < rope_cols (a wave's 64-column slab is one head: the
+// rotation partner of a lane's 8 columns is 16 columns away in the wave's own staging row).  Straight-line; same per-element
+// arithmetic, same order (bias, activation, residuals; RoPE on the fp16-rounded projection, as the stand-alone kernel sees it).
 template <bool CONV3, bool RELU_IN, bool FAST_DMA = false, int EPI = 0>
 DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     constexpr int UNIT = 128 * BK * 2;      // 16 KiB: 128 rows x 64 halfs
@@ -843,12 +845,20 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     const float* bias = g.bias ? g.bias + (size_t)z * g.sBias : nullptr;
     const bool plain = !g.shuf && g.rope_cols == 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5) {
+    if constexpr (EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5 || EPI == 6) {
         const int er = lane >> 3, ec = (lane & 7) * 8;
         const int gn = n0 + wc * 64 + ec;
         const bool col_ok = gn + 8 <= N;               // (every lane stages its accumulators; only the readers are column-bounded)
         const int gnc = col_ok ? gn : 0;
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + gnc), b1 = *reinterpret_cast<const f32x4*>(bias + gnc + 4);
+        // EPI 6: the slab n0 + wc*64 .. +63 is one head; rotated when it lies below rope_cols (wave-uniform); partner's bias
+        const bool rope_here = EPI == 6 && (n0 + wc * 64) < g.rope_cols && col_ok;
+        f32x4 pb0 = zero4, pb1 = zero4;
+        if (rope_here) {
+            const int pc = gnc + ((ec & 16) ? -16 : 16);
+            pb0 = *reinterpret_cast<const f32x4*>(bias + pc);
+            pb1 = *reinterpret_cast<const f32x4*>(bias + pc + 4);
+        }
         h16* crow = (h16*)g.C + (size_t)z * g.sC + (size_t)(m0 + wr * 128 + er) * g.ldc + gnc;
         const size_t step8 = (size_t)8 * g.ldc;
 #pragma unroll
@@ -891,6 +901,27 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
                 if (EPI == 5) {
                     v0 += ra[it]; v1 += rb[it];
                     if (g.res2) { v0 += sa[it]; v1 += sb[it]; }
+                }
+                if (EPI == 6 && rope_here) {
+                    // head-local column ec: half X = ec / 32 (y or x position), pair offset +-16 inside the half, frequency index ec % 16 ..
+                    const int po = (ec & 16) ? -16 : 16;
+                    f32x4 p0 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + po) + pb0;
+                    f32x4 p1 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + po + 4) + pb1;
+                    const int gmr = min(m0 + wr * 128 + mp * 32 + rr, M - 1);
+                    long long pv = g.rope_pos[(size_t)gmr * 2 + (ec >> 5)] - g.rope_pmin;
+                    pv = pv < 0 ? 0 : (pv >= g.rope_npos ? g.rope_npos - 1 : pv);
+                    const float* ct = g.rope_table + (size_t)pv * 16 + (ec & 15);
+                    const float* st = ct + (size_t)g.rope_npos * 16;
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(ct), c1 = *reinterpret_cast<const f32x4*>(ct + 4);
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(st), s1 = *reinterpret_cast<const f32x4*>(st + 4);
+                    const bool lower = !(ec & 16);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float t0 = (float)(h16)p0[e] * s0[e], t1 = (float)(h16)p1[e] * s1[e];
+                        asm volatile("" : "+v"(t0), "+v"(t1));          // separate multiplies, as in rope2d_kernel (no re-contraction)
+                        v0[e] = rope_rot((float)(h16)v0[e], c0[e], lower ? -t0 : t0);
+                        v1[e] = rope_rot((float)(h16)v1[e], c1[e], lower ? -t1 : t1);
+                    }
                 }
                 const half8_t o = {(h16)v0[0], (h16)v0[1], (h16)v0[2], (h16)v0[3], (h16)v1[0], (h16)v1[1], (h16)v1[2], (h16)v1[3]};
                 if (col_ok && m0 + wr * 128 + mp * 32 + rr < M) *reinterpret_cast<half8_t*>(crow + (size_t)(mp * 4 + it) * step8) = o;
@@ -1026,7 +1057,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) { gemm25
 // which compile-time epilogue of gemm256_body a plain Linear qualifies for (0: the run-time one)
 static int gemm256_epi_mode(const GemmArgs& g) {
     static const bool off = [] { const char* e = getenv("CUT3R_GEMM_EPI"); return e && atoi(e) == 0; }();
-    if (off || g.shuf || g.rope_cols || !g.bias || ((uintptr_t)g.bias & 15) || (g.sBias & 3)) return 0;
+    if (off || g.shuf || !g.bias || ((uintptr_t)g.bias & 15) || (g.sBias & 3)) return 0;
+    if (g.rope_cols) {
+        const bool ok = g.rope_d == 64 && (g.rope_cols & 63) == 0 && g.out_f16 && !g.res1 && !g.res2 && g.act == 0 && (g.N & 63) == 0 &&
+                        (g.ldc & 7) == 0 && (g.sC & 7) == 0 && ((uintptr_t)g.C & 15) == 0 && g.rope_pos && g.rope_table &&
+                        ((uintptr_t)g.rope_table & 15) == 0;
+        return ok ? 6 : 0;
+    }
     if (g.out_f16 && !g.res1 && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (g.sC & 7) == 0 && ((uintptr_t)g.C & 15) == 0)
         return g.act == 1 ? 2 : (g.act == 2 ? 4 : 1);
     if (g.out_f16 && g.res1 && g.res1_f16 && g.act == 0 && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (g.sC & 7) == 0 && ((uintptr_t)g.C & 15) == 0 &&
@@ -1267,6 +1304,7 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
                 case 1: hipLaunchKernelGGL((gemm256_kernel<false, false, true, 1>), grid, dim3(512), 0, s, g); break;
                 case 2: hipLaunchKernelGGL((gemm256_kernel<false, false, true, 2>), grid, dim3(512), 0, s, g); break;
                 case 3: hipLaunchKernelGGL((gemm256_kernel<false, false, true, 3>), grid, dim3(512), 0, s, g); break;
+                case 6: hipLaunchKernelGGL((gemm256_kernel<false, false, true, 6>), grid, dim3(512), 0, s, g); break;
                 default: hipLaunchKernelGGL((gemm256_kernel<false, false, true>), grid, dim3(512), 0, s, g);
             }
         }

@@ -82,10 +82,11 @@ class Cut3rModel:
         # launches are 30-40 % faster than the two launches they replace, but they join the two blocks at every projection, and
         # the step loses the overlap of one block's MFMA-bound GEMMs with the other block's VALU-bound attention / LayerNorm
         self.pair_gemm = _os.environ.get("CUT3R_PAIR_GEMM", "0") != "0"
-        # RoPE in the q/k projection epilogue: 0 off (default), 1 heads of 64, 2 also heads of 48.  Bit-identical to the
-        # stand-alone kernel; +1 % when the decoder ran alone, -2.5 % now that encoder / head kernels fill its gaps (the
-        # heavier epilogue lengthens every projection on the critical path, the small RoPE kernel overlaps for free)
-        self.fused_rope = int(_os.environ.get("CUT3R_FUSED_ROPE", "0"))      # RoPE in the q/k projection epilogue (D = 64)
+        # RoPE in the q/k projection epilogue: 0 off, 1 heads of 64 (default), 2 also heads of 48.  Bit-identical to the stand-alone
+        # kernel.  Through the run-time epilogue of round 1 it lost 2.5 % end to end; as a compile-time epilogue of the 256x256 kernel
+        # (a wave's 64-column slab is one head) it gains 1.0 % (5703 -> 5761 frames/s, interleaved runs); 48-wide heads straddle the
+        # slabs and keep the stand-alone launch
+        self.fused_rope = int(_os.environ.get("CUT3R_FUSED_ROPE", "1"))      # RoPE in the q/k projection epilogue (D = 64)
         # DPT head of view i (all windows) on a third stream while the recurrent decoder works on view i+1: the decoder's
         # mid-size kernels leave matrix and memory pipes idle that the head's large convolutions can use
         self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "1") != "0"
