@@ -109,6 +109,28 @@ def test_medium_config_head_dims_48_64_vs_oracle():
     print("\n".join(log))
 
 
+def test_fused_rope_epilogue_gives_the_bits_of_the_rope_launch():
+    """Cut3rModel.fused_rope (default 1: RoPE of 64-wide heads in the q / k projection epilogue) against the stand-alone RoPE
+    launches, whole window, heads of 64 (encoder, image side) and 48 (state side): every output bit-identical."""
+    cfg = Cut3rConfig(img_size=(64, 96), enc_embed_dim=256, enc_depth=2, enc_num_heads=4, dec_embed_dim=192, dec_depth=3,
+                      dec_num_heads=3, state_dec_num_heads=4, state_size=30, local_mem_size=16, ray_enc_depth=1, head_type="dpt", rgb_head=True)
+    sd = synth_state_dict(cfg, 5)
+    g = torch.Generator().manual_seed(1)
+    imgs = torch.randint(0, 256, (4, 3, 64, 96), generator=g, dtype=torch.uint8).to(DEV)
+    outs = []
+    for mode in (0, 1, 2):
+        model = Cut3rModel(cfg, sd, DEV, minimal=True)
+        model.fused_rope = mode
+        model.use_graphs = False
+        preds, _ = model.forward_window(imgs)
+        outs.append([{k: v.clone() for k, v in p.items()} for p in preds])
+    torch.cuda.synchronize()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+
+
 def test_decode_from_cached_features_equals_full_window():
     """encode once + decode_window(features) must give the window result (features are batch-invariant bit for bit)."""
     f = np.load(os.path.join(GOLD, "model_tiny_dpt.npz"))
