@@ -1358,9 +1358,19 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     } else if (tile == 64) {
         dim3 grid((d->N + 63) / 64, (d->M + 63) / 64, batch);
         if (d->stages == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 2>), grid, dim3(256), 0, s, g);
-        else if (d->stages == 8 || (d->stages == 0 && d->K >= 2048)) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4>), grid, dim3(512), 0, s, g);   // long K: 8 waves
+        else if (d->stages == 8 || (d->stages == 0 && d->K >= 2048)) {   // long K: 8 waves
+            const int am = d->stages == 0 ? tile_addr_mode(g) : 0;
+            if (am == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4, 1>), grid, dim3(512), 0, s, g);
+            else if (am == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4, 2>), grid, dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4>), grid, dim3(512), 0, s, g);
+        }
         else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<64, 64, 4>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((gemm_kernel<64, 64, 3>), grid, dim3(256), 0, s, g);
+        else {
+            const int am = d->stages == 0 ? tile_addr_mode(g) : 0;
+            if (am == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 1>), grid, dim3(256), 0, s, g);
+            else if (am == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 2>), grid, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((gemm_kernel<64, 64, 3>), grid, dim3(256), 0, s, g);
+        }
     } else {
         return CUT3R_ERR_ARG;
     }
