@@ -22,6 +22,15 @@ namespace {
 
 typedef __fp16 fp16x4_t __attribute__((ext_vector_type(4)));
 
+// x of this lane and of lane ^ 32, without the LDS round trip of ds_bpermute: v_permlane32_swap_b32 (gfx950) exchanges lanes 32..63
+// of one register with lanes 0..31 of another in ONE vector instruction; applied to two copies of x it leaves {x[lane & 31], x[lane | 32]}
+// in every lane -- the two halves' values, which is all a commutative combine (max, sum) needs.
+DEVINL void halves(float x, float& lo, float& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+
 struct AttnArgs {
     const h16* q; const h16* k; const h16* v; h16* o;
     int Nq, Nk;
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 64 && NW == 4) ? 3 : 1) void attn_ke
 #pragma unroll
             for (int j = 0; j < 8; j++) dot = fmaf((float)qf[s][j], (float)k0[j], dot);
         }
-        dot += __shfl_xor(dot, 32, 64);
+        { float d0, d1; halves(dot, d0, d1); dot = d0 + d1; }
         m_run = dot * a.scale_log2;
         l_run = hh == 0 ? 1.f : 0.f;             // the two halves' sums are added at the end
 #pragma unroll
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 64 && NW == 4) ? 3 : 1) void attn_ke
                     mloc = fmaxf(mloc, sv);
                 }
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * a.scale_log2;      // scale > 0: max commutes with the scaling
+        { float m0_, m1_; halves(mloc, m0_, m1_); mloc = fmaxf(m0_, m1_) * a.scale_log2; }      // scale > 0: max commutes with the scaling
         const float m_new = fmaxf(m_run, mloc);
         const bool grew = m_new > m_run;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -244,7 +253,9 @@ __global__ __launch_bounds__(NW * 64, (D <= 64 && NW == 4) ? 3 : 1) void attn_ke
             }
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l0_, l1_;
+    halves(l_run, l0_, l1_);
+    const float l_tot = l0_ + l1_;
     const float inv = 1.0f / l_tot;
     const int qr = q0 + r;
     if (qr < a.Nq) {
