@@ -85,6 +85,7 @@ class ShardedTracker:
         self.scan = world > 1 or force_collective or os.environ.get("CUT3R_SCAN", "0") == "1"
         self.replicate_depth = os.environ.get("CUT3R_REPLICATE_DEPTH", "0") == "1"
         self._chain = None
+        self._f0 = 0
         slam.tracked_only = True          # trajectory writers stop at the last TRACKED keyframe (the look-ahead registers more)
         self.stats = {"append_s": 0.0, "issue_s": 0.0, "issue_enc_s": 0.0, "replay_s": 0.0, "replay_wait_s": 0.0, "exchange_s": 0.0, "steps": 0}     # host wall-clock per phase
 
@@ -94,8 +95,9 @@ class ShardedTracker:
 
     # ---- default callbacks on the real SLAM objects
     def _append(self, kf_index: int, frame, tstamp, intr, mine: bool):
-        # fixed cadence: the encoder pass of a keyframe is deferred to the rank that owns its window
-        self.slam.keyframes.append(tstamp, frame[0], None, None, None, None, intr, None, None)
+        # fixed cadence: the encoder pass of a keyframe is deferred to the rank that owns its window; the other ranks register the
+        # keyframe (time stamp, calibration, counter) without copying pixels they never read (at 8 GPUs: 7 of 8 keyframes)
+        self.slam.keyframes.append(tstamp, frame[0] if (mine and frame is not None) else None, None, None, None, None, intr, None, None)
 
     def _encode(self, ranges):
         """encoder pass over this rank's not-yet-encoded keyframes (batched) -> window features [wb,V,N,E]"""
@@ -243,8 +245,14 @@ class ShardedTracker:
         for f in range(max(t, self._appended_upto), t + n_frames):
             if f % kf_every == 0:
                 k = slam.keyframes.counter.value
-                owner = min(max((k - first_t0 - 1) // (win * wb), 0), world - 1) if k > first_t0 else 0
-                self.append_fn(k, frames[f:f + 1], f, intr, owner == rank)
+                # which ranks read this keyframe's pixels: the owner of its window (windows are dealt to the ranks in blocks of wb,
+                # step after step: keyframe F0 + o lies in window (o - 1) // win), and -- when it is the last keyframe of a rank's
+                # block -- also the next rank (of this or the next step), whose first window starts with it.  Keyframes are appended
+                # up to two ahead of the step that tracks them, so the rule is absolute, not relative to the step being issued.
+                o = k - self._f0
+                blk = (o - 1) // (win * wb) if o >= 1 else 0
+                mine = blk % world == rank or (o >= 1 and o % (win * wb) == 0 and (blk + 1) % world == rank)
+                self.append_fn(k, frames[f:f + 1] if mine else None, f, intr, mine)
         self._appended_upto = max(self._appended_upto, t + n_frames)
 
     def step(self, frames, t, kf_every, win, intr):
@@ -252,6 +260,7 @@ class ShardedTracker:
         slam, world, rank, wb = self.slam, self.world, self.rank, self.wb
         if self._next_t0 is None:
             self._next_t0 = slam.tracker.t1 - 1
+            self._f0 = self._next_t0          # first keyframe of the first window this driver schedules
         first_t0 = self._next_t0
         ranges_all = window_ranges(first_t0, world * wb, win)
         mine = ranges_all[rank * wb:(rank + 1) * wb]

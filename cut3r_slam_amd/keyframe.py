@@ -142,7 +142,8 @@ class KeyFrame:
             raise IndexError(f"keyframe buffer overflow ({self.buffer}); raise --buffer")
         self._counter = i + 1
         self.tstamp[i] = float(tstamp)
-        self.image[i].copy_(image.to(self.device, non_blocking=True))
+        if image is not None:            # (None: a keyframe another rank encodes -- registered, its pixels never read here)
+            self.image[i].copy_(image.to(self.device, non_blocking=True))
         if pose is not None:
             self.set_pose(i, pose)
         if depth is not None:

@@ -112,7 +112,10 @@ def test_sharded_tracker_world2_gloo():
     assert t0 == t1 == 61 + 2 * 2 * 50 and t1_0 == t1_1 == 26
     # every keyframe is registered on every rank, encoded by exactly one
     assert [(k, ts) for k, ts, _ in app0] == [(k, ts) for k, ts, _ in app1] == [(7 + i, 70 + 10 * i) for i in range(20)]
-    assert all(m0 != m1 for (_, _, m0), (_, _, m1) in zip(app0, app1))
+    # `mine` = this rank needs the keyframe's pixels: its own windows' keyframes, plus the keyframe its first window shares with the
+    # previous rank's last window (rank 1: k = 10, 20) and, for rank 0, the step's last keyframe = the first of its next step (k = 15, 25)
+    for (k, _, m0), (_, _, m1) in zip(app0, app1):
+        assert (m0 and m1) if k in (10, 15, 20, 25) else (m0 != m1), (k, m0, m1)
     # software pipeline: the network pass of step 2 is issued BEFORE step 1 is replayed; flush() drains the last step
     assert lag0 == lag1 == [0, 0] and nb0 == nb1 == 2
 
@@ -127,7 +130,10 @@ def test_sharded_tracker_world2_window_batch2():
     assert [v for _, _, v, _ in trk0] == [a + 100 * o for (a, _), o in zip(want, [0, 0, 1, 1, 0, 0, 1, 1])]
     assert t0 == t1 == 61 + 2 * 4 * 50 and t1_0 == t1_1 == 46
     assert [(k, ts) for k, ts, _ in app0] == [(k, ts) for k, ts, _ in app1] == [(7 + i, 70 + 10 * i) for i in range(40)]
-    assert all(m0 != m1 for (_, _, m0), (_, _, m1) in zip(app0, app1))
+    # `mine` = this rank needs the keyframe's pixels: its own windows' keyframes, plus the keyframe its first window shares with the
+    # previous rank's last window (blocks of wb * 5 = 10 keyframes: k = 15, 35 for rank 1) and, for rank 0, the step's last keyframe = the first of its next step (k = 25, 45)
+    for (k, _, m0), (_, _, m1) in zip(app0, app1):
+        assert (m0 and m1) if k in (15, 25, 35, 45) else (m0 != m1), (k, m0, m1)
     # keyframes 7..16 belong to rank 0's two windows of step 1 (the shared keyframe 5/6 were initialised earlier)
     assert [m for k, _, m in app0 if k <= 15] == [True] * 9
     assert nb0 == 4
