@@ -107,8 +107,12 @@ class FactorGraph:
     # ------------------------------------------------------------------ edge maintenance
     @staticmethod
     def _as_list(x):
+        if isinstance(x, list):                      # (the graph's own callers pass int lists: no numpy round trip)
+            return x
         if isinstance(x, torch.Tensor):
             return [int(v) for v in x.reshape(-1).tolist()]
+        if isinstance(x, np.ndarray) and x.dtype.kind in "iu":
+            return x.reshape(-1).tolist()
         return [int(v) for v in np.asarray(x).reshape(-1).tolist()]
 
     def add_factors(self, ii, jj, remove=False):
