@@ -251,6 +251,35 @@ class FactorGraph:
             out.append((tk, counts_host[i - t0, 0, :i], counts_host[i - t0, 1, :i]))
         return out
 
+    def window_decide(self, r0, r1, centres, counts, npix_f, npix_b, init, first=3):
+        """The decisions of a whole window in one pass: what `window_tickets` + `add_neighborhood_factors` + `add_finish` do keyframe
+        by keyframe (factor_graph.py:109-117, 170-197), with the distance classes and ratio tests of the window's keyframes evaluated
+        as ONE set of array operations (the multi-GPU replay decides hundreds of windows per step on the host).  Same float32
+        operations per element, same insertion order, same ages.  counts: int32 [V, 2, >= r1] (forward | backward rows)."""
+        V = r1 - r0
+        c = np.asarray(centres[:r1], np.float32)
+        d = c[None, :, :] - c[r0:r1][:, None, :]
+        dists = np.sqrt((d * d).sum(axis=2, dtype=np.float32), dtype=np.float32)
+        cond1 = dists <= np.float32(1.0)
+        hit_f = (counts[:V, 0, :r1].astype(np.float32) / np.float32(npix_f)) > np.float32(0.3)
+        hit_b = (counts[:V, 1, :r1].astype(np.float32) / np.float32(npix_b)) > np.float32(0.3)
+        sel1 = cond1 & hit_f
+        sel2 = ~cond1 & (hit_f | hit_b)
+        for v in range(V):
+            i = r0 + v
+            if not init:
+                self.add_neighborhood_factors(i - 3, i + 1, r=3)
+            if i >= first:
+                for sel in (sel1, sel2):
+                    jj = np.nonzero(sel[v, :i])[0]
+                    if jj.size:
+                        jl = jj.tolist()
+                        il = [i] * len(jl)
+                        self.add_factors(il, jl)
+                        self.add_factors(jl, il)
+                self._epoch += 1
+                self._cache = None
+
     @staticmethod
     def read_counts(tickets):
         """single device->host hop for the counts of any number of tickets -> [(cf, cb|None)]"""

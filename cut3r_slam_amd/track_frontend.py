@@ -431,12 +431,11 @@ class TrackFrontend:
         def finish():
             for k, (t0, t1) in enumerate(ranges):
                 b0 = bases[k]
-                r0, r1 = t0 - b0, t1 - b0
-                done = {}
-                if r1 - 1 >= 3:
-                    for tk, cf, cb in graph.window_tickets(r0, r1, cent[k], total[k, :t1 - t0], H * W, h * w):
-                        done[tk["idx"]] = (tk, cf.copy(), cb.copy())
-                self._decide(r0, r1, cut[k], done, b0)
+                if cut[k]:
+                    if b0 != graph.base:
+                        graph.begin_sequence(b0)
+                    graph.add_neighborhood_factors(0, 3, r=3)
+                graph.window_decide(t0 - b0, t1 - b0, cent[k], total[k, :t1 - t0], H * W, h * w, cut[k])
         if defer_decisions:
             return finish
         finish()

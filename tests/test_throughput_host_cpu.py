@@ -67,3 +67,33 @@ def test_graph_sequence_cuts_archive_absolute_edges():
     assert len(ii) == n0 + 6
     assert set(zip(ii[:n0].tolist(), jj[:n0].tolist())) >= {(4, 1), (5, 2), (0, 1)}
     assert set(zip(ii[n0:].tolist(), jj[n0:].tolist())) == {(15, 16), (15, 17), (16, 15), (16, 17), (17, 15), (17, 16)}
+
+
+def test_window_decide_equals_the_per_keyframe_decisions():
+    """FactorGraph.window_decide (one set of array operations per window: the multi-GPU replay) against window_tickets +
+    add_neighborhood_factors + add_finish keyframe by keyframe: same ordered edges, same ages."""
+    def run(vectorised):
+        rng = np.random.default_rng(0)
+        g = FactorGraph(None, device="cpu", max_factors=-1, backend=object())
+        g.add_neighborhood_factors(0, 3, r=3)
+        cent = rng.normal(0, 0.8, (70, 3)).astype(np.float32)
+        for w in range(11):
+            t0, init = (0, True) if w == 0 else (5 * w, False)
+            t1 = t0 + 6
+            counts = (rng.random((6, 2, 128)) * 100).astype(np.int32)
+            if vectorised:
+                g.window_decide(t0, t1, cent, counts, 200, 100, init)
+            else:
+                done = {}
+                for tk, cf, cb in g.window_tickets(t0, t1, cent, counts, 200, 100):
+                    done[tk["idx"]] = (tk, cf.copy(), cb.copy())
+                for i in range(t0, t1):
+                    if not init:
+                        g.add_neighborhood_factors(i - 3, i + 1, r=3)
+                    if i in done:
+                        g.add_finish(*done[i])
+        return g.edges_numpy()
+    a, b = run(False), run(True)
+    assert len(a[0]) > 1000
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
