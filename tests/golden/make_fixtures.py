@@ -6,6 +6,7 @@ Run only in the build container (needs /root/reference, which never travels):
     make -C oracle ref && python tests/golden/make_fixtures.py
 
 What is pinned here:
+  * model_medium_dpt.npz : the same for head widths 64 / 48 (`medium`)
   * model_tiny_{dpt,linear}.npz : reference `inference(views, ARCroco3DStereo, "cpu")` on a tiny config with
     seeded weights from cut3r_slam_amd.weights (weights are NOT stored: they are regenerated from the seed;
     this script asserts our key/shape schema equals the reference state_dict and loads with strict=True).
@@ -283,7 +284,7 @@ def gen_camera_fixture():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "nms", "camera"]
+    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera"]
     if "nms" in what:
         gen_nms_fixture()
     if "camera" in what:
@@ -296,3 +297,9 @@ if __name__ == "__main__":
         gen_model_fixture("model_tiny_dpt", tiny_config("dpt"), seed=3, n_views=3)
     if "linear" in what:
         gen_model_fixture("model_tiny_linear", tiny_config("linear"), seed=5, n_views=2)
+    if "medium" in what:
+        # the production head widths (64-wide encoder / image-side heads, 48-wide state-side heads) at a size the reference runs in
+        # seconds on the CPU: pins the oracle and the HIP path for those widths against the reference itself
+        gen_model_fixture("model_medium_dpt", Cut3rConfig(img_size=(64, 96), enc_embed_dim=256, enc_depth=3, enc_num_heads=4, dec_embed_dim=192,
+                                                          dec_depth=4, dec_num_heads=3, state_dec_num_heads=4, state_size=30, local_mem_size=16,
+                                                          ray_enc_depth=1, head_type="dpt", rgb_head=True), seed=11, n_views=3)

@@ -37,7 +37,7 @@ def _check(name, got, ref, tol, log, mask=None):
     assert e <= tol, "\n".join(log)
 
 
-@pytest.mark.parametrize("name", ["model_tiny_dpt", "model_tiny_linear"])
+@pytest.mark.parametrize("name", ["model_tiny_dpt", "model_tiny_linear", "model_medium_dpt"])
 def test_model_matches_reference_golden(name):
     f = np.load(os.path.join(GOLD, name + ".npz"))
     cfg = Cut3rConfig.from_dict(json.loads(bytes(f["config_json"]).decode()))

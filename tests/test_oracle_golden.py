@@ -20,13 +20,14 @@ def _load_model_fixture(name):
     return f, cfg, synth_state_dict(cfg, int(f["seed"]))
 
 
-@pytest.mark.parametrize("name", ["model_tiny_dpt", "model_tiny_linear"])
+@pytest.mark.parametrize("name", ["model_tiny_dpt", "model_tiny_linear", "model_medium_dpt"])
 def test_model_oracle_matches_reference(name):
     f, cfg, sd = _load_model_fixture(name)
     imgs = O.normalize(torch.from_numpy(f["imgs"]))
     feat, pos = O.encode_image(cfg, sd, imgs[:1])
     assert torch.equal(pos, torch.from_numpy(f["enc_pos0"]))
-    np.testing.assert_allclose(feat.numpy(), f["enc_feat0"], rtol=0, atol=2e-6)
+    # fp32 re-association only (the medium fixture's 256-wide encoder: 8e-6 of the feature scale; the tiny ones: 1e-6)
+    np.testing.assert_allclose(feat.numpy(), f["enc_feat0"], rtol=0, atol=2e-6 if "tiny" in name else 1e-5 * np.abs(f["enc_feat0"]).max())
     preds, states = O.forward_views(cfg, sd, imgs, return_states=True)
     for i, p in enumerate(preds):
         for k, v in p.items():
@@ -35,7 +36,7 @@ def test_model_oracle_matches_reference(name):
             assert np.abs(v.numpy() - g).max() <= 2e-5 * max(1.0, np.abs(g).max()), (i, k)
     for i, (s, m) in enumerate(states):
         np.testing.assert_allclose(s.numpy(), f[f"state{i}_feat"], atol=1e-5)
-        np.testing.assert_allclose(m.numpy(), f[f"state{i}_mem"], atol=2e-5)
+        np.testing.assert_allclose(m.numpy(), f[f"state{i}_mem"], atol=2e-5 if "tiny" in name else 1e-5 * np.abs(f[f"state{i}_mem"]).max())
     np.testing.assert_array_equal(O.state_positions(cfg).numpy(), f["state_pos"])
 
 
