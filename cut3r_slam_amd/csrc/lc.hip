@@ -6,8 +6,8 @@
 //   lc_accum : one streaming pass over the first/last pointmaps of every submap (2*B*N*12 bytes, HBM/L2 bound); each
 //              thread folds sign(residual) x [p;1] into the 3x4 gradient of both matrices of its pair in registers,
 //              wave-shuffle + LDS reduce, one partial row per block (deterministic: no float atomics).
-//   lc_adam  : one thread per submap: sums its partial rows in fixed order, pulls the 3x4 gradient back through
-//              matrix(exp(xi)) with forward-mode duals (lie_math.h), Adam step, writes the new 3x4 matrix.
+//   lc_adam  : one wave per submap: 12 lanes sum its partial rows in fixed order, the 3x4 gradient is pulled back through
+//              matrix(exp(xi)) with forward-mode duals (lie_math.h), Adam step, lane 0 writes the new 3x4 matrix.
 // Loss (identical to the reference):  mean_{masked (b,n), xyz} |T_b last_b - T_{b+1} first_{b+1}|
 //                                    + mean_{n, xyz} |T_{B-1} cur - cur_lc|,  T_0 = I fixed.
 #include "common.h"
@@ -84,28 +84,36 @@ __global__ __launch_bounds__(LC_BLOCK) void lc_accum_kernel(const float* __restr
 
 struct AdamHyper { float lr, b1, b2, eps; };
 
-// one thread per optimised submap b = 1..B-1  (b = 0 is the fixed identity)
-__global__ void lc_adam_kernel(const float* __restrict__ partial, int nblk, int B, float* __restrict__ xi, float* __restrict__ m,
-                               float* __restrict__ v, float* __restrict__ T, float* __restrict__ loss_out, int step, AdamHyper h) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// total loss of one iteration from the partial rows (column 24), fixed order: lane l sums rows l, l+64, ... and the 64 lane
+// sums are folded by wave_sum -- for logging / convergence tests only (it never feeds the optimiser)
+DEVINL void lc_loss_row(const float* __restrict__ partial, int rows, float* __restrict__ loss_out, int step) {
+    float L = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 64) L += partial[(size_t)r * LC_ROW + 24];
+    L = wave_sum(L);
+    if (threadIdx.x == 0) loss_out[step] = L;
+}
+
+// one wave per optimised submap b = 1..B-1  (b = 0 is the fixed identity; its wave reports the loss when asked to).
+// Lanes 0..11 each sum one gradient element over the partial rows in block order (the same order a single thread would
+// use), the 12 sums are broadcast and every lane carries the (tiny) dual-number pull-back; lane 0 writes.
+__global__ __launch_bounds__(64) void lc_adam_kernel(const float* __restrict__ partial, int nblk, int B, float* __restrict__ xi,
+                                                     float* __restrict__ m, float* __restrict__ v, float* __restrict__ T,
+                                                     float* __restrict__ loss_out, int step, AdamHyper h) {
+    const int b = blockIdx.x;
     if (b == 0) {
-        // total loss of this iteration (deterministic order) -- for logging / convergence tests
-        float L = 0.f;
-        for (int p = 0; p < B; p++)
-            for (int k = 0; k < nblk; k++) L += partial[((size_t)p * nblk + k) * LC_ROW + 24];
-        if (loss_out) loss_out[step] = L;
+        if (loss_out) lc_loss_row(partial, B * nblk, loss_out, step);
         return;
     }
-    if (b >= B) return;
     float G[12];
+    {
+        // 'a' role: pair b (b <= B-2: last_b; b == B-1: the current term); 'c' role: pair b-1
+        const int e = threadIdx.x < 12 ? threadIdx.x : 0;
+        const float* ra = partial + (size_t)b * nblk * LC_ROW + e;
+        const float* rc = partial + (size_t)(b - 1) * nblk * LC_ROW + 12 + e;
+        float g = 0.f;
+        for (int k = 0; k < nblk; k++) g += ra[(size_t)k * LC_ROW] + rc[(size_t)k * LC_ROW];
 #pragma unroll
-    for (int k = 0; k < 12; k++) G[k] = 0.f;
-    // 'a' role: pair b (b <= B-2: last_b; b == B-1: the current term); 'c' role: pair b-1
-    for (int k = 0; k < nblk; k++) {
-        const float* ra = partial + ((size_t)b * nblk + k) * LC_ROW;
-        const float* rc = partial + ((size_t)(b - 1) * nblk + k) * LC_ROW + 12;
-#pragma unroll
-        for (int e = 0; e < 12; e++) G[e] += ra[e] + rc[e];
+        for (int k = 0; k < 12; k++) G[k] = __shfl(g, k);
     }
     typedef Dual<6> D;
     D a[6], X[7], M[16];
@@ -114,7 +122,7 @@ __global__ void lc_adam_kernel(const float* __restrict__ partial, int nblk, int 
     f_exp<1, D>(a, X);
     f_matrix<1, D>(X, M);
     const float bc1 = 1.f - powf(h.b1, (float)(step + 1)), bc2 = 1.f - powf(h.b2, (float)(step + 1));
-    float nx[6];
+    float nx[6], nm[6], nv[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
         float g = 0.f;
@@ -124,17 +132,20 @@ __global__ void lc_adam_kernel(const float* __restrict__ partial, int nblk, int 
             for (int c = 0; c < 4; c++) g += G[r * 4 + c] * M[r * 4 + c].d[j];
         const float mj = h.b1 * m[(size_t)b * 6 + j] + (1.f - h.b1) * g;
         const float vj = h.b2 * v[(size_t)b * 6 + j] + (1.f - h.b2) * g * g;
-        m[(size_t)b * 6 + j] = mj;
-        v[(size_t)b * 6 + j] = vj;
+        nm[j] = mj;
+        nv[j] = vj;
         // torch.optim.Adam: step_size = lr / bc1 ; denom = sqrt(v)/sqrt(bc2) + eps
         nx[j] = xi[(size_t)b * 6 + j] - (h.lr / bc1) * mj / (sqrtf(vj) / sqrtf(bc2) + h.eps);
-        xi[(size_t)b * 6 + j] = nx[j];
     }
     float Xf[7], Mf[16];
     f_exp<1, float>(nx, Xf);
     f_matrix<1, float>(Xf, Mf);
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < 12; k++) T[(size_t)b * 12 + k] = Mf[k];
+        for (int j = 0; j < 6; j++) { m[(size_t)b * 6 + j] = nm[j]; v[(size_t)b * 6 + j] = nv[j]; xi[(size_t)b * 6 + j] = nx[j]; }
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[(size_t)b * 12 + k] = Mf[k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ general term list
@@ -192,36 +203,32 @@ __global__ __launch_bounds__(LC_BLOCK) void lc_terms_accum_kernel(const LcTerm* 
     }
 }
 
-// one thread per transform p = 1..P-1 (p = 0 is the fixed identity and reports the loss)
-__global__ void lc_terms_adam_kernel(const LcTerm* __restrict__ terms, int n_terms, const float* __restrict__ partial, int nblk, int P,
-                                     float* __restrict__ xi, float* __restrict__ m, float* __restrict__ v, float* __restrict__ T,
-                                     float* __restrict__ loss_out, int step, AdamHyper h) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per transform p = 1..P-1 (p = 0 is the fixed identity and reports the loss): lanes 0..11 gather, in term order,
+// the partial rows of the terms that reference p
+__global__ __launch_bounds__(64) void lc_terms_adam_kernel(const LcTerm* __restrict__ terms, int n_terms, const float* __restrict__ partial,
+                                                           int nblk, int P, float* __restrict__ xi, float* __restrict__ m,
+                                                           float* __restrict__ v, float* __restrict__ T, float* __restrict__ loss_out,
+                                                           int step, AdamHyper h) {
+    const int b = blockIdx.x;
     if (b == 0) {
-        float L = 0.f;
-        for (int t = 0; t < n_terms; t++)
-            for (int k = 0; k < nblk; k++) L += partial[((size_t)t * nblk + k) * LC_ROW + 24];
-        if (loss_out) loss_out[step] = L;
+        if (loss_out) lc_loss_row(partial, n_terms * nblk, loss_out, step);
         return;
     }
-    if (b >= P) return;
     float G[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) G[k] = 0.f;
-    for (int t = 0; t < n_terms; t++) {
-        const int ia = terms[t].ia, ic = terms[t].ic;
-        if (ia != b && ic != b) continue;
-        for (int k = 0; k < nblk; k++) {
-            const float* row = partial + ((size_t)t * nblk + k) * LC_ROW;
-            if (ia == b) {
-#pragma unroll
-                for (int e = 0; e < 12; e++) G[e] += row[e];
-            }
-            if (ic == b) {
-#pragma unroll
-                for (int e = 0; e < 12; e++) G[e] += row[12 + e];
+    {
+        const int e = threadIdx.x < 12 ? threadIdx.x : 0;
+        float g = 0.f;
+        for (int t = 0; t < n_terms; t++) {
+            const int ia = terms[t].ia, ic = terms[t].ic;
+            if (ia != b && ic != b) continue;
+            const float* row = partial + (size_t)t * nblk * LC_ROW + e;
+            for (int k = 0; k < nblk; k++) {
+                if (ia == b) g += row[(size_t)k * LC_ROW];
+                if (ic == b) g += row[(size_t)k * LC_ROW + 12];
             }
         }
+#pragma unroll
+        for (int k = 0; k < 12; k++) G[k] = __shfl(g, k);
     }
     typedef Dual<6> D;
     D a[6], X[7], M[16];
@@ -230,7 +237,7 @@ __global__ void lc_terms_adam_kernel(const LcTerm* __restrict__ terms, int n_ter
     f_exp<1, D>(a, X);
     f_matrix<1, D>(X, M);
     const float bc1 = 1.f - powf(h.b1, (float)(step + 1)), bc2 = 1.f - powf(h.b2, (float)(step + 1));
-    float nx[6];
+    float nx[6], nm[6], nv[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
         float g = 0.f;
@@ -240,16 +247,19 @@ __global__ void lc_terms_adam_kernel(const LcTerm* __restrict__ terms, int n_ter
             for (int c = 0; c < 4; c++) g += G[r * 4 + c] * M[r * 4 + c].d[j];
         const float mj = h.b1 * m[(size_t)b * 6 + j] + (1.f - h.b1) * g;
         const float vj = h.b2 * v[(size_t)b * 6 + j] + (1.f - h.b2) * g * g;
-        m[(size_t)b * 6 + j] = mj;
-        v[(size_t)b * 6 + j] = vj;
+        nm[j] = mj;
+        nv[j] = vj;
         nx[j] = xi[(size_t)b * 6 + j] - (h.lr / bc1) * mj / (sqrtf(vj) / sqrtf(bc2) + h.eps);
-        xi[(size_t)b * 6 + j] = nx[j];
     }
     float Xf[7], Mf[16];
     f_exp<1, float>(nx, Xf);
     f_matrix<1, float>(Xf, Mf);
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < 12; k++) T[(size_t)b * 12 + k] = Mf[k];
+        for (int j = 0; j < 6; j++) { m[(size_t)b * 6 + j] = nm[j]; v[(size_t)b * 6 + j] = nv[j]; xi[(size_t)b * 6 + j] = nx[j]; }
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[(size_t)b * 12 + k] = Mf[k];
+    }
 }
 
 // in-place p <- T_b p over every pointmap of submap b (the rewrite at track_backend.py:306-310)
@@ -284,7 +294,7 @@ extern "C" int cut3r_lc_optimize(const float* first, const float* last, long lon
     for (int it = 0; it < iters; it++) {
         hipLaunchKernelGGL(lc_accum_kernel, dim3(nblk, B), dim3(LC_BLOCK), 0, s, first, last, sub_stride, mask, cur, cur_lc, T, B, N,
                            w_fl, w_cur, workspace, nblk);
-        hipLaunchKernelGGL(lc_adam_kernel, dim3((B + 63) / 64), dim3(64), 0, s, workspace, nblk, B, xi, adam_m, adam_v, T, loss_out, it, h);
+        hipLaunchKernelGGL(lc_adam_kernel, dim3(B), dim3(64), 0, s, workspace, nblk, B, xi, adam_m, adam_v, T, loss_out, it, h);
     }
     return cut3r_check_launch();
 }
@@ -300,7 +310,7 @@ extern "C" int cut3r_lc_optimize_terms(const void* terms_dev, int n_terms, int P
     const LcTerm* terms = (const LcTerm*)terms_dev;
     for (int it = 0; it < iters; it++) {
         hipLaunchKernelGGL(lc_terms_accum_kernel, dim3(nblk, n_terms), dim3(LC_BLOCK), 0, s, terms, T, N, workspace, nblk);
-        hipLaunchKernelGGL(lc_terms_adam_kernel, dim3((P + 63) / 64), dim3(64), 0, s, terms, n_terms, workspace, nblk, P, xi, adam_m, adam_v, T,
+        hipLaunchKernelGGL(lc_terms_adam_kernel, dim3(P), dim3(64), 0, s, terms, n_terms, workspace, nblk, P, xi, adam_m, adam_v, T,
                            loss_out, it, h);
     }
     return cut3r_check_launch();
