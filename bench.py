@@ -10,7 +10,7 @@ feature numerics), `--window-batch` (default 28) tracking windows pushed through
 window_batch steady-state windows = window_batch*50 frames: each new keyframe through the encoder once, 6-view recurrent
 decoder + DPT head per window, chaining/alignment + covisibility-graph update per keyframe (hislam2/hi2.py:101-133 without
 the GS mapper).  The stream is a succession of Replica-shaped SEQUENCES (`--sequence-windows`, default 40 windows = 2000 frames,
-times the number of GPUs): the last keyframe of a sequence is keyframe 0 of the next one, whose first window is handled like the
+whatever the number of GPUs): the last keyframe of a sequence is keyframe 0 of the next one, whose first window is handled like the
 reference's initialisation window, with an empty covisibility graph (TrackFrontend.sequence_windows: every sequence equals a
 fresh run over its frames, tests/test_slam_gpu.py).  One resident recording is read cyclically; frames are in HBM before the
 timed region.  value = frames of all ranks / max-over-ranks time.
@@ -371,8 +371,10 @@ def main():
     ap.add_argument("--no-operating-points", action="store_true")
     ap.add_argument("--no-trajectory-parity", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: tiny network (NOT a valid benchmark line)")
-    ap.add_argument("--sequence-windows", type=int, default=40, help="windows per sequence and GPU (40 = a Replica-shaped 2000-frame "
-                    "sequence at kf_every=10; multiplied by the number of GPUs); 0 = one endless stream")
+    ap.add_argument("--sequence-windows", type=int, default=40, help="windows per sequence (40 = a Replica-shaped 2000-frame sequence at "
+                    "kf_every=10, whatever the number of GPUs: a bigger job runs through more sequences per step); 0 = one endless stream")
+    ap.add_argument("--sequence-per-gpu", action="store_true", help="multiply --sequence-windows by the number of GPUs (sequences that grow "
+                    "with the job: the covisibility test of a keyframe then grows with it too)")
     ap.add_argument("--window-batch", type=int, default=28, help="tracking windows pushed through the decoder together "
                     "(buffered-stream throughput mode; 1 = the reference's one-window-at-a-time schedule)")
     args = ap.parse_args()
@@ -427,7 +429,9 @@ def main():
     single = rank == 0 and world == 1 and emu <= 1 and not dist_on
     probe_steps = args.steps if (single and not args.no_roofline) else 0
     log("fixed-cadence leg: initialisation window, warmup, timed region")
-    SEQ = max(0, args.sequence_windows) * world        # weak scaling: the sequence grows with the job (Replica room0 x world frames)
+    # weak scaling: every GPU adds 28 windows per step of the same Replica-shaped sequences (per-GPU work fixed: a keyframe is tested
+    # against the <= 200 keyframes of its own sequence); --sequence-per-gpu makes the sequences grow with the job instead
+    SEQ = max(0, args.sequence_windows) * (world if args.sequence_per_gpu else 1)
     leg = fixed_cadence_leg(model, Cut3rSlam, cdist, dev, WB, args.steps, args.warmup, world, rank, dist_on, emu, probe_steps, barrier,
                             seq_windows=SEQ)
     elapsed, slam, runner, frames, t, intr = (leg[k] for k in ("elapsed", "slam", "runner", "frames", "t", "intr"))

@@ -31,12 +31,12 @@ def _run(cmd, env, timeout=900):
 
 
 def test_two_ranks_on_one_gpu_match_each_other_and_a_single_rank(tmp_path):
-    # sequence cuts every 6 windows of the job (--sequence-windows is per GPU): windows 6 and 12 of the 13 start new sequences, one
+    # sequence cuts every 6 windows of the job: windows 6 and 12 of the 13 start new sequences, one
     # as the first window of a rank's batch, one inside it
     common = ["--small", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
     two = str(tmp_path / "two")
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--window-batch", "2", "--sequence-windows", "3"] + common,
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--window-batch", "2", "--sequence-windows", "6"] + common,
                {"CUT3R_DIST_BACKEND": "gloo", "CUT3R_DUMP_STATE": two, "CUT3R_REPLICATE_DEPTH": "1"})
     assert '"n_gpus": 2' in out
     one = str(tmp_path / "one")
