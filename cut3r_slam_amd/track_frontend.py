@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import math
 import time
+import warnings
 
 import numpy as np
 import torch
@@ -16,6 +17,14 @@ import torch
 from . import geom_host as gh
 from . import ops
 from .factor_graph import AlignedPoints, SubmapStore
+
+
+def _check_scale(t0, s):
+    """The reference takes torch.log of the predicted depths as they come (track_frontend.py:203-206): one depth <= 0 in the shared
+    keyframe makes the window scale NaN and every later pose with it, silently.  Same arithmetic here, plus a warning."""
+    if not math.isfinite(float(s)):
+        warnings.warn(f"window at keyframe {t0}: log-depth scale is {float(s)} (a predicted depth <= 0 in the shared keyframe); "
+                      "poses from this window on are not finite", RuntimeWarning, stacklevel=3)
 
 
 def make_views(model, images_u8):
@@ -126,6 +135,7 @@ class TrackFrontend:
         host, lsum = packed[:-1].astype(np.float32).reshape(2, 7), float(packed[-1])
         poses = gh.pose_encoding_to_camera(host)
         align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
+        _check_scale("of predict()", align_s)
         prev_c2w = gh.pose_vec_to_matrix(np.asarray(torch.as_tensor(kf_pose).cpu(), np.float32)[None])[0]
         pose = gh.chain_pose(gh.inv4(poses[0]), poses[1], prev_c2w[:3, :3], prev_c2w[:3, 3], align_s)
         pm = torch.empty(H // ds, W // ds, 3, device=self.device)
@@ -228,6 +238,7 @@ class TrackFrontend:
             align = None
             if not init_k:
                 align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
+                _check_scale(t0, align_s)
                 prev_c2w = gh.pose_vec_to_matrix(kf.pose[t0].numpy()[None])[0]
                 align = (prev_c2w[:3, :3], prev_c2w[:3, 3], align_s)
             # host: chained pose of every view, one vectorised matrix->quaternion conversion (the reference converts and
@@ -374,6 +385,9 @@ class TrackFrontend:
 
         encs = scal[:, 2:2 + 7 * V].reshape(n, V, 7).astype(np.float32)
         chained_all, s_all, vecs, rows_all = gh.chain_windows(encs, scale_of, kf.pose[ranges[0][0]].numpy(), reset=cut)
+        if not np.isfinite(s_all).all():
+            k_bad = int(np.flatnonzero(~np.isfinite(s_all))[0])
+            _check_scale(ranges[k_bad][0], s_all[k_bad])
         cent = []
         for k, (t0, t1) in enumerate(ranges):                 # later windows overwrite the shared keyframe, as track() does
             kf.pose[t0:t1] = torch.from_numpy(vecs[k])

@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -97,3 +98,14 @@ def test_window_decide_equals_the_per_keyframe_decisions():
     assert len(a[0]) > 1000
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
+
+
+def test_non_finite_window_scale_warns():
+    """hislam2/track_frontend.py:203-206 takes log of the depths as predicted; a NaN scale is kept (same arithmetic) but reported"""
+    import warnings
+    from cut3r_slam_amd.track_frontend import _check_scale
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _check_scale(5, np.float32(1.25))                      # finite: silent
+    with pytest.warns(RuntimeWarning, match="keyframe 10"):
+        _check_scale(10, np.float32("nan"))
