@@ -32,7 +32,8 @@ def _drifting_submaps(B, h, w, seed):
     return sub, mask, cur, cur_lc, drift
 
 
-@pytest.mark.parametrize("B,h,w,iters", [(4, 24, 32, 300), (9, 48, 64, 200), (2, 8, 12, 150)])
+@pytest.mark.parametrize("B,h,w,iters", [(4, 24, 32, 300), (9, 48, 64, 200), (2, 8, 12, 150),
+                                          (12, 192, 256, 100)])       # the last: production map size (stride-2 of 384x512)
 def test_fused_adam_follows_reference_optimiser(B, h, w, iters):
     sub, mask, cur, cur_lc, drift = _drifting_submaps(B, h, w, B)
     xi_ref, T_ref, losses = LO.loop_closure_init(sub, mask, cur, cur_lc, iters)
