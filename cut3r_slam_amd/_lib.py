@@ -102,6 +102,7 @@ SIGNATURES = {
     "cut3r_ba_backsub": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "cut3r_ba_proj_trans": [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 4,
     "cut3r_bi_inter": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "cut3r_depth_filter": [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_void_p],
     "cut3r_altcorr_forward": [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p],
     "cut3r_altcorr_backward": [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p, c_void_p],
     "cut3r_ba_step": [c_void_p] * 12 + [c_int] * 6 + [c_float, c_float] + [c_void_p] * 5,

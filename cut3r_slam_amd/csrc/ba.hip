@@ -405,6 +405,48 @@ __global__ __launch_bounds__(256) void bi_inter_kernel(const float* __restrict__
     vals[p] = v;
 }
 
+// ------------------------------------------------------------------------------------------------ depth_filter
+// droid_backends.depth_filter (call site hislam2/util/droid_visualization.py:100; droid_backends itself is absent from the
+// reference tree: restated from the published DROID-SLAM kernel `depth_filter_kernel`, src/droid_kernels.cu).  For frame
+// ix = inds[m] and each of its six neighbours jx in {ix-1, ix-2, ix-3, ix+3, ix+4, ix+5} (upstream's `neigh < 3 ? ix - neigh - 1 :
+// ix + neigh`) inside [0, n): a pixel is carried into jx with the relative pose T_j T_i^-1 and its inverse depth; it counts
+// once for that neighbour when its depth agrees within thresh[m] with one of the four stored depths around the landing point.
+// count [M,ht,wd] float, whole numbers.  One thread per (m, pixel) walks the six neighbours: no atomics.
+__global__ __launch_bounds__(256) void depth_filter_kernel(const float* __restrict__ poses, const float* __restrict__ disps,
+                                                           const float* __restrict__ intr, const long long* __restrict__ inds,
+                                                           const float* __restrict__ thresh, int n, int ht, int wd,
+                                                           float* __restrict__ count) {
+    const int m = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= ht * wd) return;
+    const int i = p / wd, j = p - i * wd;
+    const int ix = (int)inds[m];
+    const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+    const float t = thresh[m];
+    const size_t HW = (size_t)ht * wd;
+    const float di = disps[(size_t)ix * HW + p];
+    const float Xi[4] = {((float)j - cx) / fx, ((float)i - cy) / fy, 1.f, di};
+    float Ti_inv[7];
+    f_inv<1, float>(poses + (size_t)ix * 7, Ti_inv);
+    float c = 0.f;
+    for (int neigh = 0; neigh < 6; neigh++) {
+        const int jx = neigh < 3 ? ix - neigh - 1 : ix + neigh;
+        if (jx < 0 || jx >= n) continue;
+        float Tij[7], Xj[4];
+        f_mul<1, float>(poses + (size_t)jx * 7, Ti_inv, Tij);
+        f_act<1, float>(Tij, Xi, 4, Xj);
+        const float uj = fx * (Xj[0] / Xj[2]) + cx, vj = fy * (Xj[1] / Xj[2]) + cy, dj = Xj[3] / Xj[2];
+        const float fu = floorf(uj), fv = floorf(vj);
+        if (!(fu >= 0.f && fv >= 0.f && fu < (float)(wd - 1) && fv < (float)(ht - 1))) continue;
+        const int u0 = (int)fu, v0 = (int)fv;
+        const float* dn = disps + (size_t)jx * HW + (size_t)v0 * wd + u0;
+        const float zi = 1.f / dj;
+        if (fabsf(zi - 1.f / dn[0]) < t || fabsf(zi - 1.f / dn[1]) < t || fabsf(zi - 1.f / dn[wd]) < t || fabsf(zi - 1.f / dn[wd + 1]) < t)
+            c += 1.f;
+    }
+    count[(size_t)m * HW + p] = c;
+}
+
 // ------------------------------------------------------------------------------------------------ alt-corr (modules/corr.py:74-139)
 // fmap1 [BN,H,W,C], fmap2 [BN,H2,W2,C], coords [BN,S,H,W,2] (x,y in fmap2 pixels) -> corr [BN,S,(2r+1)^2,H,W]:
 // corr[n,s,(i,j),y,x] = sum_c fmap1[n,y,x,c] * bilinear(fmap2[n])(coords + (i - r, j - r))[c]  (x offset = i, y offset = j,
@@ -609,6 +651,14 @@ extern "C" int cut3r_bi_inter(const float* scales, const float* grid, int M, int
     const size_t tot = (size_t)M * ht * wd;
     hipLaunchKernelGGL(bi_inter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scales, grid, M, hs, ws, ht * wd,
                        vals, J);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_depth_filter(const float* poses, const float* disps, const float* intr, const long long* inds, const float* thresh, int n,
+                                  int M, int ht, int wd, float* count, void* stream) {
+    if (!poses || !disps || !intr || !inds || !thresh || !count || n <= 0 || M <= 0 || ht <= 1 || wd <= 1) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(depth_filter_kernel, dim3((unsigned)((ht * wd + 255) / 256), (unsigned)M), dim3(256), 0, (hipStream_t)stream, poses, disps,
+                       intr, inds, thresh, n, ht, wd, count);
     return cut3r_check_launch();
 }
 

@@ -1,9 +1,9 @@
 """`droid_backends` module surface (the reference's setup.py target whose CUDA sources are absent: SURVEY F5) on the
 gfx950 kernels.  Call sites: hislam2/modules/corr.py:12,19 (corr_index_forward/backward).
 
-Implemented: corr_index_forward / backward, altcorr_forward / backward (+ AltCorrBlock), bi_inter, proj_trans, iproj.
-`depth_filter` (a point-cloud filter of the Open3D viewer, hislam2/util/droid_visualization.py:100) raises
-NotImplementedError: visualisation is out of scope.
+Implemented: corr_index_forward / backward, altcorr_forward / backward (+ AltCorrBlock), bi_inter, proj_trans, iproj,
+depth_filter (the point-cloud filter of the Open3D viewer, hislam2/util/droid_visualization.py:100; the viewer itself is out
+of scope).
 """
 from __future__ import annotations
 
@@ -173,10 +173,20 @@ class AltCorrBlock:
         return corr.contiguous()
 
 
-def _missing(name):
-    def f(*a, **k):
-        raise NotImplementedError(f"droid_backends.{name}: not reachable from any live or BA path of the reference; see DESIGN.md section 7")
-    return f
-
-
-depth_filter = _missing("depth_filter")        # only the Open3D viewer (hislam2/util/droid_visualization.py:100) calls it
+def depth_filter(poses, disps, intrinsics, ix, thresh):
+    """poses [n,7] (world->camera SE3 data), disps [n,ht,wd], intrinsics [4], ix [M] int64 frame indices, thresh [M] ->
+    count [M,ht,wd] float: the number of neighbour frames {ix-1, ix-2, ix-3, ix+3, ix+4, ix+5} that confirm each pixel's depth
+    (call site hislam2/util/droid_visualization.py:98-104: `count >= 2` keeps a point)."""
+    n, ht, wd = disps.shape
+    poses, disps = poses[:n].contiguous().float(), disps.contiguous().float()
+    ix = ix.to(disps.device, torch.int64).contiguous()
+    M = ix.numel()
+    count = torch.zeros(M, ht, wd, device=disps.device)
+    if M == 0:
+        return count
+    if int(ix.min()) < 0 or int(ix.max()) >= n:
+        raise IndexError("depth_filter: frame index out of range")
+    intr = intrinsics.reshape(-1)[:4].to(disps.device, torch.float32).contiguous()
+    thresh = thresh.to(disps.device, torch.float32).contiguous()
+    check(_lib.load().cut3r_depth_filter(_p(poses), _p(disps), _p(intr), _p(ix), _p(thresh), n, M, ht, wd, _p(count), _s()), "depth_filter")
+    return count

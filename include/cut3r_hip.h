@@ -287,6 +287,12 @@ int cut3r_ba_proj_trans(const float* Gij, const float* disps, const float* intr,
 /* droid_backends.bi_inter (call site hislam2/geom/ba.py:167): bilinear interpolation of per-frame scale grids scales [M,hs,ws] at
  * grid [M,ht,wd,2] (x, y) -> vals [M,ht,wd] and the dense Jacobian J [M,ht,wd,hs*ws] w.r.t. the grid nodes. */
 int cut3r_bi_inter(const float* scales, const float* grid, int M, int hs, int ws, int ht, int wd, float* vals, float* J, void* stream);
+/* droid_backends.depth_filter (call site hislam2/util/droid_visualization.py:100; the extension is absent from the reference tree,
+ * semantics from the published DROID-SLAM kernel): poses [n,7] world->camera SE3 data (t, q_xyzw), disps [n,ht,wd] inverse depths,
+ * intr [4] (fx, fy, cx, cy), inds [M] int64 frame indices (each must lie in [0, n): checked by the Python mirror), thresh [M] ->
+ * count [M,ht,wd]: in how many of the six neighbour frames {ix-1, ix-2, ix-3, ix+3, ix+4, ix+5} the pixel's depth is confirmed. */
+int cut3r_depth_filter(const float* poses, const float* disps, const float* intr, const long long* inds, const float* thresh, int n, int M,
+                       int ht, int wd, float* count, void* stream);
 /* droid_backends.altcorr_forward / altcorr_backward (call sites hislam2/modules/corr.py:79,87): on-the-fly correlation of fmap1
  * [BN,H,W,C] with fmap2 [BN,H2,W2,C] sampled bilinearly in a (2r+1)^2 window around coords [BN,S,H,W,2] ->
  * corr [BN,S,(2r+1)^2,H,W]; backward gives the gradients w.r.t. both feature maps (coords get none). */

@@ -238,3 +238,45 @@ def altcorr_ref(fmap1, fmap2, coords, r):
         c = coords[:, s].permute(0, 3, 1, 2)                       # [BN,2,H,W] (x,y)
         outs.append(corr_lookup(vol, c, r).reshape(BN, rd * rd, H, W))
     return torch.stack(outs, 1)
+
+
+def depth_filter_ref(poses7, disps, intr, inds, thresh):
+    """droid_backends.depth_filter (call site /root/reference/hislam2/util/droid_visualization.py:100), restated in fp64 from the
+    published DROID-SLAM kernel (src/droid_kernels.cu `depth_filter_kernel`; the extension is absent from the reference tree:
+    PARITY UNPINNED).  Returns (count [M,ht,wd], margin [M,ht,wd]): margin = the smallest | |1/dj - 1/d| - thresh | met, so a test
+    can leave out pixels whose decision sits on an fp32 rounding."""
+    disps = np.asarray(disps, np.float64)
+    n, ht, wd = disps.shape
+    G = se3_matrix(poses7).numpy()
+    fx, fy, cx, cy = [float(v) for v in np.asarray(intr).reshape(-1)[:4]]
+    y, x = np.meshgrid(np.arange(ht, dtype=np.float64), np.arange(wd, dtype=np.float64), indexing="ij")
+    M = len(inds)
+    count = np.zeros((M, ht, wd))
+    margin = np.full((M, ht, wd), np.inf)
+    for m, ix in enumerate(int(v) for v in inds):
+        Xi = np.stack([(x - cx) / fx, (y - cy) / fy, np.ones_like(x), disps[ix]], -1).reshape(-1, 4)
+        for neigh in range(6):
+            jx = ix - neigh - 1 if neigh < 3 else ix + neigh
+            if jx < 0 or jx >= n:
+                continue
+            Xj = Xi @ (G[jx] @ np.linalg.inv(G[ix])).T
+            with np.errstate(divide="ignore", invalid="ignore"):
+                uj, vj, dj = fx * Xj[:, 0] / Xj[:, 2] + cx, fy * Xj[:, 1] / Xj[:, 2] + cy, Xj[:, 3] / Xj[:, 2]
+                u0, v0 = np.floor(uj), np.floor(vj)
+                inside = (u0 >= 0) & (v0 >= 0) & (u0 < wd - 1) & (v0 < ht - 1)
+                # a landing point within 1e-4 px of a pixel edge may floor differently in fp32: flag it through the margin
+                edge = np.minimum(np.abs(uj - np.round(uj)), np.abs(vj - np.round(vj)))
+                u0c, v0c = np.clip(np.nan_to_num(u0), 0, wd - 2).astype(int), np.clip(np.nan_to_num(v0), 0, ht - 2).astype(int)
+                hit = np.zeros(ht * wd, bool)
+                mg = np.full(ht * wd, np.inf)
+                for dv in (0, 1):
+                    for du in (0, 1):
+                        e = np.abs(1.0 / dj - 1.0 / disps[jx][v0c + dv, u0c + du])
+                        hit |= e < thresh[m]
+                        mg = np.minimum(mg, np.abs(e - thresh[m]))
+            hit &= inside
+            mg = np.where(inside, mg, np.inf)
+            mg = np.where(edge < 1e-4, 0.0, mg)
+            count[m] += hit.reshape(ht, wd)
+            margin[m] = np.minimum(margin[m], mg.reshape(ht, wd))
+    return count, margin

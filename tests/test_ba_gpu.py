@@ -200,3 +200,32 @@ def test_edge_sharded_ba_sums_to_the_full_system():
     sc = float(info["S"].abs().max())
     np.testing.assert_allclose(S.cpu().numpy(), info["S"].cpu().numpy(), atol=2e-5 * sc)
     np.testing.assert_allclose(vS.cpu().numpy(), info["vS"].cpu().numpy(), atol=2e-5 * float(info["vS"].abs().max()))
+
+
+def test_depth_filter_counts_match_restatement():
+    """droid_backends.depth_filter (droid_visualization.py:100): per-pixel count of confirming neighbour frames, whole numbers; pixels
+    whose decision sits on an fp32 rounding of the threshold test (margin < 5e-5) are left out of the comparison"""
+    g = torch.Generator().manual_seed(11)
+    n, ht, wd = 9, 40, 56
+    intr = torch.tensor([45.0, 46.0, 27.5, 19.5])
+    y, x = torch.meshgrid(torch.arange(ht).float(), torch.arange(wd).float(), indexing="ij")
+    depth0 = 2.5 + 0.4 * torch.sin(x / 9.0) + 0.3 * torch.cos(y / 7.0)
+    poses = torch.zeros(n, 7)
+    poses[:, 6] = 1.0
+    tw = torch.randn(n, 6, generator=g) * torch.tensor([0.03, 0.03, 0.03, 0.01, 0.01, 0.01])
+    poses = SE3.exp(tw.to(DEV)).data.cpu()                      # world->camera, small baselines around one scene
+    # every frame sees the same smooth surface, rendered through its own pose (first-order: depth0 + noise), so most pixels agree
+    disps = (1.0 / (depth0[None] + 0.02 * torch.randn(n, ht, wd, generator=g))).contiguous()
+    disps[3, 5:12, 8:20] = 2.0                                   # an inconsistent blob: must lose its confirmations
+    inds = torch.tensor([0, 3, 4, 8])
+    thresh = torch.tensor([0.02, 0.05, 0.02, 0.1])
+    got = db.depth_filter(poses.to(DEV), disps.to(DEV), intr.to(DEV), inds.to(DEV), thresh.to(DEV)).cpu().numpy()
+    ref, margin = BO.depth_filter_ref(poses.numpy(), disps.numpy(), intr.numpy(), inds.numpy(), thresh.numpy())
+    assert got.shape == (4, ht, wd) and np.array_equal(got, np.round(got))
+    safe = margin > 5e-5
+    assert safe.mean() > 0.97
+    np.testing.assert_array_equal(got[safe], ref[safe])
+    assert ref.max() >= 3 and (ref == 0).any()                   # both confirmed and rejected pixels are present
+    assert ref[1, 5:12, 8:20].mean() < 0.5 * ref[1].mean()       # the blob is rejected
+    with pytest.raises(IndexError):
+        db.depth_filter(poses.to(DEV), disps.to(DEV), intr.to(DEV), torch.tensor([9]).to(DEV), thresh[:1].to(DEV))
