@@ -106,8 +106,13 @@ SIGNATURES = {
     "cut3r_altcorr_forward": [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p],
     "cut3r_altcorr_backward": [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p, c_void_p],
     "cut3r_ba_step": [c_void_p] * 12 + [c_int] * 6 + [c_float, c_float] + [c_void_p] * 5,
+    "cut3r_gs_preprocess": [c_int] + [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_int] + [c_float] * 4 + [c_void_p] * 5
+                           + [c_ll, c_void_p],
+    "cut3r_gs_workspace_bytes": [c_int, c_ll],
+    "cut3r_gs_bin": [c_int, c_void_p, c_void_p, c_ll, c_int, c_int] + [c_void_p] * 6 + [c_ll, c_void_p],
+    "cut3r_gs_render_forward": [c_void_p] * 3 + [c_int, c_int, c_float, c_float] + [c_void_p] * 11,
 }
-RESTYPES = {"cut3r_ba_workspace_floats": c_ll}
+RESTYPES = {"cut3r_ba_workspace_floats": c_ll, "cut3r_gs_workspace_bytes": c_ll}
 
 _lib = None
 

@@ -1,0 +1,448 @@
+// Gaussian-splatting rasteriser for gfx950 (the operator behind the GS mapper's `render`,
+// /root/reference/hislam2/gaussian/renderer/__init__.py:89-152 -> diff_gaussian_rasterization._C.rasterize_gaussians, the RaDe-GS
+// flavour vendored under thirdparty/diff-gaussian-rasterization: colour, alpha, ray-distance depth (expected + median), camera-space
+// coordinate (expected + median) and normal per pixel).
+//
+// Design for this chip (not the reference's kernel list):
+//   * ONE 128-byte record per Gaussian (GS_REC floats, one cache line): the render kernel gathers whole records by sorted id into
+//     LDS, 256 per batch, and every lane of the 16x16 tile reads the same record at the same time (LDS broadcast, no conflicts).
+//   * the 3D covariance of a scale/rotation Gaussian is R S^2 R^T, so its inverse and its smallest eigenvector (the ray-space
+//     plane of forward.cu:130-153) are written down directly from R and S -- no iterative eigen-solver per Gaussian.
+//   * the per-Gaussian projection is ONE templated function: instantiated on float for the forward pass and on 10-wide forward-mode
+//     dual numbers (mean, scale, quaternion) for the backward pass, which contracts the Jacobian with the gradients the render
+//     backward accumulated per record -- the hand-derived chain of backward.cu:145-628 is not restated.
+//   * binning: hipCUB inclusive scan + 64-bit radix sort of (tile << 32 | depth bits) keys, as the reference's CUB calls.
+#include <hipcub/hipcub.hpp>
+#include "common.h"
+#include "lie_math.h"
+#include "../../include/cut3r_hip.h"
+
+namespace {
+using namespace liemath;
+
+constexpr int GS_REC = 32;                 // floats per Gaussian record
+constexpr int GS_TILE = 16;                // tile edge (config.h:16-17)
+constexpr int GS_BATCH = 256;              // Gaussians staged per round = threads per tile
+constexpr int GS_STAGE = 25;               // leading floats of a record the render kernels read
+enum { G_XY = 0, G_DEPTH = 2, G_TS = 3, G_CONIC = 4, G_OP = 7, G_RGB = 8, G_VP = 11, G_CP = 14, G_RP = 20, G_NRM = 22, G_RADIUS = 25,
+       G_TILES = 26, G_RECT = 27, G_CLAMP = 31 };
+
+struct GsCam {
+    float view[16], proj[16], campos[3];
+    int W, H;
+    float tanx, tany, fx, fy, ks, mod;
+    int deg, K;
+};
+
+template <typename T> struct GsProj {
+    T xy[2], conic[3], coef, ts, vp[3], cp[6], rp[2], nrm[3], cov[3];
+    bool in_front, det_ok;
+};
+
+DEVINL float Clampv(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+template <int N> DEVINL Dual<N> Clampv(const Dual<N>& x, float lo, float hi) {
+    if (x.v < lo) return Dual<N>(lo);
+    if (x.v > hi) return Dual<N>(hi);
+    return x;
+}
+DEVINL float Maxc(float x, float c) { return fmaxf(x, c); }
+template <int N> DEVINL Dual<N> Maxc(const Dual<N>& x, float c) { return x.v < c ? Dual<N>(c) : x; }
+
+// forward.cu:308-421 + :77-265 + :270-305 for one Gaussian, over T = float or dual numbers
+template <typename T>
+DEVINL GsProj<T> gs_project(const T* mean, const T* scale, const T* rot, const GsCam& cam) {
+    GsProj<T> o;
+    const float* V = cam.view;
+    T pv[3], ph[4];
+#pragma unroll
+    for (int i = 0; i < 3; i++) pv[i] = mean[0] * T(V[i]) + mean[1] * T(V[4 + i]) + mean[2] * T(V[8 + i]) + T(V[12 + i]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) ph[i] = mean[0] * T(cam.proj[i]) + mean[1] * T(cam.proj[4 + i]) + mean[2] * T(cam.proj[8 + i]) + T(cam.proj[12 + i]);
+    o.in_front = val(pv[2]) > 0.2f;                                           // auxiliary.h:170
+    const T p_w = T(1.f) / (ph[3] + T(1e-7f));
+    o.xy[0] = ((ph[0] * p_w + T(1.f)) * T((float)cam.W) - T(1.f)) * T(0.5f);
+    o.xy[1] = ((ph[1] * p_w + T(1.f)) * T((float)cam.H) - T(1.f)) * T(0.5f);
+#pragma unroll
+    for (int i = 0; i < 3; i++) o.vp[i] = pv[i];
+    o.ts = Sqrt(pv[0] * pv[0] + pv[1] * pv[1] + pv[2] * pv[2]);
+    // rotation of the (r, x, y, z) quaternion as given (the rasteriser does not normalise), squared scales
+    const T r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    T R[3][3];
+    R[0][0] = T(1.f) - T(2.f) * (y * y + z * z); R[0][1] = T(2.f) * (x * y - r * z); R[0][2] = T(2.f) * (x * z + r * y);
+    R[1][0] = T(2.f) * (x * y + r * z); R[1][1] = T(1.f) - T(2.f) * (x * x + z * z); R[1][2] = T(2.f) * (y * z - r * x);
+    R[2][0] = T(2.f) * (x * z - r * y); R[2][1] = T(2.f) * (y * z + r * x); R[2][2] = T(1.f) - T(2.f) * (x * x + y * y);
+    T s2[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const T s = T(cam.mod) * scale[k]; s2[k] = s * s; }
+    // EWA: cov = (J Rw2c) Sigma (J Rw2c)^T with B = (J Rw2c) R  ->  cov = B diag(s2) B^T
+    const T tz = o.in_front ? pv[2] : T(1.f);
+    const T txtz = Clampv(pv[0] / tz, -1.3f * cam.tanx, 1.3f * cam.tanx), tytz = Clampv(pv[1] / tz, -1.3f * cam.tany, 1.3f * cam.tany);
+    const T tx = txtz * tz, ty = tytz * tz;
+    T A[2][3], B[2][3];
+    {
+        const T j00 = T(cam.fx) / tz, j02 = -(T(cam.fx) * tx) / (tz * tz), j11 = T(cam.fy) / tz, j12 = -(T(cam.fy) * ty) / (tz * tz);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {                                          // Rw2c[i][j] = V[4 j + i]
+            A[0][j] = j00 * T(V[4 * j + 0]) + j02 * T(V[4 * j + 2]);
+            A[1][j] = j11 * T(V[4 * j + 1]) + j12 * T(V[4 * j + 2]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) B[i][k] = A[i][0] * R[0][k] + A[i][1] * R[1][k] + A[i][2] * R[2][k];
+    const T c00 = B[0][0] * B[0][0] * s2[0] + B[0][1] * B[0][1] * s2[1] + B[0][2] * B[0][2] * s2[2];
+    const T c01 = B[0][0] * B[1][0] * s2[0] + B[0][1] * B[1][1] * s2[1] + B[0][2] * B[1][2] * s2[2];
+    const T c11 = B[1][0] * B[1][0] * s2[0] + B[1][1] * B[1][1] * s2[1] + B[1][2] * B[1][2] * s2[2];
+    const T a = c00 + T(cam.ks), b = c01, c = c11 + T(cam.ks);
+    o.cov[0] = a; o.cov[1] = b; o.cov[2] = c;
+    {
+        const T d0 = Maxc(c00 * c11 - c01 * c01, 1e-6f), d1 = Maxc(a * c - c01 * c01, 1e-6f);
+        o.coef = Sqrt(d0 / (d1 + T(1e-6f)) + T(1e-6f));
+        if (val(d0) <= 1e-6f || val(d1) <= 1e-6f) o.coef = T(0.f);
+    }
+    const T det = a * c - b * b;
+    o.det_ok = val(det) != 0.f;
+    const T di = T(1.f) / (o.det_ok ? det : T(1.f));
+    o.conic[0] = c * di; o.conic[1] = -b * di; o.conic[2] = a * di;
+    // ray-space plane and normal (forward.cu:130-262): inverse covariance along the viewing ray, in the camera frame
+    int kmin = val(s2[0]) > val(s2[1]) ? (val(s2[1]) > val(s2[2]) ? 2 : 1) : (val(s2[0]) > val(s2[2]) ? 2 : 0);
+    const bool well = val(s2[kmin]) > 1e-8f;
+    const T uvh[3] = {txtz, tytz, T(1.f)};
+    T w[3], g[3], m[3];                                                         // w = Rw2c^T uvh, g = R^T w, m = Rw2c Sig_inv w
+#pragma unroll
+    for (int j = 0; j < 3; j++) w[j] = T(V[4 * j + 0]) * uvh[0] + T(V[4 * j + 1]) * uvh[1] + T(V[4 * j + 2]) * uvh[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) g[k] = R[0][k] * w[0] + R[1][k] * w[1] + R[2][k] * w[2];
+    if (well) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) g[k] = g[k] / s2[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (k != kmin) g[k] = T(0.f);
+    }
+    T q[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) q[i] = R[i][0] * g[0] + R[i][1] * g[1] + R[i][2] * g[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) m[i] = T(V[0 + i]) * q[0] + T(V[4 + i]) * q[1] + T(V[8 + i]) * q[2];
+    const T mlen = Sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+    const float mv = val(mlen);
+    if (!(mv > 0.f) || mv != mv || isinf(mv)) {                                // isnan(normalize(.)) of forward.cu:155
+#pragma unroll
+        for (int k = 0; k < 6; k++) o.cp[k] = T(0.f);
+        o.rp[0] = o.rp[1] = T(0.f);
+        o.nrm[0] = o.nrm[1] = o.nrm[2] = T(0.f);
+        return o;
+    }
+    const T n0 = m[0] / mlen, n1 = m[1] / mlen, n2 = m[2] / mlen;
+    const T u2 = txtz * txtz, v2 = tytz * tytz, uv = txtz * tytz;
+    const T l = Sqrt(tx * tx + ty * ty + tz * tz);
+    const T vbn = Maxc(n0 * uvh[0] + n1 * uvh[1] + n2, 1e-7f);
+    const T a0 = n0 / vbn, a1 = n1 / vbn, a2 = n2 / vbn;
+    const T p0 = (v2 + T(1.f)) * a0 - uv * a1 - txtz * a2, p1 = (u2 + T(1.f)) * a1 - uv * a0 - tytz * a2;
+    const T nl = u2 + v2 + T(1.f);
+    const T ifx = T(1.f / cam.fx) / nl, ify = T(1.f / cam.fy) / nl;
+    o.cp[0] = (p0 * tx - (v2 + T(1.f)) * tz) * ifx; o.cp[1] = (uv * tz + p1 * tx) * ify;
+    o.cp[2] = (uv * tz + p0 * ty) * ifx;            o.cp[3] = (p1 * ty - (u2 + T(1.f)) * tz) * ify;
+    o.cp[4] = (tx + p0 * tz) * ifx;                 o.cp[5] = (ty + p1 * tz) * ify;
+    o.rp[0] = p0 * l * ifx; o.rp[1] = p1 * l * ify;
+    const T fn = l / nl;
+    const T r0 = -p0 * fn, r1 = -p1 * fn;                                      // ray normal (r0, r1, -1) through nJ
+    const T c0 = r0 / tz - tx / l, c1 = r1 / tz - ty / l, c2 = -(r0 * tx + r1 * ty) / (tz * tz) - tz / l;
+    const T cl = Sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+    o.nrm[0] = c0 / cl; o.nrm[1] = c1 / cl; o.nrm[2] = c2 / cl;
+    return o;
+}
+
+__constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f, -0.4570457994644658f,
+                               1.445305721320277f, -0.5900435899266435f};
+
+// SH basis of forward.cu:23-74 at the unit direction (mean - campos): b[0..15]
+template <typename T> DEVINL void sh_basis(const T* mean, const float* campos, int deg, T* b) {
+    T d[3] = {mean[0] - T(campos[0]), mean[1] - T(campos[1]), mean[2] - T(campos[2])};
+    const T len = Sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const T x = d[0] / len, y = d[1] / len, z = d[2] / len;
+    b[0] = T(0.28209479177387814f);
+    if (deg > 0) { b[1] = -T(0.4886025119029199f) * y; b[2] = T(0.4886025119029199f) * z; b[3] = -T(0.4886025119029199f) * x; }
+    if (deg > 1) {
+        const T xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[4] = T(SH_C2[0]) * xy; b[5] = T(SH_C2[1]) * yz; b[6] = T(SH_C2[2]) * (T(2.f) * zz - xx - yy); b[7] = T(SH_C2[3]) * xz;
+        b[8] = T(SH_C2[4]) * (xx - yy);
+        if (deg > 2) {
+            b[9] = T(SH_C3[0]) * y * (T(3.f) * xx - yy); b[10] = T(SH_C3[1]) * xy * z; b[11] = T(SH_C3[2]) * y * (T(4.f) * zz - xx - yy);
+            b[12] = T(SH_C3[3]) * z * (T(2.f) * zz - T(3.f) * xx - T(3.f) * yy); b[13] = T(SH_C3[4]) * x * (T(4.f) * zz - xx - yy);
+            b[14] = T(SH_C3[5]) * z * (xx - yy); b[15] = T(SH_C3[6]) * x * (xx - T(3.f) * yy);
+        }
+    }
+}
+
+DEVINL int gs_tile_clamp(float v, int g) {                                     // auxiliary.h:62-72: (int) truncation, then [0, g]
+    const int t = (int)(v / (float)GS_TILE);
+    return t < 0 ? 0 : (t > g ? g : t);
+}
+
+__global__ __launch_bounds__(256) void gs_preprocess_kernel(int P, const float* __restrict__ means, const float* __restrict__ scales,
+                                                            const float* __restrict__ rots, const float* __restrict__ opac,
+                                                            const float* __restrict__ shs, const float* __restrict__ colors, GsCam cam,
+                                                            float* __restrict__ geom, int* __restrict__ radii, unsigned* __restrict__ tiles) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float* rec = geom + (size_t)i * GS_REC;
+#pragma unroll
+    for (int k = 0; k < GS_REC; k++) rec[k] = 0.f;
+    radii[i] = 0;
+    tiles[i] = 0;
+    const float mean[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    const float sc[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+    const float rt[4] = {rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]};
+    const GsProj<float> o = gs_project<float>(mean, sc, rt, cam);
+    if (!o.in_front || !o.det_ok) return;
+    const float mid = 0.5f * (o.cov[0] + o.cov[2]);
+    const float root = sqrtf(fmaxf(0.1f, mid * mid - (o.cov[0] * o.cov[2] - o.cov[1] * o.cov[1])));
+    const float radius = ceilf(3.f * sqrtf(fmaxf(mid + root, mid - root)));
+    const int gx = (cam.W + GS_TILE - 1) / GS_TILE, gy = (cam.H + GS_TILE - 1) / GS_TILE;
+    const int rad = (int)radius;
+    const int x0 = gs_tile_clamp(o.xy[0] - (float)rad, gx), y0 = gs_tile_clamp(o.xy[1] - (float)rad, gy);
+    const int x1 = gs_tile_clamp(o.xy[0] + (float)rad + (float)(GS_TILE - 1), gx), y1 = gs_tile_clamp(o.xy[1] + (float)rad + (float)(GS_TILE - 1), gy);
+    if ((x1 - x0) * (y1 - y0) == 0) return;
+    float rgb[3];
+    unsigned clampbits = 0;
+    if (colors) {
+        rgb[0] = colors[3 * i]; rgb[1] = colors[3 * i + 1]; rgb[2] = colors[3 * i + 2];
+    } else {
+        float b[16];
+        sh_basis<float>(mean, cam.campos, cam.deg, b);
+        const int nb = (cam.deg + 1) * (cam.deg + 1);
+        const float* sh = shs + (size_t)i * cam.K * 3;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float v = 0.f;
+            for (int k = 0; k < nb; k++) v += b[k] * sh[3 * k + ch];
+            v += 0.5f;
+            if (v < 0.f) { clampbits |= 1u << ch; v = 0.f; }
+            rgb[ch] = v;
+        }
+    }
+    rec[G_XY] = o.xy[0]; rec[G_XY + 1] = o.xy[1];
+    rec[G_DEPTH] = o.vp[2];
+    rec[G_TS] = o.ts;
+    rec[G_CONIC] = o.conic[0]; rec[G_CONIC + 1] = o.conic[1]; rec[G_CONIC + 2] = o.conic[2];
+    rec[G_OP] = opac[i] * o.coef;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rec[G_RGB + k] = rgb[k]; rec[G_VP + k] = o.vp[k]; rec[G_NRM + k] = o.nrm[k]; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) rec[G_CP + k] = o.cp[k];
+    rec[G_RP] = o.rp[0]; rec[G_RP + 1] = o.rp[1];
+    rec[G_RADIUS] = radius;
+    rec[G_TILES] = __int_as_float((x1 - x0) * (y1 - y0));
+    rec[G_RECT] = __int_as_float(x0); rec[G_RECT + 1] = __int_as_float(y0); rec[G_RECT + 2] = __int_as_float(x1); rec[G_RECT + 3] = __int_as_float(y1);
+    rec[G_CLAMP] = __uint_as_float(clampbits);
+    radii[i] = rad;
+    tiles[i] = (unsigned)((x1 - x0) * (y1 - y0));
+}
+
+// rasterizer_impl.cu:70-112: one (tile << 32 | depth bits, id) pair per covered tile
+__global__ __launch_bounds__(256) void gs_duplicate_kernel(int P, const float* __restrict__ geom, const unsigned* __restrict__ offsets, int gx,
+                                                           unsigned long long n_inst, unsigned long long* __restrict__ keys,
+                                                           unsigned* __restrict__ vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float* rec = geom + (size_t)i * GS_REC;
+    if (__float_as_int(rec[G_TILES]) <= 0) return;
+    unsigned long long off = i == 0 ? 0 : offsets[i - 1];
+    const int x0 = __float_as_int(rec[G_RECT]), y0 = __float_as_int(rec[G_RECT + 1]), x1 = __float_as_int(rec[G_RECT + 2]),
+              y1 = __float_as_int(rec[G_RECT + 3]);
+    const unsigned long long dbits = __float_as_uint(rec[G_DEPTH]);
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            if (off >= n_inst) return;                                         // (cannot happen when offsets is the scan of `tiles`)
+            keys[off] = ((unsigned long long)(y * gx + x) << 32) | dbits;
+            vals[off] = (unsigned)i;
+            off++;
+        }
+}
+
+// rasterizer_impl.cu:151-176: [start, end) of every tile in the sorted list
+__global__ __launch_bounds__(256) void gs_ranges_kernel(unsigned long long n, const unsigned long long* __restrict__ keys, int n_tiles,
+                                                        unsigned* __restrict__ ranges) {
+    const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+    if (i >= n) return;
+    const unsigned t = (unsigned)(keys[i] >> 32);
+    if (t >= (unsigned)n_tiles) return;
+    if (i == 0) ranges[2 * t] = 0;
+    else {
+        const unsigned tp = (unsigned)(keys[i - 1] >> 32);
+        if (tp != t) {
+            if (tp < (unsigned)n_tiles) ranges[2 * tp + 1] = (unsigned)i;
+            ranges[2 * t] = (unsigned)i;
+        }
+    }
+    if (i == n - 1) ranges[2 * t + 1] = (unsigned)n;
+}
+
+// forward.cu:429-692: one 16x16 tile per workgroup, one pixel per thread, front-to-back
+__global__ __launch_bounds__(GS_BATCH) void gs_render_fwd_kernel(const unsigned* __restrict__ ranges, const unsigned* __restrict__ point_list,
+                                                                 const float* __restrict__ geom, int W, int H, float fx, float fy, float bg0,
+                                                                 float bg1, float bg2, float* __restrict__ out_color,
+                                                                 float* __restrict__ out_coord, float* __restrict__ out_mcoord,
+                                                                 float* __restrict__ out_depth, float* __restrict__ out_mdepth,
+                                                                 float* __restrict__ out_alpha, float* __restrict__ out_normal,
+                                                                 unsigned* __restrict__ n_contrib, float* __restrict__ aux) {
+    __shared__ float stage[GS_BATCH * GS_STAGE];
+    __shared__ unsigned stage_id[GS_BATCH];
+    const int gx = (W + GS_TILE - 1) / GS_TILE;
+    const int tid = threadIdx.x;
+    const int px = blockIdx.x * GS_TILE + (tid & 15), py = blockIdx.y * GS_TILE + (tid >> 4);
+    const bool inside = px < W && py < H;
+    const size_t HW = (size_t)W * H, pix = (size_t)py * W + px;
+    const float pxf = (float)px, pyf = (float)py;
+    const unsigned r0 = ranges[2 * (blockIdx.y * gx + blockIdx.x)], r1 = ranges[2 * (blockIdx.y * gx + blockIdx.x) + 1];
+    bool done = !inside;
+    float T = 1.f, weight = 0.f, C[3] = {0.f, 0.f, 0.f}, Co[3] = {0.f, 0.f, 0.f}, mC[3] = {0.f, 0.f, 0.f}, Nr[3] = {0.f, 0.f, 0.f}, D = 0.f, mD = 0.f;
+    unsigned contributor = 0, last = 0, maxc = 0xffffffffu;
+    for (unsigned base = r0; base < r1; base += GS_BATCH) {
+        if (__syncthreads_count(done) == GS_BATCH) break;
+        const unsigned cnt = (r1 - base) < (unsigned)GS_BATCH ? (r1 - base) : (unsigned)GS_BATCH;
+        if ((unsigned)tid < cnt) stage_id[tid] = point_list[base + tid];
+        __syncthreads();
+        for (unsigned e = tid; e < cnt * GS_STAGE; e += GS_BATCH) {            // coalesced over the 25 leading floats of each record
+            const unsigned j = e / GS_STAGE, f = e - j * GS_STAGE;
+            stage[e] = geom[(size_t)stage_id[j] * GS_REC + f];
+        }
+        __syncthreads();
+        for (unsigned j = 0; !done && j < cnt; j++) {
+            contributor++;
+            const float* g = stage + j * GS_STAGE;
+            const float dx = g[G_XY] - pxf, dy = g[G_XY + 1] - pyf;
+            const float power = -0.5f * (g[G_CONIC] * dx * dx + g[G_CONIC + 2] * dy * dy) - g[G_CONIC + 1] * dx * dy;
+            if (power > 0.f) continue;
+            const float alpha = fminf(0.99f, g[G_OP] * expf(power));
+            if (alpha < 1.f / 255.f) continue;
+            const float test_T = T * (1.f - alpha);
+            if (test_T < 0.0001f) { done = true; continue; }
+            const float aT = alpha * T;
+            const bool before = T > 0.5f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                C[ch] += g[G_RGB + ch] * aT;
+                Nr[ch] += g[G_NRM + ch] * aT;
+                const float co = g[G_VP + ch] + g[G_CP + 2 * ch] * dx + g[G_CP + 2 * ch + 1] * dy;
+                Co[ch] += co * aT;
+                if (before) mC[ch] = co;
+            }
+            const float t = g[G_TS] + g[G_RP] * dx + g[G_RP + 1] * dy;
+            D += t * aT;
+            if (before) { mD = t; maxc = contributor; }
+            weight += aT;
+            T = test_T;
+            last = contributor;
+        }
+    }
+    if (!inside) return;
+    const float nx = (pxf - 0.5f * (float)W) / fx, ny = (pyf - 0.5f * (float)H) / fy;
+    const float ln = sqrtf(nx * nx + ny * ny + 1.f);
+    n_contrib[pix] = last;
+    n_contrib[HW + pix] = maxc;
+    out_color[pix] = C[0] + T * bg0; out_color[HW + pix] = C[1] + T * bg1; out_color[2 * HW + pix] = C[2] + T * bg2;
+    out_alpha[pix] = weight;
+    const float iw = last ? 1.f / weight : 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) { out_coord[ch * HW + pix] = Co[ch] * iw; out_mcoord[ch * HW + pix] = mC[ch]; }
+    out_depth[pix] = D / ln * iw;
+    out_mdepth[pix] = mD / ln;
+    float nlen = 1.f;
+    if (last) {
+        nlen = sqrtf(Nr[0] * Nr[0] + Nr[1] * Nr[1] + Nr[2] * Nr[2]);
+        const float il = 1.f / fmaxf(nlen, 1e-12f);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) out_normal[ch * HW + pix] = Nr[ch] * il;
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) out_normal[ch * HW + pix] = 0.f;
+    }
+    aux[pix] = T;                                                              // final transmittance and normal length: backward pass
+    aux[HW + pix] = nlen;
+}
+
+}  // namespace
+
+static int gs_fill_cam(GsCam& cam, const float* view, const float* proj, const float* campos, int W, int H, float tanx, float tany, float ks,
+                       float mod, int deg, int K) {
+    if (!view || !proj || W <= 0 || H <= 0 || !(tanx > 0.f) || !(tany > 0.f) || deg < 0 || deg > 3) return CUT3R_ERR_ARG;
+    for (int i = 0; i < 16; i++) { cam.view[i] = view[i]; cam.proj[i] = proj[i]; }
+    for (int i = 0; i < 3; i++) cam.campos[i] = campos ? campos[i] : 0.f;
+    cam.W = W; cam.H = H; cam.tanx = tanx; cam.tany = tany; cam.fx = (float)W / (2.f * tanx); cam.fy = (float)H / (2.f * tany);
+    cam.ks = ks; cam.mod = mod; cam.deg = deg; cam.K = K;
+    return CUT3R_OK;
+}
+
+extern "C" int cut3r_gs_preprocess(int P, const float* means, const float* scales, const float* rots, const float* opacities, const float* shs,
+                                   int sh_degree, int sh_coeffs, const float* colors_precomp, const float* viewmatrix_host,
+                                   const float* projmatrix_host, const float* campos_host, int W, int H, float tanfovx, float tanfovy,
+                                   float kernel_size, float scale_modifier, float* geom, int* radii, unsigned* tiles_touched,
+                                   unsigned* offsets, void* scan_ws, long long scan_ws_bytes, void* stream) {
+    if (P <= 0 || !means || !scales || !rots || !opacities || !geom || !radii || !tiles_touched || !offsets) return CUT3R_ERR_ARG;
+    if (!shs && !colors_precomp) return CUT3R_ERR_ARG;
+    if (shs && !colors_precomp && sh_coeffs < (sh_degree + 1) * (sh_degree + 1)) return CUT3R_ERR_ARG;
+    GsCam cam;
+    const int rc = gs_fill_cam(cam, viewmatrix_host, projmatrix_host, campos_host, W, H, tanfovx, tanfovy, kernel_size, scale_modifier, sh_degree,
+                               sh_coeffs);
+    if (rc != CUT3R_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gs_preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means, scales, rots, opacities, shs, colors_precomp, cam, geom,
+                       radii, tiles_touched);
+    size_t need = 0;
+    if (hipcub::DeviceScan::InclusiveSum(nullptr, need, tiles_touched, offsets, P, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    if (!scan_ws || (size_t)scan_ws_bytes < need) return CUT3R_ERR_ARG;
+    if (hipcub::DeviceScan::InclusiveSum(scan_ws, need, tiles_touched, offsets, P, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    return cut3r_check_launch();
+}
+
+extern "C" long long cut3r_gs_workspace_bytes(int P, long long n_instances) {
+    size_t a = 0, b = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, a, (unsigned*)nullptr, (unsigned*)nullptr, P > 0 ? P : 1, (hipStream_t)0);
+    if (n_instances > 0)
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
+                                           (unsigned*)nullptr, (int)n_instances, 0, 64, (hipStream_t)0);
+    return (long long)((a > b ? a : b) + 256);
+}
+
+extern "C" int cut3r_gs_bin(int P, const float* geom, const unsigned* offsets, long long n_instances, int W, int H, unsigned long long* keys_tmp,
+                            unsigned* vals_tmp, unsigned long long* keys_sorted, unsigned* point_list, unsigned* ranges, void* sort_ws,
+                            long long sort_ws_bytes, void* stream) {
+    if (P <= 0 || !geom || !offsets || W <= 0 || H <= 0 || !ranges || n_instances < 0 || n_instances > 0x7fffffffLL) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = (W + GS_TILE - 1) / GS_TILE, gy = (H + GS_TILE - 1) / GS_TILE;
+    if (hipMemsetAsync(ranges, 0, sizeof(unsigned) * 2 * (size_t)gx * gy, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    if (n_instances == 0) return CUT3R_OK;
+    if (!keys_tmp || !vals_tmp || !keys_sorted || !point_list || !sort_ws) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(gs_duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, geom, offsets, gx, (unsigned long long)n_instances, keys_tmp,
+                       vals_tmp);
+    int bits = 32;                                                             // tile id bits above the 32 depth bits
+    for (int t = gx * gy; t > 0; t >>= 1) bits++;
+    size_t need = 0;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys_tmp, keys_sorted, vals_tmp, point_list, (int)n_instances, 0, bits, s) != hipSuccess)
+        return CUT3R_ERR_LAUNCH;
+    if ((size_t)sort_ws_bytes < need) return CUT3R_ERR_ARG;
+    if (hipcub::DeviceRadixSort::SortPairs(sort_ws, need, keys_tmp, keys_sorted, vals_tmp, point_list, (int)n_instances, 0, bits, s) != hipSuccess)
+        return CUT3R_ERR_LAUNCH;
+    hipLaunchKernelGGL(gs_ranges_kernel, dim3((unsigned)((n_instances + 255) / 256)), dim3(256), 0, s, (unsigned long long)n_instances, keys_sorted,
+                       gx * gy, ranges);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_gs_render_forward(const unsigned* ranges, const unsigned* point_list, const float* geom, int W, int H, float tanfovx,
+                                       float tanfovy, const float* bg_host, float* out_color, float* out_coord, float* out_mcoord,
+                                       float* out_depth, float* out_mdepth, float* out_alpha, float* out_normal, unsigned* n_contrib, float* aux,
+                                       void* stream) {
+    if (!ranges || !geom || W <= 0 || H <= 0 || !bg_host || !out_color || !out_coord || !out_mcoord || !out_depth || !out_mdepth || !out_alpha ||
+        !out_normal || !n_contrib || !aux || !(tanfovx > 0.f) || !(tanfovy > 0.f))
+        return CUT3R_ERR_ARG;
+    const int gx = (W + GS_TILE - 1) / GS_TILE, gy = (H + GS_TILE - 1) / GS_TILE;
+    hipLaunchKernelGGL(gs_render_fwd_kernel, dim3(gx, gy), dim3(GS_BATCH), 0, (hipStream_t)stream, ranges, point_list, geom, W, H,
+                       (float)W / (2.f * tanfovx), (float)H / (2.f * tanfovy), bg_host[0], bg_host[1], bg_host[2], out_color, out_coord, out_mcoord,
+                       out_depth, out_mdepth, out_alpha, out_normal, n_contrib, aux);
+    return cut3r_check_launch();
+}

@@ -1,0 +1,154 @@
+"""`diff_gaussian_rasterization` on gfx950: the interface of thirdparty/diff-gaussian-rasterization/diff_gaussian_rasterization/
+__init__.py (GaussianRasterizationSettings :190-205, GaussianRasterizer :207-249, _RasterizeGaussians :42-188) over the HIP
+rasteriser in csrc/gs.hip.  Call site: hislam2/gaussian/renderer/__init__.py:101-140 (`render`).
+
+Same argument meaning, same outputs `(color, radii, coord, mcoord, depth, mdepth, alpha, normal)`, same exceptions for the
+either/or argument pairs.  Not built: `cov3D_precomp` (the live renderer passes scales + rotations; the ray-space plane of this
+rasteriser is written from R and S directly) and `integrate` (mesh extraction, not on the SLAM path) raise NotImplementedError.
+There is no CPU fallback: without the HIP library every call raises."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check
+
+GS_REC = 32
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    kernel_size: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    require_depth: bool
+    require_coord: bool
+    debug: bool
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _host16(t, n):
+    a = (C.c_float * n)(*[float(v) for v in t.detach().reshape(-1).cpu().tolist()[:n]])
+    return a
+
+
+class _Buffers:
+    """what rasterize_gaussians keeps between forward and backward (geomBuffer / binningBuffer / imgBuffer of the reference)"""
+    __slots__ = ("geom", "point_list", "ranges", "n_contrib", "aux", "n_inst")
+
+
+def _forward(means3D, sh, colors_precomp, opacities, scales, rotations, st):
+    lib = _lib.load()
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("GaussianRasterizer: tensors must live on the GPU")
+    P = means3D.shape[0]
+    H, W = int(st.image_height), int(st.image_width)
+    f32 = dict(dtype=torch.float32, device=dev)
+    means3D, scales, rotations, opacities = (t.detach().contiguous().float() for t in (means3D, scales, rotations, opacities))
+    use_sh = colors_precomp is None or colors_precomp.numel() == 0
+    sh = sh.detach().contiguous().float() if use_sh else None
+    colors = None if use_sh else colors_precomp.detach().contiguous().float()
+    K = sh.shape[1] if use_sh else 0
+    out = {k: torch.zeros(c, H, W, **f32) for k, c in (("color", 3), ("coord", 3), ("mcoord", 3), ("depth", 1), ("mdepth", 1), ("alpha", 1),
+                                                      ("normal", 3))}
+    radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    buf = _Buffers()
+    buf.n_contrib = torch.zeros(2, H, W, dtype=torch.int32, device=dev)
+    buf.aux = torch.zeros(2, H, W, **f32)
+    bg = _host16(st.bg, 3)
+    if P == 0:
+        out["color"] += torch.as_tensor(list(bg), **f32)[:, None, None]
+        buf.geom, buf.point_list, buf.ranges, buf.n_inst = None, None, None, 0
+        return out, radii, buf
+    buf.geom = torch.empty(P, GS_REC, **f32)
+    tiles = torch.empty(P, dtype=torch.int32, device=dev)
+    offsets = torch.empty(P, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.cut3r_gs_workspace_bytes(P, 0)), dtype=torch.uint8, device=dev)
+    view, proj, campos = _host16(st.viewmatrix, 16), _host16(st.projmatrix, 16), _host16(st.campos, 3)
+    check(lib.cut3r_gs_preprocess(P, _p(means3D), _p(scales), _p(rotations), _p(opacities), _p(sh), int(st.sh_degree), K, _p(colors), view, proj,
+                                  campos, W, H, float(st.tanfovx), float(st.tanfovy), float(st.kernel_size), float(st.scale_modifier), _p(buf.geom),
+                                  _p(radii), _p(tiles), _p(offsets), _p(ws), ws.numel(), _s()), "gs_preprocess")
+    n_inst = int(offsets[-1].item()) & 0xffffffff                     # the one host read of the pass (rasterizer_impl.cu:346-354)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    buf.ranges = torch.empty(gy * gx, 2, dtype=torch.int32, device=dev)
+    buf.n_inst = n_inst
+    keys_tmp = torch.empty(max(1, n_inst), dtype=torch.int64, device=dev)
+    keys_sorted = torch.empty_like(keys_tmp)
+    vals_tmp = torch.empty(max(1, n_inst), dtype=torch.int32, device=dev)
+    buf.point_list = torch.empty_like(vals_tmp)
+    ws2 = torch.empty(int(lib.cut3r_gs_workspace_bytes(P, n_inst)), dtype=torch.uint8, device=dev)
+    check(lib.cut3r_gs_bin(P, _p(buf.geom), _p(offsets), n_inst, W, H, _p(keys_tmp), _p(vals_tmp), _p(keys_sorted), _p(buf.point_list),
+                           _p(buf.ranges), _p(ws2), ws2.numel(), _s()), "gs_bin")
+    check(lib.cut3r_gs_render_forward(_p(buf.ranges), _p(buf.point_list), _p(buf.geom), W, H, float(st.tanfovx), float(st.tanfovy), bg,
+                                      _p(out["color"]), _p(out["coord"]), _p(out["mcoord"]), _p(out["depth"]), _p(out["mdepth"]), _p(out["alpha"]),
+                                      _p(out["normal"]), _p(buf.n_contrib), _p(buf.aux), _s()), "gs_render_forward")
+    return out, radii, buf
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """diff_gaussian_rasterization/__init__.py:42-188"""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        if cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0:
+            raise NotImplementedError("GaussianRasterizer: cov3D_precomp is not built (pass scales and rotations)")
+        out, radii, buf = _forward(means3D, sh, colors_precomp, opacities, scales, rotations, raster_settings)
+        ctx.raster_settings = raster_settings
+        ctx.buf = buf
+        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations)
+        ctx.mark_non_differentiable(radii)
+        return out["color"], radii, out["coord"], out["mcoord"], out["depth"], out["mdepth"], out["alpha"], out["normal"]
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_coord, grad_mcoord, grad_depth, grad_mdepth, grad_alpha, grad_normal):
+        raise NotImplementedError("GaussianRasterizer: the backward pass is not built yet (forward rendering only)")
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """auxiliary.h:155-180 / rasterizer_impl.cu:54-66: in front of the near plane (view z > 0.2)"""
+        with torch.no_grad():
+            V = self.raster_settings.viewmatrix.to(positions.device, torch.float32)
+            z = positions.float() @ V[:3, 2] + V[3, 2]
+            return z > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        return rasterize_gaussians(means3D, means2D, shs if shs is not None else empty, colors_precomp if colors_precomp is not None else empty,
+                                   opacities, scales if scales is not None else empty, rotations if rotations is not None else empty,
+                                   cov3D_precomp if cov3D_precomp is not None else empty, self.raster_settings)
+
+    def integrate(self, *args, **kwargs):
+        raise NotImplementedError("GaussianRasterizer.integrate (mesh extraction) is not on the SLAM path and is not built")

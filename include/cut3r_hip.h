@@ -314,6 +314,30 @@ int cut3r_resize_linear_u8(const void* src, int H0, int W0, int C, void* dst, in
 int cut3r_remap_linear_u8(const void* src, int H, int W, int C, const int32_t* map_ix, const int32_t* map_iy, void* dst, int Ho, int Wo,
                           void* stream);
 
+/* ---- Gaussian-splatting rasteriser ---------------------------------------------------------------
+ * replaces diff_gaussian_rasterization._C.rasterize_gaussians (thirdparty/diff-gaussian-rasterization/rasterize_points.cu:55-195,
+ * bound at ext.cpp:16; called from diff_gaussian_rasterization/__init__.py:75-84, hislam2/gaussian/renderer/__init__.py:132-140),
+ * split into its three stages so that the caller owns every buffer.  All pointers are device pointers except the *_host ones
+ * (16 / 16 / 3 / 3 floats read on the host when the call is made).  Matrices as the reference passes them: the TRANSPOSED 4x4s
+ * (p_view = [p,1] @ viewmatrix).  geom: P records of 32 floats (xy, view depth, ray distance, conic + opacity, rgb, view point,
+ * camera plane, ray plane, normal, radius, tile rectangle): the render stages gather from it.
+ *   preprocess: forward.cu:308-421 per Gaussian + inclusive scan of the covered-tile counts -> offsets[P] (offsets[P-1] = number of
+ *               instances, read back by the caller to size the binning buffers, as rasterizer_impl.cu:346-354 does).
+ *   bin:        rasterizer_impl.cu:70-112,151-176: instance keys (tile << 32 | depth bits), radix sort, per-tile [start, end).
+ *   render:     forward.cu:429-692.  color/coord/mcoord/normal [3,H,W]; depth/mdepth/alpha [1,H,W]; n_contrib uint32 [2,H,W];
+ *               aux float [2,H,W] (final transmittance, normal length: kept for the backward pass). */
+int cut3r_gs_preprocess(int P, const float* means, const float* scales, const float* rots, const float* opacities, const float* shs,
+                        int sh_degree, int sh_coeffs, const float* colors_precomp, const float* viewmatrix_host, const float* projmatrix_host,
+                        const float* campos_host, int W, int H, float tanfovx, float tanfovy, float kernel_size, float scale_modifier, float* geom,
+                        int* radii, unsigned* tiles_touched, unsigned* offsets, void* scan_ws, long long scan_ws_bytes, void* stream);
+long long cut3r_gs_workspace_bytes(int P, long long n_instances);
+int cut3r_gs_bin(int P, const float* geom, const unsigned* offsets, long long n_instances, int W, int H, unsigned long long* keys_tmp,
+                 unsigned* vals_tmp, unsigned long long* keys_sorted, unsigned* point_list, unsigned* ranges, void* sort_ws,
+                 long long sort_ws_bytes, void* stream);
+int cut3r_gs_render_forward(const unsigned* ranges, const unsigned* point_list, const float* geom, int W, int H, float tanfovx, float tanfovy,
+                            const float* bg_host, float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth,
+                            float* out_alpha, float* out_normal, unsigned* n_contrib, float* aux, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
