@@ -366,6 +366,218 @@ __global__ __launch_bounds__(GS_BATCH) void gs_render_fwd_kernel(const unsigned*
     aux[HW + pix] = nlen;
 }
 
+// ------------------------------------------------------------------------------------------------ backward pass
+// Render backward (the job of backward.cu:631-1015, re-derived): per pixel the outputs are sums  Q_k = sum_i f_ki a_i T_i  over its
+// contributors (colour, coordinate, ray distance, normal, weight) plus T_final * bg, then normalised.  With G_k = dL/dQ_k the
+// scalar v_i = sum_k G_k f_ki gives  dL/da_i = v_i T_i - (sum_{j>i} v_j a_j T_j + G_T T_final) / (1 - a_i): ONE suffix sum S per pixel,
+// walked back to front with T_i = T_{i+1} / (1 - a_i).  The gradients of a Gaussian's record fields are reduced over the wave
+// (DPP) before one atomic per wave and field.  dgeom uses the record layout; slot G_DEPTH carries the |d/dxy| sum of the alpha
+// path (backward.cu:1005, the densification statistic).
+constexpr int GS_NGRAD = 25;               // record slots 0..24 receive gradients
+
+__global__ __launch_bounds__(GS_BATCH) void gs_render_bwd_kernel(const unsigned* __restrict__ ranges, const unsigned* __restrict__ point_list,
+                                                                 const float* __restrict__ geom, int W, int H, float fx, float fy, float bg0,
+                                                                 float bg1, float bg2, const unsigned* __restrict__ n_contrib,
+                                                                 const float* __restrict__ aux, const float* __restrict__ out_alpha,
+                                                                 const float* __restrict__ out_coord, const float* __restrict__ out_depth,
+                                                                 const float* __restrict__ out_normal, const float* __restrict__ g_color,
+                                                                 const float* __restrict__ g_coord, const float* __restrict__ g_mcoord,
+                                                                 const float* __restrict__ g_depth, const float* __restrict__ g_mdepth,
+                                                                 const float* __restrict__ g_alpha, const float* __restrict__ g_normal,
+                                                                 float* __restrict__ dgeom) {
+    __shared__ float stage[GS_BATCH * GS_STAGE];
+    __shared__ unsigned stage_id[GS_BATCH];
+    const int gx = (W + GS_TILE - 1) / GS_TILE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int px = blockIdx.x * GS_TILE + (tid & 15), py = blockIdx.y * GS_TILE + (tid >> 4);
+    const bool inside = px < W && py < H;
+    const size_t HW = (size_t)W * H, pix = inside ? (size_t)py * W + px : 0;
+    const float pxf = (float)px, pyf = (float)py;
+    const unsigned r0 = ranges[2 * (blockIdx.y * gx + blockIdx.x)], r1 = ranges[2 * (blockIdx.y * gx + blockIdx.x) + 1];
+    const unsigned n_list = r1 - r0;
+    unsigned last = 0, maxc = 0xffffffffu;
+    float T = 1.f, S = 0.f, GC[3] = {0.f, 0.f, 0.f}, GCo[3] = {0.f, 0.f, 0.f}, GN[3] = {0.f, 0.f, 0.f}, GmC[3] = {0.f, 0.f, 0.f}, GD = 0.f, GW = 0.f,
+          GmD = 0.f;
+    if (inside) {
+        last = n_contrib[pix];
+        maxc = n_contrib[HW + pix];
+        T = aux[pix];
+        const float nlen = aux[HW + pix];
+        const float nx = (pxf - 0.5f * (float)W) / fx, ny = (pyf - 0.5f * (float)H) / fy;
+        const float ln = sqrtf(nx * nx + ny * ny + 1.f);
+        GC[0] = g_color[pix]; GC[1] = g_color[HW + pix]; GC[2] = g_color[2 * HW + pix];
+        S = (GC[0] * bg0 + GC[1] * bg1 + GC[2] * bg2) * T;
+        GW = g_alpha[pix];
+        GmD = g_mdepth[pix] / ln;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) GmC[ch] = g_mcoord[ch * HW + pix];
+        if (last) {
+            const float iw = 1.f / out_alpha[pix];
+            float dotn = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float gc = g_coord[ch * HW + pix];
+                GCo[ch] = gc * iw;
+                GW -= gc * out_coord[ch * HW + pix] * iw;
+                dotn += g_normal[ch * HW + pix] * out_normal[ch * HW + pix];
+            }
+            GD = g_depth[pix] * iw / ln;
+            GW -= g_depth[pix] * out_depth[pix] * iw;
+            const bool unit = nlen > 1e-12f;
+            const float il = 1.f / fmaxf(nlen, 1e-12f);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) GN[ch] = (g_normal[ch * HW + pix] - (unit ? out_normal[ch * HW + pix] * dotn : 0.f)) * il;
+        }
+    }
+    const unsigned rounds = (n_list + GS_BATCH - 1) / GS_BATCH;
+    for (unsigned rd = 0; rd < rounds; rd++) {
+        // batch rd holds list positions hi-1 ... lo (back to front); slot j of the stage = position hi - 1 - j
+        const unsigned hi = n_list - rd * GS_BATCH, cnt = hi < (unsigned)GS_BATCH ? hi : (unsigned)GS_BATCH;
+        __syncthreads();
+        if ((unsigned)tid < cnt) stage_id[tid] = point_list[r0 + hi - 1 - tid];
+        __syncthreads();
+        for (unsigned e = tid; e < cnt * GS_STAGE; e += GS_BATCH) {
+            const unsigned j = e / GS_STAGE, f = e - j * GS_STAGE;
+            stage[e] = geom[(size_t)stage_id[j] * GS_REC + f];
+        }
+        __syncthreads();
+        if (!__any(inside && last > 0 && hi - cnt < last)) continue;          // wave-uniform: nothing of this batch reaches this wave
+        for (unsigned j = 0; j < cnt; j++) {
+            const unsigned pos1 = hi - j;                                     // 1-based contributor index of this list position
+            const float* g = stage + j * GS_STAGE;
+            float d[GS_NGRAD];
+#pragma unroll
+            for (int k = 0; k < GS_NGRAD; k++) d[k] = 0.f;
+            bool act = inside && pos1 <= last;
+            if (act) {
+                const float dx = g[G_XY] - pxf, dy = g[G_XY + 1] - pyf;
+                const float power = -0.5f * (g[G_CONIC] * dx * dx + g[G_CONIC + 2] * dy * dy) - g[G_CONIC + 1] * dx * dy;
+                const float Gs = expf(power);
+                const float araw = g[G_OP] * Gs;
+                const float alpha = fminf(0.99f, araw);
+                act = !(power > 0.f) && !(alpha < 1.f / 255.f);
+                if (act) {
+                    T = T / (1.f - alpha);
+                    const float aT = alpha * T;
+                    const float t = g[G_TS] + g[G_RP] * dx + g[G_RP + 1] * dy;
+                    float v = GW + GD * t, ddx = GD * g[G_RP] * aT, ddy = GD * g[G_RP + 1] * aT;
+                    d[G_TS] = GD * aT; d[G_RP] = GD * aT * dx; d[G_RP + 1] = GD * aT * dy;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float co = g[G_VP + ch] + g[G_CP + 2 * ch] * dx + g[G_CP + 2 * ch + 1] * dy;
+                        v += GC[ch] * g[G_RGB + ch] + GCo[ch] * co + GN[ch] * g[G_NRM + ch];
+                        d[G_RGB + ch] = GC[ch] * aT;
+                        d[G_NRM + ch] = GN[ch] * aT;
+                        d[G_VP + ch] = GCo[ch] * aT;
+                        d[G_CP + 2 * ch] = GCo[ch] * aT * dx;
+                        d[G_CP + 2 * ch + 1] = GCo[ch] * aT * dy;
+                        ddx += GCo[ch] * aT * g[G_CP + 2 * ch];
+                        ddy += GCo[ch] * aT * g[G_CP + 2 * ch + 1];
+                    }
+                    if (pos1 == maxc) {                                        // the median contributor carries mdepth / mcoord
+                        d[G_TS] += GmD; d[G_RP] += GmD * dx; d[G_RP + 1] += GmD * dy;
+                        ddx += GmD * g[G_RP]; ddy += GmD * g[G_RP + 1];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            d[G_VP + ch] += GmC[ch]; d[G_CP + 2 * ch] += GmC[ch] * dx; d[G_CP + 2 * ch + 1] += GmC[ch] * dy;
+                            ddx += GmC[ch] * g[G_CP + 2 * ch]; ddy += GmC[ch] * g[G_CP + 2 * ch + 1];
+                        }
+                    }
+                    const float dalpha = v * T - S / (1.f - alpha);
+                    S += v * aT;
+                    if (araw <= 0.99f) {                                       // d min(0.99, .) = 0 beyond the cap
+                        d[G_OP] = Gs * dalpha;
+                        const float dpow = araw * dalpha;
+                        d[G_CONIC] = -0.5f * dx * dx * dpow; d[G_CONIC + 1] = -dx * dy * dpow; d[G_CONIC + 2] = -0.5f * dy * dy * dpow;
+                        const float ax = (-g[G_CONIC] * dx - g[G_CONIC + 1] * dy) * dpow, ay = (-g[G_CONIC + 2] * dy - g[G_CONIC + 1] * dx) * dpow;
+                        ddx += ax; ddy += ay;
+                        d[G_DEPTH] = fabsf(ax) * 0.5f * (float)W + fabsf(ay) * 0.5f * (float)H;
+                    }
+                    d[G_XY] = ddx; d[G_XY + 1] = ddy;
+                }
+            }
+            if (!__any(act)) continue;
+            float* dst = dgeom + (size_t)stage_id[j] * GS_REC;
+#pragma unroll
+            for (int k = 0; k < GS_NGRAD; k++) {
+                const float sum = wave_sum(d[k]);
+                if (lane == 0 && sum != 0.f) atomicAdd(dst + k, sum);
+            }
+        }
+    }
+}
+
+// Per-Gaussian backward: the projection again, on dual numbers seeded with (mean, scale, quaternion), contracted with the record
+// gradients; SH colour by its (linear) basis.  Replaces backward.cu:21-143,145-628.
+__global__ __launch_bounds__(64) void gs_preprocess_bwd_kernel(int P, const float* __restrict__ means, const float* __restrict__ scales,
+                                                               const float* __restrict__ rots, const float* __restrict__ opac,
+                                                               const float* __restrict__ shs, int use_sh, GsCam cam,
+                                                               const float* __restrict__ geom, const float* __restrict__ dgeom,
+                                                               float* __restrict__ d_means, float* __restrict__ d_scales,
+                                                               float* __restrict__ d_rots, float* __restrict__ d_opac, float* __restrict__ d_shs,
+                                                               float* __restrict__ d_colors, float* __restrict__ d_means2D) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= P) return;
+    const float* rec = geom + (size_t)i * GS_REC;
+    if (!(rec[G_RADIUS] > 0.f)) return;                                        // culled in the forward pass: every gradient stays 0
+    const float* dg = dgeom + (size_t)i * GS_REC;
+    typedef Dual<10> D;
+    D mean[3], sc[3], rt[4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { mean[k] = D(means[3 * i + k]); mean[k].d[k] = 1.f; sc[k] = D(scales[3 * i + k]); sc[k].d[3 + k] = 1.f; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { rt[k] = D(rots[4 * i + k]); rt[k].d[6 + k] = 1.f; }
+    const GsProj<D> o = gs_project<D>(mean, sc, rt, cam);
+    float gin[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) gin[k] = 0.f;
+    auto acc = [&](const D& f, float gf) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) gin[k] += gf * f.d[k];
+    };
+    acc(o.xy[0], dg[G_XY]); acc(o.xy[1], dg[G_XY + 1]);
+    acc(o.ts, dg[G_TS]);
+    acc(o.conic[0], dg[G_CONIC]); acc(o.conic[1], dg[G_CONIC + 1]); acc(o.conic[2], dg[G_CONIC + 2]);
+    acc(o.coef, dg[G_OP] * opac[i]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { acc(o.vp[k], dg[G_VP + k]); acc(o.nrm[k], dg[G_NRM + k]); }
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc(o.cp[k], dg[G_CP + k]);
+    acc(o.rp[0], dg[G_RP]); acc(o.rp[1], dg[G_RP + 1]);
+    d_opac[i] = dg[G_OP] * o.coef.v;
+    if (use_sh) {
+        typedef Dual<3> D3;
+        D3 m3[3], b[16];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { m3[k] = D3(means[3 * i + k]); m3[k].d[k] = 1.f; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) b[k] = D3(0.f);
+        sh_basis<D3>(m3, cam.campos, cam.deg, b);
+        const int nb = (cam.deg + 1) * (cam.deg + 1);
+        const unsigned clampbits = __float_as_uint(rec[G_CLAMP]);
+        const float* sh = shs + (size_t)i * cam.K * 3;
+        float* dsh = d_shs + (size_t)i * cam.K * 3;
+        for (int ch = 0; ch < 3; ch++) {
+            const float gc = (clampbits >> ch) & 1u ? 0.f : dg[G_RGB + ch];    // clamped at 0 in the forward pass: no gradient
+            for (int k = 0; k < nb; k++) {
+                dsh[3 * k + ch] = gc * b[k].v;
+                const float w = gc * sh[3 * k + ch];
+                gin[0] += w * b[k].d[0]; gin[1] += w * b[k].d[1]; gin[2] += w * b[k].d[2];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) d_colors[3 * i + ch] = dg[G_RGB + ch];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { d_means[3 * i + k] = gin[k]; d_scales[3 * i + k] = gin[3 + k]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) d_rots[4 * i + k] = gin[6 + k];
+    d_means2D[3 * i] = dg[G_XY] * 0.5f * (float)cam.W;                         // backward.cu:1002-1006: in NDC units, |.| sum in z
+    d_means2D[3 * i + 1] = dg[G_XY + 1] * 0.5f * (float)cam.H;
+    d_means2D[3 * i + 2] = dg[G_DEPTH];
+}
+
 }  // namespace
 
 static int gs_fill_cam(GsCam& cam, const float* view, const float* proj, const float* campos, int W, int H, float tanx, float tany, float ks,
@@ -444,5 +656,41 @@ extern "C" int cut3r_gs_render_forward(const unsigned* ranges, const unsigned* p
     hipLaunchKernelGGL(gs_render_fwd_kernel, dim3(gx, gy), dim3(GS_BATCH), 0, (hipStream_t)stream, ranges, point_list, geom, W, H,
                        (float)W / (2.f * tanfovx), (float)H / (2.f * tanfovy), bg_host[0], bg_host[1], bg_host[2], out_color, out_coord, out_mcoord,
                        out_depth, out_mdepth, out_alpha, out_normal, n_contrib, aux);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_gs_render_backward(const unsigned* ranges, const unsigned* point_list, const float* geom, int P, int W, int H, float tanfovx,
+                                        float tanfovy, const float* bg_host, const unsigned* n_contrib, const float* aux, const float* out_alpha,
+                                        const float* out_coord, const float* out_depth, const float* out_normal, const float* g_color,
+                                        const float* g_coord, const float* g_mcoord, const float* g_depth, const float* g_mdepth,
+                                        const float* g_alpha, const float* g_normal, float* dgeom, void* stream) {
+    if (!ranges || !geom || P <= 0 || W <= 0 || H <= 0 || !bg_host || !n_contrib || !aux || !out_alpha || !out_coord || !out_depth || !out_normal ||
+        !g_color || !g_coord || !g_mcoord || !g_depth || !g_mdepth || !g_alpha || !g_normal || !dgeom || !(tanfovx > 0.f) || !(tanfovy > 0.f))
+        return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dgeom, 0, sizeof(float) * (size_t)P * GS_REC, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    const int gx = (W + GS_TILE - 1) / GS_TILE, gy = (H + GS_TILE - 1) / GS_TILE;
+    hipLaunchKernelGGL(gs_render_bwd_kernel, dim3(gx, gy), dim3(GS_BATCH), 0, s, ranges, point_list, geom, W, H, (float)W / (2.f * tanfovx),
+                       (float)H / (2.f * tanfovy), bg_host[0], bg_host[1], bg_host[2], n_contrib, aux, out_alpha, out_coord, out_depth, out_normal,
+                       g_color, g_coord, g_mcoord, g_depth, g_mdepth, g_alpha, g_normal, dgeom);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_gs_preprocess_backward(int P, const float* means, const float* scales, const float* rots, const float* opacities,
+                                            const float* shs, int sh_degree, int sh_coeffs, const float* viewmatrix_host,
+                                            const float* projmatrix_host, const float* campos_host, int W, int H, float tanfovx, float tanfovy,
+                                            float kernel_size, float scale_modifier, const float* geom, const float* dgeom, float* d_means,
+                                            float* d_scales, float* d_rots, float* d_opacities, float* d_shs, float* d_colors, float* d_means2D,
+                                            void* stream) {
+    if (P <= 0 || !means || !scales || !rots || !opacities || !geom || !dgeom || !d_means || !d_scales || !d_rots || !d_opacities || !d_means2D)
+        return CUT3R_ERR_ARG;
+    if (shs ? !d_shs : !d_colors) return CUT3R_ERR_ARG;
+    if (shs && sh_coeffs < (sh_degree + 1) * (sh_degree + 1)) return CUT3R_ERR_ARG;
+    GsCam cam;
+    const int rc = gs_fill_cam(cam, viewmatrix_host, projmatrix_host, campos_host, W, H, tanfovx, tanfovy, kernel_size, scale_modifier, sh_degree,
+                               sh_coeffs);
+    if (rc != CUT3R_OK) return rc;
+    hipLaunchKernelGGL(gs_preprocess_bwd_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, means, scales, rots, opacities, shs,
+                       shs ? 1 : 0, cam, geom, dgeom, d_means, d_scales, d_rots, d_opacities, d_shs, d_colors, d_means2D);
     return cut3r_check_launch();
 }

@@ -3,8 +3,10 @@ __init__.py (GaussianRasterizationSettings :190-205, GaussianRasterizer :207-249
 rasteriser in csrc/gs.hip.  Call site: hislam2/gaussian/renderer/__init__.py:101-140 (`render`).
 
 Same argument meaning, same outputs `(color, radii, coord, mcoord, depth, mdepth, alpha, normal)`, same exceptions for the
-either/or argument pairs.  Not built: `cov3D_precomp` (the live renderer passes scales + rotations; the ray-space plane of this
-rasteriser is written from R and S directly) and `integrate` (mesh extraction, not on the SLAM path) raise NotImplementedError.
+either/or argument pairs.  Forward and backward.  The backward pass returns the exact derivatives of the forward function (forward-mode duals through
+the per-Gaussian projection); `means2D` receives the screen-space gradient in the reference's units (x, y in NDC, z = |.| sum).
+Not built: `cov3D_precomp` (the live renderer passes scales + rotations; the ray-space plane of this rasteriser is written from
+R and S directly) and `integrate` (mesh extraction, not on the SLAM path) raise NotImplementedError.
 There is no CPU fallback: without the HIP library every call raises."""
 from __future__ import annotations
 
@@ -53,7 +55,7 @@ def _host16(t, n):
 
 class _Buffers:
     """what rasterize_gaussians keeps between forward and backward (geomBuffer / binningBuffer / imgBuffer of the reference)"""
-    __slots__ = ("geom", "point_list", "ranges", "n_contrib", "aux", "n_inst")
+    __slots__ = ("geom", "point_list", "ranges", "n_contrib", "aux", "n_inst", "alpha", "coord", "depth", "normal")
 
 
 def _forward(means3D, sh, colors_precomp, opacities, scales, rotations, st):
@@ -102,7 +104,40 @@ def _forward(means3D, sh, colors_precomp, opacities, scales, rotations, st):
     check(lib.cut3r_gs_render_forward(_p(buf.ranges), _p(buf.point_list), _p(buf.geom), W, H, float(st.tanfovx), float(st.tanfovy), bg,
                                       _p(out["color"]), _p(out["coord"]), _p(out["mcoord"]), _p(out["depth"]), _p(out["mdepth"]), _p(out["alpha"]),
                                       _p(out["normal"]), _p(buf.n_contrib), _p(buf.aux), _s()), "gs_render_forward")
+    buf.alpha, buf.coord, buf.depth, buf.normal = out["alpha"], out["coord"], out["depth"], out["normal"]
     return out, radii, buf
+
+
+def _backward(buf, st, means3D, sh, colors_precomp, opacities, scales, rotations, grads):
+    """grads: (color, coord, mcoord, depth, mdepth, alpha, normal) images or None -> the gradients of the Gaussian parameters"""
+    lib = _lib.load()
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = int(st.image_height), int(st.image_width)
+    f32 = dict(dtype=torch.float32, device=dev)
+    use_sh = colors_precomp is None or colors_precomp.numel() == 0
+    d = {"means": torch.zeros(P, 3, **f32), "scales": torch.zeros(P, 3, **f32), "rots": torch.zeros(P, 4, **f32), "opac": torch.zeros(P, 1, **f32),
+         "means2D": torch.zeros(P, 3, **f32)}
+    d["shs"] = torch.zeros(sh.shape, **f32) if use_sh else None
+    d["colors"] = None if use_sh else torch.zeros(P, 3, **f32)
+    if P == 0 or buf.geom is None:
+        return d
+    chans = (3, 3, 3, 1, 1, 1, 3)
+    g = [torch.zeros(c, H, W, **f32) if t is None else t.detach().contiguous().float() for t, c in zip(grads, chans)]
+    means3D, scales, rotations, opacities = (t.detach().contiguous().float() for t in (means3D, scales, rotations, opacities))
+    sh_c = sh.detach().contiguous().float() if use_sh else None
+    K = sh_c.shape[1] if use_sh else 0
+    dgeom = torch.empty(P, GS_REC, **f32)
+    bg = _host16(st.bg, 3)
+    check(lib.cut3r_gs_render_backward(_p(buf.ranges), _p(buf.point_list), _p(buf.geom), P, W, H, float(st.tanfovx), float(st.tanfovy), bg,
+                                       _p(buf.n_contrib), _p(buf.aux), _p(buf.alpha), _p(buf.coord), _p(buf.depth), _p(buf.normal), _p(g[0]),
+                                       _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(g[5]), _p(g[6]), _p(dgeom), _s()), "gs_render_backward")
+    view, proj, campos = _host16(st.viewmatrix, 16), _host16(st.projmatrix, 16), _host16(st.campos, 3)
+    check(lib.cut3r_gs_preprocess_backward(P, _p(means3D), _p(scales), _p(rotations), _p(opacities), _p(sh_c), int(st.sh_degree), K, view, proj,
+                                           campos, W, H, float(st.tanfovx), float(st.tanfovy), float(st.kernel_size), float(st.scale_modifier),
+                                           _p(buf.geom), _p(dgeom), _p(d["means"]), _p(d["scales"]), _p(d["rots"]), _p(d["opac"]), _p(d["shs"]),
+                                           _p(d["colors"]), _p(d["means2D"]), _s()), "gs_preprocess_backward")
+    return d
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -121,7 +156,11 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_coord, grad_mcoord, grad_depth, grad_mdepth, grad_alpha, grad_normal):
-        raise NotImplementedError("GaussianRasterizer: the backward pass is not built yet (forward rendering only)")
+        means3D, sh, colors_precomp, opacities, scales, rotations = ctx.saved_tensors
+        d = _backward(ctx.buf, ctx.raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations,
+                      (grad_color, grad_coord, grad_mcoord, grad_depth, grad_mdepth, grad_alpha, grad_normal))
+        # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+        return d["means"], d["means2D"], d["shs"], d["colors"], d["opac"].reshape(opacities.shape), d["scales"], d["rots"], None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):

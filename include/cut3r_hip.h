@@ -337,6 +337,24 @@ int cut3r_gs_bin(int P, const float* geom, const unsigned* offsets, long long n_
 int cut3r_gs_render_forward(const unsigned* ranges, const unsigned* point_list, const float* geom, int W, int H, float tanfovx, float tanfovy,
                             const float* bg_host, float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth,
                             float* out_alpha, float* out_normal, unsigned* n_contrib, float* aux, void* stream);
+/* backward of the rasteriser (replaces _C.rasterize_gaussians_backward, rasterize_points.cu:197-330 -> backward.cu:145-1160).
+ *   render_backward:     per-pixel gradients of the seven images -> dgeom [P,32]: gradients of the record fields (record layout; it is
+ *                        zeroed here; slot 2 carries the |d/dxy| sum of backward.cu:1005).  Needs the forward's geom, point_list,
+ *                        ranges, n_contrib, aux and its alpha / coord / depth / normal images.
+ *   preprocess_backward: dgeom -> d_means [P,3], d_scales [P,3], d_rots [P,4], d_opacities [P], d_shs [P,sh_coeffs,3] (rows beyond the
+ *                        active degree are left untouched: pass zeros) or d_colors [P,3] when shs == NULL, d_means2D [P,3] (x, y in
+ *                        NDC units as backward.cu:1002-1003, z the |.| sum).  Gaussians culled by the forward pass are not written:
+ *                        pass zero-initialised outputs.  Exact derivatives of the forward function (forward-mode duals). */
+int cut3r_gs_render_backward(const unsigned* ranges, const unsigned* point_list, const float* geom, int P, int W, int H, float tanfovx,
+                             float tanfovy, const float* bg_host, const unsigned* n_contrib, const float* aux, const float* out_alpha,
+                             const float* out_coord, const float* out_depth, const float* out_normal, const float* g_color, const float* g_coord,
+                             const float* g_mcoord, const float* g_depth, const float* g_mdepth, const float* g_alpha, const float* g_normal,
+                             float* dgeom, void* stream);
+int cut3r_gs_preprocess_backward(int P, const float* means, const float* scales, const float* rots, const float* opacities, const float* shs,
+                                 int sh_degree, int sh_coeffs, const float* viewmatrix_host, const float* projmatrix_host,
+                                 const float* campos_host, int W, int H, float tanfovx, float tanfovy, float kernel_size, float scale_modifier,
+                                 const float* geom, const float* dgeom, float* d_means, float* d_scales, float* d_rots, float* d_opacities,
+                                 float* d_shs, float* d_colors, float* d_means2D, void* stream);
 
 #ifdef __cplusplus
 }

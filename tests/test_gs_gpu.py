@@ -107,3 +107,51 @@ def test_argument_checks_and_empty_scene():
     np.testing.assert_allclose(color.cpu().numpy(), np.broadcast_to(np.array([0.5, 0.25, 0.0], np.float32)[:, None, None], (3, 32, 32)))
     vis = rast.markVisible(torch.tensor([[0.0, 0.0, 1.0], [0.0, 0.0, 0.1], [0.0, 0.0, -1.0]], device=DEV))
     assert vis.tolist() == [True, False, False]
+
+
+def _grad_compare(got, ref, name, tol, max_bad):
+    g, r = got.double().cpu().numpy(), ref.numpy()
+    scale = np.abs(r).mean() + 1e-12
+    err = np.abs(g - r)
+    bad = (err > tol * (np.abs(r) + scale)).mean()
+    print(f"[gs bwd] {name}: mean |ref| {scale:.3e}, median |err| {np.median(err):.2e}, max |err| / scale {err.max() / scale:.2e}, "
+          f"beyond tolerance {100 * bad:.3f} %")
+    assert bad <= max_bad, f"{name}: {bad}"
+    assert np.abs(g.sum() - r.sum()) <= 5e-3 * np.abs(r).sum() + 1e-9, name
+
+
+@pytest.mark.parametrize("H,W,P,deg,ks,cam,precomp", [(40, 56, 60, 3, 0.0, (0.0, 0.0, (0.0, 0.0, 0.0)), False),
+                                                      (48, 64, 200, 1, 0.1, (0.15, -0.2, (0.1, -0.05, 0.3)), False),
+                                                      (33, 47, 120, 0, 0.0, (-0.1, 0.1, (0.0, 0.1, 0.0)), True)])
+def test_backward_matches_autograd_of_the_restatement(H, W, P, deg, ks, cam, precomp):
+    """every output image gets a random cotangent; the gradients of means, scales, rotations, opacities and SH / colours are compared
+    with torch autograd through the fp64 restatement (hard per-pixel decisions flip for a few pixels in fp32: bounded fraction)"""
+    means, scales, q, op, shs = _scene(P, 7 * P + deg)
+    st = GO.camera_settings(H, W, 1.0, 1.0 * H / W, _w2c(*cam), bg=(0.1, 0.2, 0.3), sh_degree=deg, kernel_size=ks)
+    colors = torch.rand(P, 3, dtype=torch.float64) if precomp else None
+    g = torch.Generator().manual_seed(99)
+    names = ("color", "coord", "mcoord", "depth", "mdepth", "alpha", "normal")
+    chans = (3, 3, 3, 1, 1, 1, 3)
+    cot = {n: torch.randn(c, H, W, generator=g, dtype=torch.float64) for n, c in zip(names, chans)}
+    # ---- oracle
+    leaves = [t.clone().requires_grad_(True) for t in (means, scales, q, op)] + [(colors if precomp else shs).clone().requires_grad_(True)]
+    ref = GO.rasterize(leaves[0], leaves[3], leaves[1], leaves[2], st, shs=None if precomp else leaves[4], colors_precomp=leaves[4] if precomp else None)
+    sum(float(1.0) * (ref[n] * cot[n]).sum() for n in names).backward()
+    # ---- HIP
+    f = lambda t: t.float().to(DEV)
+    hm, hs, hq, ho = (f(t).requires_grad_(True) for t in (means, scales, q, op))
+    hc = f(colors if precomp else shs).requires_grad_(True)
+    m2d = torch.zeros(P, 3, device=DEV, requires_grad=True)
+    rast = GaussianRasterizer(_settings(st))
+    outs = rast(means3D=hm, means2D=m2d, opacities=ho, shs=None if precomp else hc, colors_precomp=hc if precomp else None, scales=hs, rotations=hq)
+    color, radii, coord, mcoord, depth, mdepth, alpha, normal = outs
+    loss = sum((o * f(cot[n])).sum() for n, o in zip(names, (color, coord, mcoord, depth, mdepth, alpha, normal)))
+    loss.backward()
+    torch.cuda.synchronize()
+    _grad_compare(hm.grad, leaves[0].grad, "means3D", 2e-4, 0.01)
+    _grad_compare(hs.grad, leaves[1].grad, "scales", 2e-4, 0.01)
+    _grad_compare(hq.grad, leaves[2].grad, "rotations", 5e-4, 0.01)
+    _grad_compare(ho.grad, leaves[3].grad, "opacities", 2e-4, 0.01)
+    _grad_compare(hc.grad, leaves[4].grad, "colors" if precomp else "shs", 2e-4, 0.01)
+    assert m2d.grad.shape == (P, 3) and float(m2d.grad[:, 2].min()) >= 0.0 and float(m2d.grad.abs().sum()) > 0
+    assert float(hm.grad[:4].abs().max()) == 0.0                          # culled Gaussians get no gradient
