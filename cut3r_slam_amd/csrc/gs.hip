@@ -578,6 +578,36 @@ __global__ __launch_bounds__(64) void gs_preprocess_bwd_kernel(int P, const floa
     d_means2D[3 * i + 2] = dg[G_DEPTH];
 }
 
+// ------------------------------------------------------------------------------------------------ simple_knn.distCUDA2
+// Mean squared distance of every point to its 3 nearest OTHER points (call sites hislam2/gaussian/scene/gaussian_model.py:191,313:
+// the initial scale of a new Gaussian).  The extension is not vendored in the reference tree (graphdeco-inria/simple-knn): the
+// published operator is restated.  Exhaustive search instead of upstream's Morton-box pruning: candidates stream through LDS in tiles
+// of 256 points and every lane of the wave reads the same candidate (broadcast), 3 compare-exchanges per pair -- exact, no tree
+// to build, and a keyframe's worth of points (<= ~2e5) is a few milliseconds on this chip.
+__global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ pts, int P, float* __restrict__ out) {
+    __shared__ float sx[256], sy[256], sz[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < P;
+    const float x = live ? pts[3 * (size_t)i] : 0.f, y = live ? pts[3 * (size_t)i + 1] : 0.f, z = live ? pts[3 * (size_t)i + 2] : 0.f;
+    float b0 = 3.402823466e38f, b1 = b0, b2 = b0;
+    for (int base = 0; base < P; base += 256) {
+        const int j = base + threadIdx.x;
+        __syncthreads();
+        if (j < P) { sx[threadIdx.x] = pts[3 * (size_t)j]; sy[threadIdx.x] = pts[3 * (size_t)j + 1]; sz[threadIdx.x] = pts[3 * (size_t)j + 2]; }
+        __syncthreads();
+        const int cnt = P - base < 256 ? P - base : 256;
+        for (int k = 0; k < cnt; k++) {
+            const float dx = sx[k] - x, dy = sy[k] - y, dz = sz[k] - z;
+            float d = dx * dx + dy * dy + dz * dz;
+            if (base + k == i) d = 3.402823466e38f;                            // the point itself is not its own neighbour
+            const float t0 = fminf(b0, d); d = fmaxf(b0, d); b0 = t0;
+            const float t1 = fminf(b1, d); d = fmaxf(b1, d); b1 = t1;
+            b2 = fminf(b2, d);
+        }
+    }
+    if (live) out[i] = (b0 + b1 + b2) / 3.f;
+}
+
 }  // namespace
 
 static int gs_fill_cam(GsCam& cam, const float* view, const float* proj, const float* campos, int W, int H, float tanx, float tany, float ks,
@@ -692,5 +722,11 @@ extern "C" int cut3r_gs_preprocess_backward(int P, const float* means, const flo
     if (rc != CUT3R_OK) return rc;
     hipLaunchKernelGGL(gs_preprocess_bwd_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, means, scales, rots, opacities, shs,
                        shs ? 1 : 0, cam, geom, dgeom, d_means, d_scales, d_rots, d_opacities, d_shs, d_colors, d_means2D);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_knn3_mean_dist2(const float* points, int P, float* out, void* stream) {
+    if (!points || !out || P < 4) return CUT3R_ERR_ARG;                      // three OTHER points must exist
+    hipLaunchKernelGGL(knn3_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, points, P, out);
     return cut3r_check_launch();
 }

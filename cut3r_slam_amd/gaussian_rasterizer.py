@@ -191,3 +191,16 @@ class GaussianRasterizer(nn.Module):
 
     def integrate(self, *args, **kwargs):
         raise NotImplementedError("GaussianRasterizer.integrate (mesh extraction) is not on the SLAM path and is not built")
+
+
+def distCUDA2(points):
+    """simple_knn._C.distCUDA2 (hislam2/gaussian/scene/gaussian_model.py:18,191,313): points [P,3] float32 on the GPU -> [P] mean squared
+    distance to the 3 nearest other points (exhaustive search on the GPU)."""
+    if points.device.type != "cuda":
+        raise RuntimeError("distCUDA2: points must live on the GPU")
+    pts = points.detach().contiguous().float()
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise ValueError("distCUDA2: points must be [P,3]")
+    out = torch.empty(pts.shape[0], dtype=torch.float32, device=pts.device)
+    check(_lib.load().cut3r_knn3_mean_dist2(_p(pts), pts.shape[0], _p(out), _s()), "knn3_mean_dist2")
+    return out

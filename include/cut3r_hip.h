@@ -355,6 +355,9 @@ int cut3r_gs_preprocess_backward(int P, const float* means, const float* scales,
                                  const float* campos_host, int W, int H, float tanfovx, float tanfovy, float kernel_size, float scale_modifier,
                                  const float* geom, const float* dgeom, float* d_means, float* d_scales, float* d_rots, float* d_opacities,
                                  float* d_shs, float* d_colors, float* d_means2D, void* stream);
+/* simple_knn._C.distCUDA2 (call sites hislam2/gaussian/scene/gaussian_model.py:191,313; the extension is not vendored in the
+ * reference tree): points [P,3] -> out [P], the mean squared distance to the 3 nearest other points.  P >= 4. */
+int cut3r_knn3_mean_dist2(const float* points, int P, float* out, void* stream);
 
 #ifdef __cplusplus
 }

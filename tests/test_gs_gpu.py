@@ -155,3 +155,30 @@ def test_backward_matches_autograd_of_the_restatement(H, W, P, deg, ks, cam, pre
     _grad_compare(hc.grad, leaves[4].grad, "colors" if precomp else "shs", 2e-4, 0.01)
     assert m2d.grad.shape == (P, 3) and float(m2d.grad[:, 2].min()) >= 0.0 and float(m2d.grad.abs().sum()) > 0
     assert float(hm.grad[:4].abs().max()) == 0.0                          # culled Gaussians get no gradient
+
+
+def test_knn_mean_distance_matches_kdtree_and_alias_imports():
+    """simple_knn.distCUDA2 (gaussian_model.py:191): mean squared distance to the 3 nearest other points, against scipy's cKDTree in
+    fp64; duplicates count as neighbours at distance 0; the alias packages resolve to the same objects"""
+    from scipy.spatial import cKDTree
+    from cut3r_slam_amd.gaussian_rasterizer import distCUDA2
+    g = torch.Generator().manual_seed(5)
+    for P in (4, 257, 5000):
+        pts = torch.randn(P, 3, generator=g) * torch.tensor([2.0, 1.0, 0.3])
+        if P > 100:
+            pts[10] = pts[11]                                              # an exact duplicate
+        got = distCUDA2(pts.to(DEV)).cpu().numpy()
+        d, _ = cKDTree(pts.double().numpy()).query(pts.double().numpy(), k=4)
+        ref = (d[:, 1:] ** 2).mean(axis=1)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-7)
+    with pytest.raises(Exception):
+        distCUDA2(torch.zeros(3, 3, device=DEV))
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cut3r_slam_amd", "compat")
+    sys.path.insert(0, compat)
+    try:
+        import diff_gaussian_rasterization as dgr
+        from simple_knn._C import distCUDA2 as d2
+        assert dgr.GaussianRasterizer is GaussianRasterizer and dgr.GaussianRasterizationSettings is GaussianRasterizationSettings
+        assert d2 is distCUDA2
+    finally:
+        sys.path.remove(compat)
