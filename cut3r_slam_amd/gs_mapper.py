@@ -1,0 +1,465 @@
+"""Gaussian-splatting mapper on the gfx950 rasteriser: the part of the reference's GS backend that sits between the tracker and the
+rasteriser.  Mirrors, with the same names, argument meaning and loss terms:
+
+  GaussianMap            hislam2/gaussian/scene/gaussian_model.py:34-105,146-216,336-431,547-790 (parameters and activations, new
+                         Gaussians from a keyframe's pointmap with 3-NN scales, Adam groups, prune / clone / split)
+  Camera, get_pose,      hislam2/gaussian/utils/camera_utils.py, slam_utils.py:62-102 (world->camera R, T plus the tangent-space
+  update_pose            deltas the optimiser moves; new_w2c = exp([trans, rot]) @ T_w2c)
+  render                 hislam2/gaussian/renderer/__init__.py:89-152 (Gaussians moved into the camera frame, identity view matrix)
+  GSMapper.pose_refine   hislam2/gs_backend_per_frame.py:202-326
+  GSMapper.optimization  hislam2/gs_backend_per_frame.py:451-587
+  GSMapper.add_new_view  hislam2/gs_backend_per_frame.py:87-121
+  GSMapper.global_BA     hislam2/gs_backend_per_frame.py:946-1058 (all keyframes, poses and Gaussians together; simplified schedule)
+
+The reference's backend cannot run here (CUDA rasteriser, open3d, munch): PARITY UNPINNED, covered by functional tests on a
+synthetic scene (tests/test_gs_mapper_gpu.py).  The rasteriser and the 3-NN search are the HIP kernels of csrc/gs.hip; the loss
+terms and the Adam updates are plain torch tensor arithmetic on the GPU.  Not built: GUI, exposure compensation, opacity reset
+schedule, ply export, the TSDF / evaluation utilities."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .gaussian_rasterizer import GaussianRasterizationSettings, GaussianRasterizer, distCUDA2
+from .lietorch import SE3
+
+SH_C0 = 0.28209479177387814
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def pose_vec_to_matrix(p):
+    """[.., 7] (t, q_xyzw) camera->world -> [.., 4, 4]"""
+    return SE3(torch.as_tensor(p, dtype=torch.float32)).matrix()
+
+
+class GaussianMap:
+    GROUPS = ("xyz", "f_dc", "opacity", "scaling", "rotation")
+
+    def __init__(self, opt, device="cuda:0", isotropic=False):
+        self.device, self.isotropic = torch.device(device), isotropic
+        z = lambda *s: torch.zeros(*s, device=self.device)
+        self.p = {"xyz": z(0, 3), "f_dc": z(0, 3), "opacity": z(0, 1), "scaling": z(0, 3), "rotation": z(0, 4)}
+        for t in self.p.values():
+            t.requires_grad_(True)
+        self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.lr = {"xyz": opt["position_lr_init"], "f_dc": opt["feature_lr"], "opacity": opt["opacity_lr"], "scaling": opt["scaling_lr"],
+                   "rotation": opt["rotation_lr"]}
+        self.percent_dense = opt.get("percent_dense", 0.01)
+        self.step_count = z(0, 1)
+        self.kf_id = torch.zeros(0, dtype=torch.int32, device=self.device)
+        self.max_radii2D = z(0)
+        self.grad_accum, self.denom = z(0, 1), z(0, 1)
+
+    # ---- activations (gaussian_model.py:77-101)
+    def __len__(self):
+        return self.p["xyz"].shape[0]
+
+    @property
+    def get_xyz(self):
+        return self.p["xyz"]
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self.p["scaling"])
+
+    @property
+    def get_rotation(self):
+        return F.normalize(self.p["rotation"], dim=-1)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self.p["opacity"])
+
+    @property
+    def get_features(self):
+        return self.p["f_dc"][:, None, :]                                 # [P,1,3]: SH degree 0, as the backend runs the model
+
+    # ---- growth
+    def _append(self, new, kf_id):
+        n = new["xyz"].shape[0]
+        for k in self.GROUPS:
+            self.p[k] = torch.cat([self.p[k].detach(), new[k].to(self.device).float()], 0).requires_grad_(True)
+            self.m[k] = torch.cat([self.m[k], torch.zeros_like(new[k], device=self.device, dtype=torch.float32)], 0)
+            self.v[k] = torch.cat([self.v[k], torch.zeros_like(new[k], device=self.device, dtype=torch.float32)], 0)
+        z = lambda *s: torch.zeros(*s, device=self.device)
+        self.step_count = torch.cat([self.step_count, z(n, 1)], 0)
+        self.kf_id = torch.cat([self.kf_id, kf_id.to(self.device, torch.int32)], 0)
+        self.max_radii2D = torch.cat([self.max_radii2D, z(n)], 0)
+        self.grad_accum, self.denom = torch.cat([self.grad_accum, z(n, 1)], 0), torch.cat([self.denom, z(n, 1)], 0)
+
+    def extend_from_pcd_seq(self, submap_idx=-1, rgb=None, pointmap=None, conf=None, point_size=1.0):
+        """gaussian_model.py:150-216,363-372: one Gaussian per pointmap pixel with conf > 0; scale = sqrt of the mean squared 3-NN distance,
+        identity rotation, opacity 0.1, colour as the DC SH coefficient.  rgb [.., 3] in [0,1], pointmap [.., 3], conf [..] or None."""
+        pts = torch.as_tensor(pointmap, dtype=torch.float32, device=self.device).reshape(-1, 3)
+        col = torch.as_tensor(rgb, dtype=torch.float32, device=self.device).reshape(-1, 3)
+        if conf is not None:
+            keep = torch.as_tensor(conf, device=self.device).reshape(-1) > 0.0
+            pts, col = pts[keep], col[keep]
+        if pts.shape[0] < 5:
+            return 0
+        d2 = torch.clamp_min(distCUDA2(pts), 1e-7) * point_size
+        scales = torch.log(torch.sqrt(d2))[:, None].repeat(1, 3)
+        rots = torch.zeros(pts.shape[0], 4, device=self.device)
+        rots[:, 0] = 1
+        new = {"xyz": pts, "f_dc": (col - 0.5) / SH_C0, "opacity": inverse_sigmoid(0.1 * torch.ones(pts.shape[0], 1, device=self.device)),
+               "scaling": scales, "rotation": rots}
+        self._append(new, torch.full((pts.shape[0],), int(submap_idx)))
+        return pts.shape[0]
+
+    def prune_points(self, mask):
+        keep = ~mask
+        for k in self.GROUPS:
+            self.p[k] = self.p[k].detach()[keep].requires_grad_(True)
+            self.m[k], self.v[k] = self.m[k][keep], self.v[k][keep]
+        self.step_count, self.kf_id, self.max_radii2D = self.step_count[keep], self.kf_id[keep], self.max_radii2D[keep]
+        self.grad_accum, self.denom = self.grad_accum[keep], self.denom[keep]
+
+    def add_densification_stats(self, viewspace_grad, update_filter):
+        """gaussian_model.py:779-790: norm of the screen-space gradient (x, y) per visible Gaussian"""
+        self.grad_accum[update_filter] += torch.norm(viewspace_grad[update_filter, :2], dim=-1, keepdim=True)
+        self.denom[update_filter] += 1
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
+        """gaussian_model.py:639-777: clone small Gaussians with a large mean screen gradient, split large ones in two, then prune the
+        transparent and the oversized"""
+        grads = self.grad_accum / self.denom.clamp_min(1)
+        grads[grads.isnan()] = 0.0
+        big = self.get_scaling.detach().max(dim=1).values > self.percent_dense * extent
+        hot = grads[:, 0] >= max_grad
+        clone, split = hot & ~big, hot & big
+        new = []
+        if clone.any():
+            new.append(({k: self.p[k].detach()[clone].clone() for k in self.GROUPS}, self.kf_id[clone]))
+        if split.any():
+            n = int(split.sum())
+            std = self.get_scaling.detach()[split].repeat(2, 1)
+            R = SO3_matrix(self.get_rotation.detach()[split]).repeat(2, 1, 1)
+            xyz = (R @ (torch.randn(2 * n, 3, device=self.device) * std)[:, :, None])[:, :, 0] + self.p["xyz"].detach()[split].repeat(2, 1)
+            s = {k: self.p[k].detach()[split].repeat(2, 1) for k in self.GROUPS}
+            s["xyz"], s["scaling"] = xyz, torch.log(std / (0.8 * 2))
+            new.append((s, self.kf_id[split].repeat(2)))
+        n_before = len(self)
+        for s, ids in new:
+            self._append(s, ids)
+        drop = torch.zeros(len(self), dtype=torch.bool, device=self.device)
+        drop[:n_before] = split
+        drop |= (self.get_opacity.detach() < min_opacity)[:, 0]
+        if max_screen_size:
+            drop |= (self.max_radii2D > max_screen_size) | (self.get_scaling.detach().max(dim=1).values > 0.1 * extent)
+        self.prune_points(drop)
+        self.grad_accum.zero_()
+        self.denom.zero_()
+        self.max_radii2D.zero_()
+
+    # ---- Adam (torch.optim.Adam(lr per group, eps=1e-15) of gaussian_model.py:374-417, with per-Gaussian step counts so that appended
+    #      Gaussians start their own bias correction)
+    def zero_grad(self):
+        for t in self.p.values():
+            t.grad = None
+
+    @torch.no_grad()
+    def step(self, b1=0.9, b2=0.999, eps=1e-15):
+        touched = None
+        for k in self.GROUPS:
+            g = self.p[k].grad
+            if g is None:
+                continue
+            if touched is None:
+                self.step_count += 1
+                touched = True
+            self.m[k].mul_(b1).add_(g, alpha=1 - b1)
+            self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+            bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
+            self.p[k].sub_(self.lr[k] * (self.m[k] / bc1) / ((self.v[k] / bc2).sqrt() + eps))
+
+
+def SO3_matrix(q):
+    """(r, x, y, z) unit quaternions [n,4] -> rotation matrices [n,3,3]"""
+    r, x, y, z = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                        2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+
+
+class Camera:
+    """camera_utils.py Camera.init_from_tracking: image [3,H,W] in [0,1], depth [H,W], world->camera w2c [4,4], pinhole K"""
+
+    def __init__(self, uid, image, depth, w2c, fx, fy, cx, cy, tstamp=None, device="cuda:0"):
+        dev = torch.device(device)
+        self.uid, self.tstamp, self.device = uid, tstamp, dev
+        self.original_image = image.to(dev, torch.float32)
+        self.depth = depth.to(dev, torch.float32)
+        self.image_height, self.image_width = image.shape[-2:]
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+        self.FoVx, self.FoVy = 2 * math.atan(self.image_width / (2 * self.fx)), 2 * math.atan(self.image_height / (2 * self.fy))
+        w2c = torch.as_tensor(w2c, dtype=torch.float32, device=dev)
+        self.R, self.T = w2c[:3, :3].clone(), w2c[:3, 3].clone()
+        self.cam_rot_delta = torch.zeros(3, device=dev, requires_grad=True)
+        self.cam_trans_delta = torch.zeros(3, device=dev, requires_grad=True)
+        # pinhole projection in the rasteriser's NDC (pixel u = ((ndc + 1) W - 1) / 2, forward.cu ndc2Pix): u = fx X/Z + cx exactly;
+        # stored transposed like the reference's cameras (graphics_utils.getProjectionMatrix2 + .transpose(0, 1))
+        znear, zfar, W, H = 0.01, 100.0, self.image_width, self.image_height
+        P = torch.zeros(4, 4)
+        P[0, 0], P[1, 1] = 2 * self.fx / W, 2 * self.fy / H
+        P[0, 2], P[1, 2] = (2 * self.cx + 1) / W - 1, (2 * self.cy + 1) / H - 1
+        P[3, 2], P[2, 2], P[2, 3] = 1.0, zfar / (zfar - znear), -(zfar * znear) / (zfar - znear)
+        self.projection_matrix = P.T.contiguous().to(dev)
+
+    def update_RT(self, R, T):
+        self.R, self.T = R.detach().clone(), T.detach().clone()
+
+    @property
+    def camera_center(self):
+        return -(self.R.T @ self.T)
+
+
+def get_pose(camera):
+    """slam_utils.py:93-102"""
+    tau = torch.cat([camera.cam_trans_delta, camera.cam_rot_delta], 0)
+    T = torch.eye(4, device=camera.device)
+    T[:3, :3], T[:3, 3] = camera.R, camera.T
+    return SE3.exp(tau[None]).matrix()[0] @ T
+
+
+@torch.no_grad()
+def update_pose(camera):
+    """slam_utils.py:77-91"""
+    new = get_pose(camera)
+    camera.update_RT(new[:3, :3], new[:3, 3])
+    camera.cam_rot_delta.data.fill_(0)
+    camera.cam_trans_delta.data.fill_(0)
+
+
+def _rotmat_to_quat(R):
+    """renderer/__init__.py:165-195, branch-free through atan-free copysign form (r, x, y, z); differentiable"""
+    m00, m11, m22 = R[0, 0], R[1, 1], R[2, 2]
+    r = torch.sqrt(torch.clamp(1 + m00 + m11 + m22, min=1e-12)) / 2
+    x = torch.sqrt(torch.clamp(1 + m00 - m11 - m22, min=1e-12)) / 2
+    y = torch.sqrt(torch.clamp(1 - m00 + m11 - m22, min=1e-12)) / 2
+    z = torch.sqrt(torch.clamp(1 - m00 - m11 + m22, min=1e-12)) / 2
+    m00d, m11d, m22d = float(m00.detach()), float(m11.detach()), float(m22.detach())
+    if m00d + m11d + m22d > 0:
+        return torch.stack([r, (R[2, 1] - R[1, 2]) / (4 * r), (R[0, 2] - R[2, 0]) / (4 * r), (R[1, 0] - R[0, 1]) / (4 * r)])
+    if m00d > m11d and m00d > m22d:
+        return torch.stack([(R[2, 1] - R[1, 2]) / (4 * x), x, (R[0, 1] + R[1, 0]) / (4 * x), (R[0, 2] + R[2, 0]) / (4 * x)])
+    if m11d > m22d:
+        return torch.stack([(R[0, 2] - R[2, 0]) / (4 * y), (R[0, 1] + R[1, 0]) / (4 * y), y, (R[1, 2] + R[2, 1]) / (4 * y)])
+    return torch.stack([(R[1, 0] - R[0, 1]) / (4 * z), (R[0, 2] + R[2, 0]) / (4 * z), (R[1, 2] + R[2, 1]) / (4 * z), z])
+
+
+def _quat_mult(a, b):
+    r1, x1, y1, z1 = a.unbind(-1)
+    r2, x2, y2, z2 = b.unbind(-1)
+    return torch.stack([r1 * r2 - x1 * x2 - y1 * y2 - z1 * z2, r1 * x2 + x1 * r2 + y1 * z2 - z1 * y2, r1 * y2 - x1 * z2 + y1 * r2 + z1 * x2,
+                        r1 * z2 + x1 * y2 - y1 * x2 + z1 * r2], -1)
+
+
+def render(viewpoint, pc, bg_color, scaling_modifier=1.0):
+    """renderer/__init__.py:89-152: the Gaussians are moved into the camera frame (so the pose receives gradients through means and
+    rotations) and rasterised with an identity view matrix; returns the reference's dict"""
+    w2c = get_pose(viewpoint)
+    xyz = pc.get_xyz @ w2c[:3, :3].T + w2c[:3, 3]
+    rot = _quat_mult(F.normalize(_rotmat_to_quat(w2c[:3, :3]), dim=-1)[None], pc.get_rotation)
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+    view = torch.eye(4, device=xyz.device)
+    st = GaussianRasterizationSettings(image_height=int(viewpoint.image_height), image_width=int(viewpoint.image_width),
+                                       tanfovx=math.tan(viewpoint.FoVx * 0.5), tanfovy=math.tan(viewpoint.FoVy * 0.5), kernel_size=0.0, bg=bg_color,
+                                       scale_modifier=scaling_modifier, viewmatrix=view, projmatrix=view @ viewpoint.projection_matrix, sh_degree=0,
+                                       campos=torch.zeros(3, device=xyz.device), prefiltered=False, require_coord=True, require_depth=True,
+                                       debug=False)
+    color, radii, coord, mcoord, depth, mdepth, alpha, normal = GaussianRasterizer(st)(
+        means3D=xyz, means2D=screenspace_points, opacities=pc.get_opacity, shs=pc.get_features, scales=pc.get_scaling, rotations=rot)
+    return {"render": color, "mask": alpha, "expected_coord": coord, "median_coord": mcoord, "depth": depth, "median_depth": mdepth,
+            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii, "normal": normal, "n_touched": None}
+
+
+def project2world(c2w, depths, fx, fy, cx, cy):
+    """slam_utils.py:108-140: depth maps [N,H,W] -> world points [N,H,W,3]"""
+    N, H, W = depths.shape
+    y, x = torch.meshgrid(torch.arange(H, device=depths.device).float(), torch.arange(W, device=depths.device).float(), indexing="ij")
+    pc = torch.stack([(x - cx) / fx * depths, (y - cy) / fy * depths, depths], -1)
+    return pc @ c2w[:, None, :3, :3].transpose(-1, -2) + c2w[:, None, None, :3, 3]
+
+
+def depth_to_normal(viewpoint, depth):
+    """camera-frame normals from a depth map [1,H,W] (cross product of the back-projected neighbours; borders zero) -> [3,H,W]"""
+    d = depth[0]
+    H, W = d.shape
+    y, x = torch.meshgrid(torch.arange(H, device=d.device).float(), torch.arange(W, device=d.device).float(), indexing="ij")
+    pts = torch.stack([(x - viewpoint.cx) / viewpoint.fx * d, (y - viewpoint.cy) / viewpoint.fy * d, d], 0)
+    dx = pts[:, 1:-1, 2:] - pts[:, 1:-1, :-2]
+    dy = pts[:, 2:, 1:-1] - pts[:, :-2, 1:-1]
+    n = F.normalize(torch.cross(dx, dy, dim=0), dim=0)
+    return F.pad(n, (1, 1, 1, 1))
+
+
+def ssim(a, b, window=11, sigma=1.5):
+    """gaussian/utils/loss_utils.py ssim: 11x11 Gaussian window, per-channel, mean over the image"""
+    g = torch.exp(-((torch.arange(window, device=a.device).float() - window // 2) ** 2) / (2 * sigma * sigma))
+    g = (g / g.sum())[:, None]
+    w = (g @ g.T)[None, None].expand(a.shape[0], 1, window, window).contiguous()
+    f = lambda t: F.conv2d(t[None], w, padding=window // 2, groups=a.shape[0])[0]
+    mu1, mu2 = f(a), f(b)
+    s11, s22, s12 = f(a * a) - mu1 * mu1, f(b * b) - mu2 * mu2, f(a * b) - mu1 * mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2))).mean()
+
+
+class GSMapper:
+    """the mapping half of hislam2/gs_backend_per_frame.py:GSBackEnd"""
+
+    def __init__(self, config, fx, fy, cx, cy, downsample_ratio=2, device="cuda:0"):
+        self.config, self.device, self.downsample_ratio = config, torch.device(device), downsample_ratio
+        self.fx, self.fy, self.cx, self.cy = fx, fy, cx, cy
+        tr = config["Training"]
+        self.lambda_depth, self.lambda_normal, self.lambda_iso = tr["lambda_depth"], tr["lambda_normal"], tr["lambda_iso"]
+        self.gaussian_th, self.size_threshold = tr["gaussian_th"], tr["size_threshold"]
+        self.gaussian_extent = 6.0 * tr["gaussian_extent"]                # cameras_extent * gaussian_extent (:49,71)
+        self.gaussians = GaussianMap(config["opt_params"], device)
+        self.background = torch.zeros(3, device=self.device)
+        self.viewpoints = {}
+
+    def _pose_optimizer(self, views):
+        lr = self.config["opt_params"]["pose_lr"]
+        groups = []
+        for v in views:
+            groups += [{"params": [v.cam_rot_delta], "lr": lr * 2}, {"params": [v.cam_trans_delta], "lr": lr * 10}]
+        return torch.optim.Adam(groups)
+
+    def pose_refine(self, BA_window, iters=50, return_args=True, alpha_th=0.5):
+        """gs_backend_per_frame.py:202-326: the Gaussians stay fixed, the poses of the window move; photometric L1 on the covered pixels,
+        scale-invariant log-depth variance, a small pull to the starting pose.  Returns (pointmaps_ds, valid_ds) of the refined poses."""
+        views = [self.viewpoints[k] for k in BA_window]
+        B = len(views)
+        if len(self.gaussians) > 0:
+            opt = self._pose_optimizer(views)
+            for _ in range(iters):
+                rgb_all = depth_all = pose_all = 0.0
+                for v in views:
+                    pkg = render(v, self.gaussians, self.background)
+                    image, depth, alpha = pkg["render"], pkg["depth"], pkg["mask"]
+                    gt_depth = v.depth[None]
+                    amask = (alpha > alpha_th).detach()
+                    ratio = amask.sum() / amask.numel()
+                    dmask = (gt_depth > 0.001) & (depth > 0.001) & amask
+                    rgb = torch.abs((v.original_image - image)[:, amask[0]]).mean() if amask.any() else image.sum() * 0
+                    if dmask.any():
+                        diff = torch.log(depth[dmask]) - torch.log(gt_depth[dmask])
+                        dl = (diff ** 2).mean() - diff.mean() ** 2
+                    else:
+                        dl = depth.sum() * 0
+                    pl = (v.cam_rot_delta ** 2).sum() + (v.cam_trans_delta ** 2).sum()
+                    rgb_all, depth_all, pose_all = rgb_all + ratio * rgb, depth_all + ratio * dl, pose_all + (2 - ratio) * pl
+                loss = (5 * rgb_all + depth_all + 0.05 * pose_all) / B
+                opt.zero_grad(set_to_none=True)
+                self.gaussians.zero_grad()
+                loss.backward()
+                opt.step()
+            self.gaussians.zero_grad()
+            for v in views:
+                update_pose(v)
+        if not return_args:
+            return None
+        with torch.no_grad():
+            w2c_all, depth_all, valid_all = [], [], []
+            for v in views:
+                gt_depth = v.depth[None]
+                if len(self.gaussians) > 0:
+                    pkg = render(v, self.gaussians, self.background)
+                    depth, alpha = pkg["depth"], pkg["mask"]
+                else:
+                    depth, alpha = torch.zeros_like(gt_depth), torch.zeros_like(gt_depth)
+                valid = (alpha <= alpha_th) & (gt_depth > 0.001)
+                amask = alpha > alpha_th
+                dmask = (gt_depth > 0.001) & (depth > 0.001) & amask
+                if float(amask.float().mean()) > 0.3 and dmask.any():
+                    scale = torch.exp((torch.log(depth[dmask]) - torch.log(gt_depth[dmask])).mean()).clamp(0.95, 1.05)
+                    gt_depth = scale * gt_depth
+                w2c_all.append(get_pose(v))
+                depth_all.append(gt_depth)
+                valid_all.append(valid)
+            pm = project2world(torch.inverse(torch.stack(w2c_all)), torch.cat(depth_all), self.fx, self.fy, self.cx, self.cy)
+            ds = self.downsample_ratio
+            return pm[:, ::ds, ::ds], torch.cat(valid_all).float()[:, ::ds, ::ds]
+
+    def add_new_view(self, new_img, new_pose, new_depth, new_tstamp=None, kf_sub_idx=0, iters=50):
+        """gs_backend_per_frame.py:87-121: register the keyframe, refine its pose against the map, add Gaussians where the map does not
+        cover it yet.  new_img u8 or float [3,H,W]; new_pose [7] camera->world (t, q_xyzw); new_depth [H,W]."""
+        img = new_img.to(self.device).float()
+        img = img / 255.0 if img.max() > 1.5 else img
+        w2c = torch.inverse(pose_vec_to_matrix(torch.as_tensor(new_pose)[None].to(self.device))[0])
+        idx = len(self.viewpoints)
+        self.viewpoints[idx] = Camera(idx, img, new_depth, w2c, self.fx, self.fy, self.cx, self.cy, new_tstamp, self.device)
+        pointmap, valid = self.pose_refine([idx], iters=iters)
+        ds = self.downsample_ratio
+        rgb = img[:, ::ds, ::ds].permute(1, 2, 0)
+        self.gaussians.extend_from_pcd_seq(submap_idx=kf_sub_idx, rgb=rgb, pointmap=pointmap[0], conf=valid[0])
+        return idx
+
+    def optimization(self, iters, optimize_pose=True, current_window=None, densify=False):
+        """gs_backend_per_frame.py:451-587: L1 + SSIM colour, inverse-depth L1, depth-normal agreement with the keyframe depth, isotropy;
+        Gaussians (and optionally the window's poses) step together; clone / split / prune at iters/4 and iters/2 when densifying."""
+        views = [self.viewpoints[k] for k in current_window]
+        N = len(views)
+        opt = self._pose_optimizer(views) if optimize_pose else None
+        last = None
+        for it in range(iters):
+            loss = 0.0
+            stats = []
+            for v in views:
+                pkg = render(v, self.gaussians, self.background)
+                image, depth = pkg["render"], pkg["depth"]
+                gt_image, gt_depth = v.original_image, v.depth[None]
+                rgb = 0.8 * torch.abs(gt_image - image).mean() + 0.2 * (1.0 - ssim(image, gt_image))
+                dmask = ((gt_depth > 0.001) & (depth > 0.001)).detach()
+                dl = torch.abs(1.0 / depth[dmask] - 1.0 / gt_depth[dmask]).mean() if dmask.any() else depth.sum() * 0
+                dn, gn = depth_to_normal(v, depth), depth_to_normal(v, gt_depth)
+                nl = (1 - (dn[:, dmask[0]] * gn[:, dmask[0]]).sum(0)).mean() if dmask.any() else depth.sum() * 0
+                sc = self.gaussians.get_scaling[pkg["visibility_filter"]]
+                iso = torch.abs(sc - sc.mean(dim=1, keepdim=True)).mean() if sc.numel() else depth.sum() * 0
+                loss = loss + rgb + self.lambda_depth * dl + self.lambda_normal * nl + self.lambda_iso * iso
+                stats.append((pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]))
+            loss = loss / N
+            self.gaussians.zero_grad()
+            if opt is not None:
+                opt.zero_grad(set_to_none=True)
+            loss.backward()
+            with torch.no_grad():
+                if densify:
+                    for vs, vis, radii in stats:
+                        self.gaussians.max_radii2D[vis] = torch.max(self.gaussians.max_radii2D[vis], radii[vis].float())
+                        self.gaussians.add_densification_stats(vs.grad, vis)
+                self.gaussians.step()
+                if densify and it in (iters // 4, iters // 2):
+                    self.gaussians.densify_and_prune(self.config["opt_params"]["densify_grad_threshold"], self.gaussian_th, self.gaussian_extent,
+                                                     self.size_threshold)
+            if opt is not None:
+                opt.step()
+                for v in views:
+                    update_pose(v)
+            last = float(loss.detach())
+        self.gaussians.zero_grad()
+        return last
+
+    def global_BA(self, iteration_total, window=8, densify=True):
+        """gs_backend_per_frame.py:946-1058 in outline: every keyframe takes part; random windows of keyframes are optimised jointly
+        (Gaussians + poses) until iteration_total renders have been spent"""
+        keys = list(self.viewpoints.keys())
+        g = torch.Generator().manual_seed(0)
+        spent, last = 0, None
+        while spent < iteration_total and keys:
+            pick = [keys[i] for i in torch.randperm(len(keys), generator=g)[:window].tolist()]
+            n = max(1, min(10, (iteration_total - spent) // len(pick)))
+            last = self.optimization(n, optimize_pose=True, current_window=pick, densify=densify and spent < iteration_total // 2)
+            spent += n * len(pick)
+        return last
+
+    @torch.no_grad()
+    def trajectory(self):
+        """camera->world [n,4,4] of the keyframes as refined by the mapper"""
+        return torch.stack([torch.inverse(get_pose(self.viewpoints[k])) for k in sorted(self.viewpoints)])
