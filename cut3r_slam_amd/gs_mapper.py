@@ -459,7 +459,82 @@ class GSMapper:
             spent += n * len(pick)
         return last
 
+    # ---- the tracker-facing entry points (hi2.py:56-99 calls run() once per tracked window)
+    def run(self, packet, iterations=100, init_iters=100, gba_per_view=10):
+        """gs_backend_per_frame.py:776-862.  packet: viz_idx (keyframe indices of the window), submap_idx, tstamp [n], poses [n,7]
+        camera->world, images [n,3,H,W] u8, pointmaps [n,h,w,3] world, confs [n,h,w], depths [n,h',w'], intrinsics [4].  New keyframes
+        are chained to the mapper's own estimate of the previous one, refined against the map, mapped; then a global pass.  Returns
+        (updated packet, keyframe indices) as data_update()."""
+        with torch.no_grad():
+            H, W = packet["images"].shape[-2:]
+            self.fx, self.fy, self.cx, self.cy = (float(v) for v in list(packet["intrinsics"])[:4])
+            viz_idx, submap_idx = list(packet["viz_idx"]), int(packet["submap_idx"])
+            imgs = packet["images"].to(self.device).float() / 255.0
+            ds = self.downsample_ratio
+            pointmaps = F.interpolate(packet["pointmaps"].to(self.device).permute(0, 3, 1, 2), size=(H // ds, W // ds), mode="bilinear",
+                                      align_corners=False).permute(0, 2, 3, 1)
+            self.h, self.w = packet["pointmaps"].shape[1:3]
+            depths = F.interpolate(packet["depths"].to(self.device)[None], size=(H, W), mode="bilinear", align_corners=False)[0].clone()
+            confs = F.interpolate(packet["confs"].to(self.device)[None], size=(H, W), mode="bilinear", align_corners=False)[0]
+            depths[confs < 0.0] = 0.0
+            w2c = torch.inverse(pose_vec_to_matrix(packet["poses"].to(self.device)))
+        if not hasattr(self, "current_window"):
+            self.current_window, self.initialized = [], False
+        window_size = self.config["Training"].get("window_size", 10)
+        for i, idx in enumerate(viz_idx):
+            cur = w2c[i]
+            if i > 0 and viz_idx[i - 1] in self.viewpoints:
+                with torch.no_grad():
+                    cur = (cur @ torch.inverse(w2c[i - 1])) @ get_pose(self.viewpoints[viz_idx[i - 1]]).detach()
+            if idx in self.viewpoints:
+                continue
+            self.viewpoints[idx] = Camera(idx, imgs[i], depths[i], cur, self.fx, self.fy, self.cx, self.cy, float(packet["tstamp"][i]), self.device)
+            if not self.initialized:
+                self.gaussians.extend_from_pcd_seq(submap_idx=0, rgb=imgs[i, :, ::ds, ::ds].permute(1, 2, 0), pointmap=pointmaps[i])
+                self.current_window = [idx]
+                self.optimization(init_iters, current_window=self.current_window)
+                self.initialized = True
+            else:
+                self.current_window = (self.current_window + [idx])[-window_size:]
+                pm, valid = self.pose_refine([idx], iters=50)
+                self.gaussians.extend_from_pcd_seq(submap_idx=submap_idx, rgb=imgs[i, :, ::ds, ::ds].permute(1, 2, 0), pointmap=pm[0], conf=valid[0])
+                self.optimization(min(20, iterations), current_window=self.current_window)
+                self.optimization(min(50, iterations), current_window=[idx], optimize_pose=False)
+        self.global_BA(gba_per_view * len(self.viewpoints), densify=True)
+        return self.data_update(self.h, self.w, self.current_window)
+
+    @torch.no_grad()
+    def data_update(self, h, w, current_window):
+        """gs_backend_per_frame.py:649-699: poses (camera->world, t + q_xyzw), scale-corrected depths and their world pointmaps of the
+        window's keyframes, resampled to (h, w) * downsample_ratio"""
+        poses, depths, pms = [], [], []
+        for k in current_window:
+            v = self.viewpoints[k]
+            gt = v.depth[None]
+            pkg = render(v, self.gaussians, self.background)
+            ok = (pkg["depth"] > 0.001) & (gt > 0.001) & (pkg["mask"] > 0.9)
+            if ok.any():
+                gt = gt * torch.exp((torch.log(pkg["depth"][ok]) - torch.log(gt[ok])).mean()).clamp(0.95, 1.05)
+            v.depth = gt[0]
+            c2w = torch.inverse(get_pose(v))
+            pms.append(project2world(c2w[None], gt, self.fx, self.fy, self.cx, self.cy)[0])
+            depths.append(gt[0])
+            poses.append(SE3_from_matrix(c2w))
+        ds = self.downsample_ratio
+        size = (h * ds, w * ds)
+        pms = F.interpolate(torch.stack(pms).permute(0, 3, 1, 2), size=size, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+        depths = F.interpolate(torch.stack(depths)[None], size=size, mode="bilinear", align_corners=False)[0]
+        return {"pointmaps": pms, "depths": depths, "poses": torch.stack(poses)}, list(current_window)
+
+
     @torch.no_grad()
     def trajectory(self):
         """camera->world [n,4,4] of the keyframes as refined by the mapper"""
         return torch.stack([torch.inverse(get_pose(self.viewpoints[k])) for k in sorted(self.viewpoints)])
+
+
+def SE3_from_matrix(T):
+    """[4,4] rigid transform -> [7] (t, q_xyzw), quaternion by the largest-diagonal rule (scipy Rotation.from_matrix / as_quat order)"""
+    q = _rotmat_to_quat(T[:3, :3])
+    q = q / q.norm()
+    return torch.cat([T[:3, 3], q[1:], q[:1]])

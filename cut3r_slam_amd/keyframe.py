@@ -128,6 +128,14 @@ class KeyFrame:
             self.w2c[start:start + n].copy_(torch.from_numpy(rows), non_blocking=True)
         return rows
 
+    def set_poses_at(self, idx, poses7):
+        """set_pose for arbitrary keyframe indices (the mapper's write-back, hi2.py:84): host table + device mirror"""
+        p = np.asarray(poses7, np.float32).reshape(-1, 7)
+        rows = gh.w2c_rows(gh.pose_vec_to_matrix(p))
+        for j, k in enumerate(idx):
+            self.pose[int(k)] = torch.from_numpy(p[j])
+            self.w2c[int(k)].copy_(torch.from_numpy(rows[j]))
+
     def pointmap_slot(self, kf: int, sub_num: int, t0: int):
         """(submap, slot) holding the current estimate of keyframe `kf` as seen from window `sub_num` starting at t0
         (track_frontend.py:251-255: earlier submaps contribute slots 0..4, the running window its own slots)."""

@@ -49,10 +49,34 @@ class Cut3rSlam:
         # dist.ShardedTracker registers keyframes ahead of the tracker (encoder look-ahead): it sets this, and the trajectory writers
         # then stop at tracker.t1 instead of the reference's counter - 1 (demo_s.py:97-100)
         self.tracked_only = False
+        # hi2.py:47-48: the Gaussian mapper (cut3r_slam_amd.gs_mapper.GSMapper); None = tracking only (BASELINE configs 1-4)
+        self.mapper = None
+        self.gs_iter_num = self.config.get("Mapping", {}).get("itr_num", 100)
+
+    def call_gs(self, viz_idx, submap_idx, iterations, intrinsics):
+        """hi2.py:56-91: hand the window's keyframes to the mapper and take back its refined poses, scale-corrected depths and
+        pointmaps (the chain of later windows then starts from them).  Images are the stored tracking-resolution keyframes."""
+        kf = self.keyframes
+        viz = list(viz_idx)
+        n = len(viz)
+        data = {"viz_idx": viz, "submap_idx": submap_idx, "tstamp": kf.tstamp[viz], "poses": kf.pose[viz], "images": kf.image[viz],
+                "pointmaps": kf.submap_ds[submap_idx][:n], "confs": kf.conf_ds[submap_idx][:n], "depths": kf.depth[viz],
+                "intrinsics": torch.as_tensor(intrinsics).reshape(-1)[:4]}
+        with torch.enable_grad():
+            updated, idx = self.mapper.run(data, iterations)
+        kf.set_poses_at(idx, updated["poses"].float().cpu().numpy())
+        depth = updated["depths"]
+        ds = self.downsample_ratio
+        for j, k in enumerate(idx):
+            ok = depth[j] > 0
+            kf.depth[k][ok] = depth[j][ok]
+            kf.submap_ds[k // 5, k % 5] = updated["pointmaps"][j, ::ds, ::ds]
+        kf.submap_ds[:submap_idx + 1, -1] = kf.submap_ds[1:submap_idx + 2, 0]
+        return idx
 
     @torch.no_grad()
     def run(self, tstamp, image, intrinsics, image_ds, intrinsics_ds, second_last_frame=False, last_frame=False):
-        """hi2.py:101-133 without the GS mapper: image_ds [1,3,H,W] uint8 at tracking resolution."""
+        """hi2.py:101-133 (the GS mapper takes part when `self.mapper` is set): image_ds [1,3,H,W] uint8 at tracking resolution."""
         if self.keep_images:
             self.images[int(tstamp)] = image
         self.filterx.kfFilter(tstamp, image_ds, intrinsics=intrinsics_ds, second_last_frame=second_last_frame,
@@ -66,6 +90,8 @@ class Cut3rSlam:
                     self.freeze_counter = 0
             else:
                 self.freeze_counter += 1
+        if viz_idx is not None and self.mapper is not None:
+            self.call_gs(viz_idx, submap_idx, self.gs_iter_num, intrinsics_ds)
         return viz_idx, submap_idx, lc_did
 
     @torch.no_grad()

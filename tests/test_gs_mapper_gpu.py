@@ -134,3 +134,51 @@ def test_mapping_from_keyframes_reaches_the_observations():
     assert ba is not None and ba < 1.2 * last
     traj = mapper.trajectory()
     assert traj.shape == (3, 4, 4) and torch.isfinite(traj).all()
+
+
+def test_tracker_hand_over_runs_the_mapper_and_writes_back():
+    """Cut3rSlam.call_gs (hi2.py:56-91) with a keyframe store filled by hand: one 6-keyframe window of the synthetic wall with
+    centimetre pose noise goes through GSMapper.run (gs_backend_per_frame.py:776-862); the store receives the refined poses,
+    depths and stride-2 pointmaps"""
+    from types import SimpleNamespace
+    from cut3r_slam_amd.keyframe import KeyFrame
+    from cut3r_slam_amd.slam import Cut3rSlam, DEFAULT_CONFIG
+    truth = _truth()
+    g = torch.Generator().manual_seed(8)
+    true_poses = [_pose7(0.06 * k, 0.01 * (k % 2), 0.0, 0.0, -0.012 * k) for k in range(6)]
+    kf = KeyFrame(DEFAULT_CONFIG, (H, W), 16, 2, DEV, feat_dim=8, patch=16)
+    ys, xs = torch.meshgrid(torch.arange(H, device=DEV).float(), torch.arange(W, device=DEV).float(), indexing="ij")
+    noisy = []
+    for k, p in enumerate(true_poses):
+        img, depth = _observe(truth, p)
+        tw = torch.cat([torch.randn(3, generator=g) * 0.01, torch.randn(3, generator=g) * 0.002]) if k else torch.zeros(6)
+        T = SE3.exp(tw[None].to(DEV)).matrix()[0] @ GM.pose_vec_to_matrix(p[None].to(DEV))[0]
+        p_noisy = GM.SE3_from_matrix(T).cpu()
+        noisy.append(p_noisy)
+        kf.append(float(10 * k), (img * 255).round().to(torch.uint8), p_noisy.numpy(), None, depth, None, torch.tensor([FX, FY, CX, CY]))
+        pts_c = torch.stack([(xs - CX) / FX * depth, (ys - CY) / FY * depth, depth], -1)
+        kf.submap_ds[0, k] = (pts_c @ T[:3, :3].T + T[:3, 3])[::2, ::2]
+        kf.conf_ds[0, k] = 1.0
+    cfg = dict(CONFIG, Training=dict(CONFIG["Training"], window_size=10))
+    mapper = GM.GSMapper(cfg, FX, FY, CX, CY, downsample_ratio=2, device=DEV)
+    slam = SimpleNamespace(keyframes=kf, mapper=mapper, downsample_ratio=2)
+
+    def terr(poses):
+        e = []
+        for k in range(1, 6):
+            d = GM.pose_vec_to_matrix(torch.as_tensor(poses[k])[None].to(DEV))[0] @ torch.inverse(GM.pose_vec_to_matrix(true_poses[k][None].to(DEV))[0])
+            e.append(float(d[:3, 3].norm()))
+        return float(np.mean(e))
+    before = terr(noisy)
+    idx = Cut3rSlam.call_gs(slam, range(0, 6), 0, 20, torch.tensor([FX, FY, CX, CY]))
+    after = terr([kf.pose[k] for k in range(6)])
+    bg = torch.zeros(3, device=DEV)
+    with torch.no_grad():
+        psnr = np.mean([_psnr(GM.render(mapper.viewpoints[k], mapper.gaussians, bg)["render"], kf.image[k].float() / 255) for k in range(6)])
+    print(f"[gs mapper] window hand-over: {len(mapper.gaussians)} Gaussians, mean translation error {100 * before:.2f} -> {100 * after:.2f} cm, "
+          f"PSNR {psnr:.2f} dB")
+    assert sorted(idx) == list(range(6)) and len(mapper.viewpoints) == 6
+    assert after < 0.7 * before and psnr > 25.0
+    w2c = torch.inverse(GM.pose_vec_to_matrix(kf.pose[3][None].to(DEV))[0])
+    np.testing.assert_allclose(kf.w2c[3].cpu().numpy().reshape(3, 4), w2c[:3].cpu().numpy(), atol=2e-5)   # device mirror follows
+    assert torch.isfinite(kf.submap_ds[0, :6]).all() and float((kf.depth[:6] > 0).float().mean()) > 0.95
