@@ -497,12 +497,25 @@ __global__ __launch_bounds__(GS_BATCH) void gs_render_bwd_kernel(const unsigned*
                 }
             }
             if (!__any(act)) continue;
-            float* dst = dgeom + (size_t)stage_id[j] * GS_REC;
+            // 25 sums over the 64 lanes as a transposing butterfly: at each of five steps a lane keeps one half of its slots and hands the
+            // other half to its partner, so the slots per lane halve while the lanes summed double (16 + 8 + 4 + 2 + 1 exchanges instead of
+            // 25 x 6); one more exchange folds the two 32-lane halves, and lanes 0..24 issue their slot's atomic together
+            float r[32];
 #pragma unroll
-            for (int k = 0; k < GS_NGRAD; k++) {
-                const float sum = wave_sum(d[k]);
-                if (lane == 0 && sum != 0.f) atomicAdd(dst + k, sum);
+            for (int k = 0; k < 32; k++) r[k] = k < GS_NGRAD ? d[k] : 0.f;
+#define GS_BFLY(HALF, BIT)                                                                          \
+            {                                                                                       \
+                const bool up = (lane & BIT) != 0;                                                  \
+                _Pragma("unroll") for (int k = 0; k < HALF; k++) {                                  \
+                    const float send = up ? r[k] : r[k + HALF], keep = up ? r[k + HALF] : r[k];     \
+                    r[k] = keep + __shfl_xor(send, BIT);                                            \
+                }                                                                                   \
             }
+            GS_BFLY(16, 1) GS_BFLY(8, 2) GS_BFLY(4, 4) GS_BFLY(2, 8) GS_BFLY(1, 16)
+#undef GS_BFLY
+            const float total = r[0] + __shfl_xor(r[0], 32);
+            const int slot = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+            if (lane < 32 && slot < GS_NGRAD && total != 0.f) atomicAdd(dgeom + (size_t)stage_id[j] * GS_REC + slot, total);
         }
     }
 }
