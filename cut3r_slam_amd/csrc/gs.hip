@@ -370,8 +370,8 @@ __global__ __launch_bounds__(GS_BATCH) void gs_render_fwd_kernel(const unsigned*
 // Render backward (the job of backward.cu:631-1015, re-derived): per pixel the outputs are sums  Q_k = sum_i f_ki a_i T_i  over its
 // contributors (colour, coordinate, ray distance, normal, weight) plus T_final * bg, then normalised.  With G_k = dL/dQ_k the
 // scalar v_i = sum_k G_k f_ki gives  dL/da_i = v_i T_i - (sum_{j>i} v_j a_j T_j + G_T T_final) / (1 - a_i): ONE suffix sum S per pixel,
-// walked back to front with T_i = T_{i+1} / (1 - a_i).  The gradients of a Gaussian's record fields are reduced over the wave
-// (DPP) before one atomic per wave and field.  dgeom uses the record layout; slot G_DEPTH carries the |d/dxy| sum of the alpha
+// walked back to front with T_i = T_{i+1} / (1 - a_i).  The gradients of a Gaussian's record fields are summed over the wave
+// (transposing butterfly, below) before one atomic per wave and field.  dgeom uses the record layout; slot G_DEPTH carries the |d/dxy| sum of the alpha
 // path (backward.cu:1005, the densification statistic).
 constexpr int GS_NGRAD = 25;               // record slots 0..24 receive gradients
 
