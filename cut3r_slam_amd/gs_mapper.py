@@ -14,7 +14,8 @@ rasteriser.  Mirrors, with the same names, argument meaning
 The reference's backend cannot run here (CUDA rasteriser, open3d, munch): PARITY UNPINNED, covered by functional tests on a
 synthetic scene (tests/test_gs_mapper_gpu.py).  The rasteriser and the 3-NN search are the HIP kernels of csrc/gs.hip; the loss
 terms and the Adam updates are plain torch tensor arithmetic on the GPU.  Not built: GUI, exposure compensation, opacity reset
-schedule, ply export, the TSDF / evaluation utilities."""
+schedule, ply export, the TSDF / evaluation utilities.
+`gaussain_update` (the map correction after a loop closure, :701-774) composes rotations consistently by default; see its docstring."""
 from __future__ import annotations
 
 import math
@@ -257,6 +258,12 @@ def _quat_mult(a, b):
     r2, x2, y2, z2 = b.unbind(-1)
     return torch.stack([r1 * r2 - x1 * x2 - y1 * y2 - z1 * z2, r1 * x2 + x1 * r2 + y1 * z2 - z1 * y2, r1 * y2 - x1 * z2 + y1 * r2 + z1 * x2,
                         r1 * z2 + x1 * y2 - y1 * x2 + z1 * r2], -1)
+
+
+def _quat_mult_xyzw(a, b):
+    """Hamilton product of (x, y, z, w) quaternions (lietorch SO3 data order)"""
+    r = _quat_mult(torch.cat([a[:, 3:], a[:, :3]], -1), torch.cat([b[:, 3:], b[:, :3]], -1))
+    return torch.cat([r[:, 1:], r[:, :1]], -1)
 
 
 def render(viewpoint, pc, bg_color, scaling_modifier=1.0):
@@ -503,11 +510,60 @@ class GSMapper:
         self.global_BA(gba_per_view * len(self.viewpoints), densify=True)
         return self.data_update(self.h, self.w, self.current_window)
 
+    def gaussain_update(self, packet, reference_quat_order=False, refine_iters=50):
+        """gs_backend_per_frame.py:701-774 (the reference's spelling): after a loop closure the tracker hands over the corrected poses of
+        the affected keyframes (`camera_idx`, `camera_pose` [n,7] camera->world) and one SE3 correction per submap (`submap_idx`,
+        `pose_updates` [m,7]); every Gaussian born in such a submap moves with its correction (position and orientation, optimiser state
+        reset as the reference's prune + re-append does), each updated keyframe is re-refined against the moved map, and the window data
+        goes back as in data_update().
+        Orientation: the reference multiplies `SO3(update[:, 3:]) * SO3(get_rotation)`, i.e. it reads the Gaussians' (r, x, y, z)
+        quaternions as lietorch's (x, y, z, w).  That is exact only for isotropic Gaussians; the default here composes the rotations in
+        one convention (a rigid correction of the whole scene then leaves every rendering unchanged, which the test checks);
+        reference_quat_order=True reproduces the reference's arithmetic."""
+        with torch.no_grad():
+            w2cs = torch.inverse(pose_vec_to_matrix(torch.as_tensor(packet["camera_pose"]).float().to(self.device)))
+            update_idx = []
+            for i, k in enumerate(packet["camera_idx"]):
+                if k in self.viewpoints and i < w2cs.shape[0]:
+                    update_idx.append(k)
+                    self.viewpoints[k].update_RT(w2cs[i, :3, :3], w2cs[i, :3, 3])
+            sub = torch.as_tensor(list(packet["submap_idx"]), device=self.device, dtype=torch.int32)
+            upd = torch.as_tensor(packet["pose_updates"]).float().to(self.device)
+            hit = self.gaussians.kf_id[:, None] == sub[None, :]
+            gi = hit.any(dim=1).nonzero()[:, 0]
+            if gi.numel():
+                row = hit[gi].float().argmax(dim=1)
+                T = SE3(upd[row]).matrix()
+                gm = self.gaussians
+                xyz = (T[:, :3, :3] @ gm.p["xyz"].detach()[gi][:, :, None])[:, :, 0] + T[:, :3, 3]
+                rot = gm.get_rotation.detach()[gi]
+                q_u = upd[row][:, 3:]                                        # (x, y, z, w)
+                if reference_quat_order:
+                    new_rot = _quat_mult_xyzw(q_u, rot)
+                else:
+                    new_rot = _quat_mult(torch.cat([q_u[:, 3:], q_u[:, :3]], -1), rot)
+                gm.p["xyz"].data[gi] = xyz
+                gm.p["rotation"].data[gi] = new_rot
+                for k in gm.GROUPS:
+                    gm.m[k][gi] = 0
+                    gm.v[k][gi] = 0
+                gm.step_count[gi] = 0
+                gm.grad_accum.zero_()
+                gm.denom.zero_()
+                gm.max_radii2D.zero_()
+        for k in update_idx:
+            if refine_iters > 0:
+                self.pose_refine([k], iters=refine_iters, return_args=False, alpha_th=0.0)
+        return self.data_update(self.h, self.w, update_idx)
+
     @torch.no_grad()
     def data_update(self, h, w, current_window):
         """gs_backend_per_frame.py:649-699: poses (camera->world, t + q_xyzw), scale-corrected depths and their world pointmaps of the
         window's keyframes, resampled to (h, w) * downsample_ratio"""
         poses, depths, pms = [], [], []
+        if not len(current_window):
+            e = torch.zeros(0, device=self.device)
+            return {"pointmaps": e.reshape(0, 0, 0, 3), "depths": e.reshape(0, 0, 0), "poses": e.reshape(0, 7)}, []
         for k in current_window:
             v = self.viewpoints[k]
             gt = v.depth[None]

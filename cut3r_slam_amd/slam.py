@@ -85,9 +85,18 @@ class Cut3rSlam:
         lc_did = False
         if run_backend and not last_frame and self.do_lc and self.backend is not None:
             if self.freeze_counter > 0:
-                lc_did, _ = self.backend.run()
+                lc_did, updates = self.backend.run()
                 if lc_did:
                     self.freeze_counter = 0
+                    if self.mapper is not None and getattr(self.mapper, "initialized", False):      # hi2.py:124-131
+                        with torch.enable_grad():
+                            updated, idx = self.mapper.gaussain_update(updates)
+                        if idx:
+                            self.keyframes.set_poses_at(idx, updated["poses"].float().cpu().numpy())
+                            ds = self.downsample_ratio
+                            for j, k in enumerate(idx):
+                                self.keyframes.submap_ds[k // 5, k % 5] = updated["pointmaps"][j, ::ds, ::ds]
+                            self.keyframes.submap_ds[:submap_idx + 1, -1] = self.keyframes.submap_ds[1:submap_idx + 2, 0]
             else:
                 self.freeze_counter += 1
         if viz_idx is not None and self.mapper is not None:
