@@ -225,3 +225,40 @@ def test_loop_closure_correction_moves_the_map_rigidly():
     print(f"[gs mapper] rigid correction, rendering before vs after: {results[False]:.1f} dB (consistent quaternions), "
           f"{results[True]:.1f} dB (the reference's order)")
     assert results[False] > 40.0 and results[True] < results[False] - 10.0
+
+
+def test_slam_loop_with_the_mapper_attached():
+    """BASELINE config 5 in miniature (tracker + GS mapper, hi2.py:101-133): the per-frame loop with `slam.mapper` set hands every tracked
+    window to the mapper and takes its poses / depths / pointmaps back.  Random weights give meaningless geometry, so this checks the
+    plumbing (packet shapes of a real tracker, write-back, finite state), not quality."""
+    from cut3r_slam_amd.config import tiny_config
+    from cut3r_slam_amd.model import Cut3rModel
+    from cut3r_slam_amd.slam import Cut3rSlam
+    from cut3r_slam_amd.weights import synth_state_dict
+    h, w, n = 32, 48, 40
+    cfg = tiny_config("dpt")
+    model = Cut3rModel(cfg, synth_state_dict(cfg, 3), DEV, minimal=True)
+    cfgd = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 1, "kf_every": 2}, "frontend": {"iteration": 0}}, "Mapping": {"itr_num": 5}}
+    slam = Cut3rSlam(model, cfgd, (h, w), buffer=40, device=DEV)
+    mcfg = dict(CONFIG, Training=dict(CONFIG["Training"], window_size=4))
+    slam.mapper = GM.GSMapper(mcfg, 40.0, 40.0, 24.0, 16.0, downsample_ratio=2, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    base = torch.nn.functional.avg_pool2d(torch.rand(3, h + 2 * n, w + 2 * n, generator=g)[None], 5, 1, 2)[0]
+    base = (base - base.min()) / (base.max() - base.min())
+    frames = torch.stack([(base[:, t:t + h, 2 * t % n:2 * t % n + w] * 255).round().to(torch.uint8) for t in range(n)]).to(DEV)
+    intr = torch.tensor([40.0, 40.0, 24.0, 16.0])
+    calls = []
+    real_run = slam.mapper.run
+
+    def spy(packet, iterations):
+        calls.append((list(packet["viz_idx"]), tuple(packet["pointmaps"].shape), tuple(packet["depths"].shape)))
+        return real_run(packet, iterations, init_iters=5, gba_per_view=1)
+    slam.mapper.run = spy
+    for t in range(n):
+        slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr, last_frame=(t == n - 1))
+    nkf = slam.keyframes.counter.value
+    assert len(calls) >= 3 and calls[0][1][1:] == (h // 2, w // 2, 3) and calls[0][2][1:] == (h, w)
+    assert len(slam.mapper.viewpoints) >= 10 and len(slam.mapper.gaussians) > 100
+    assert torch.isfinite(slam.keyframes.pose[:nkf - 1]).all() and torch.isfinite(slam.mapper.trajectory()).all()
+    print(f"[gs mapper] slam loop: {nkf} keyframes, {len(calls)} windows handed over, {len(slam.mapper.viewpoints)} mapper views, "
+          f"{len(slam.mapper.gaussians)} Gaussians")
