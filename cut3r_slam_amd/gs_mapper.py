@@ -39,56 +39,63 @@ def pose_vec_to_matrix(p):
 
 
 class GaussianMap:
+    """Parameters of all Gaussians in ONE [P,14] block (xyz 3 | DC colour 3 | opacity logit 1 | log scale 3 | quaternion 4) with its Adam
+    moments and per-Gaussian step counts beside it: growth and pruning are row operations on three tensors, the optimiser step is one
+    pass over the block with a per-column learning rate, `p[name]` are column views."""
     GROUPS = ("xyz", "f_dc", "opacity", "scaling", "rotation")
+    COLS = {"xyz": (0, 3), "f_dc": (3, 6), "opacity": (6, 7), "scaling": (7, 10), "rotation": (10, 14)}
 
     def __init__(self, opt, device="cuda:0", isotropic=False):
         self.device, self.isotropic = torch.device(device), isotropic
         z = lambda *s: torch.zeros(*s, device=self.device)
-        self.p = {"xyz": z(0, 3), "f_dc": z(0, 3), "opacity": z(0, 1), "scaling": z(0, 3), "rotation": z(0, 4)}
-        for t in self.p.values():
-            t.requires_grad_(True)
-        self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
-        self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
-        self.lr = {"xyz": opt["position_lr_init"], "f_dc": opt["feature_lr"], "opacity": opt["opacity_lr"], "scaling": opt["scaling_lr"],
-                   "rotation": opt["rotation_lr"]}
+        self.theta = z(0, 14).requires_grad_(True)
+        self.m, self.v = z(0, 14), z(0, 14)
+        lr = {"xyz": opt["position_lr_init"], "f_dc": opt["feature_lr"], "opacity": opt["opacity_lr"], "scaling": opt["scaling_lr"],
+              "rotation": opt["rotation_lr"]}
+        self.lr = z(1, 14)
+        for k, (a, b) in self.COLS.items():
+            self.lr[0, a:b] = lr[k]
         self.percent_dense = opt.get("percent_dense", 0.01)
         self.step_count = z(0, 1)
         self.kf_id = torch.zeros(0, dtype=torch.int32, device=self.device)
         self.max_radii2D = z(0)
         self.grad_accum, self.denom = z(0, 1), z(0, 1)
 
+    @property
+    def p(self):
+        return {k: self.theta[:, a:b] for k, (a, b) in self.COLS.items()}
+
     # ---- activations (gaussian_model.py:77-101)
     def __len__(self):
-        return self.p["xyz"].shape[0]
+        return self.theta.shape[0]
 
     @property
     def get_xyz(self):
-        return self.p["xyz"]
+        return self.theta[:, 0:3]
 
     @property
     def get_scaling(self):
-        return torch.exp(self.p["scaling"])
+        return torch.exp(self.theta[:, 7:10])
 
     @property
     def get_rotation(self):
-        return F.normalize(self.p["rotation"], dim=-1)
+        return F.normalize(self.theta[:, 10:14], dim=-1)
 
     @property
     def get_opacity(self):
-        return torch.sigmoid(self.p["opacity"])
+        return torch.sigmoid(self.theta[:, 6:7])
 
     @property
     def get_features(self):
-        return self.p["f_dc"][:, None, :]                                 # [P,1,3]: SH degree 0, as the backend runs the model
+        return self.theta[:, None, 3:6]                                   # [P,1,3]: SH degree 0, as the backend runs the model
 
     # ---- growth
     def _append(self, new, kf_id):
-        n = new["xyz"].shape[0]
-        for k in self.GROUPS:
-            self.p[k] = torch.cat([self.p[k].detach(), new[k].to(self.device).float()], 0).requires_grad_(True)
-            self.m[k] = torch.cat([self.m[k], torch.zeros_like(new[k], device=self.device, dtype=torch.float32)], 0)
-            self.v[k] = torch.cat([self.v[k], torch.zeros_like(new[k], device=self.device, dtype=torch.float32)], 0)
+        rows = torch.cat([new[k].to(self.device).float().reshape(-1, b - a) for k, (a, b) in self.COLS.items()], 1)
+        n = rows.shape[0]
         z = lambda *s: torch.zeros(*s, device=self.device)
+        self.theta = torch.cat([self.theta.detach(), rows], 0).requires_grad_(True)
+        self.m, self.v = torch.cat([self.m, z(n, 14)], 0), torch.cat([self.v, z(n, 14)], 0)
         self.step_count = torch.cat([self.step_count, z(n, 1)], 0)
         self.kf_id = torch.cat([self.kf_id, kf_id.to(self.device, torch.int32)], 0)
         self.max_radii2D = torch.cat([self.max_radii2D, z(n)], 0)
@@ -115,16 +122,21 @@ class GaussianMap:
 
     def prune_points(self, mask):
         keep = ~mask
-        for k in self.GROUPS:
-            self.p[k] = self.p[k].detach()[keep].requires_grad_(True)
-            self.m[k], self.v[k] = self.m[k][keep], self.v[k][keep]
+        self.theta = self.theta.detach()[keep].requires_grad_(True)
+        self.m, self.v = self.m[keep], self.v[keep]
         self.step_count, self.kf_id, self.max_radii2D = self.step_count[keep], self.kf_id[keep], self.max_radii2D[keep]
         self.grad_accum, self.denom = self.grad_accum[keep], self.denom[keep]
 
+    def reset_moments(self, rows):
+        """optimiser state of the given Gaussians back to that of new ones (what the reference's prune + re-append does)"""
+        self.m[rows] = 0
+        self.v[rows] = 0
+        self.step_count[rows] = 0
+
     def add_densification_stats(self, viewspace_grad, update_filter):
         """gaussian_model.py:779-790: norm of the screen-space gradient (x, y) per visible Gaussian"""
-        self.grad_accum[update_filter] += torch.norm(viewspace_grad[update_filter, :2], dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
+        self.grad_accum += torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True) * update_filter[:, None]
+        self.denom += update_filter[:, None].float()
 
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
         """gaussian_model.py:639-777: clone small Gaussians with a large mean screen gradient, split large ones in two, then prune the
@@ -134,20 +146,21 @@ class GaussianMap:
         big = self.get_scaling.detach().max(dim=1).values > self.percent_dense * extent
         hot = grads[:, 0] >= max_grad
         clone, split = hot & ~big, hot & big
+        th = self.theta.detach()
         new = []
         if clone.any():
-            new.append(({k: self.p[k].detach()[clone].clone() for k in self.GROUPS}, self.kf_id[clone]))
+            new.append((th[clone].clone(), self.kf_id[clone]))
         if split.any():
             n = int(split.sum())
             std = self.get_scaling.detach()[split].repeat(2, 1)
             R = SO3_matrix(self.get_rotation.detach()[split]).repeat(2, 1, 1)
-            xyz = (R @ (torch.randn(2 * n, 3, device=self.device) * std)[:, :, None])[:, :, 0] + self.p["xyz"].detach()[split].repeat(2, 1)
-            s = {k: self.p[k].detach()[split].repeat(2, 1) for k in self.GROUPS}
-            s["xyz"], s["scaling"] = xyz, torch.log(std / (0.8 * 2))
-            new.append((s, self.kf_id[split].repeat(2)))
+            rows = th[split].repeat(2, 1)
+            rows[:, 0:3] = (R @ (torch.randn(2 * n, 3, device=self.device) * std)[:, :, None])[:, :, 0] + rows[:, 0:3]
+            rows[:, 7:10] = torch.log(std / (0.8 * 2))
+            new.append((rows, self.kf_id[split].repeat(2)))
         n_before = len(self)
-        for s, ids in new:
-            self._append(s, ids)
+        for rows, ids in new:
+            self._append({k: rows[:, a:b] for k, (a, b) in self.COLS.items()}, ids)
         drop = torch.zeros(len(self), dtype=torch.bool, device=self.device)
         drop[:n_before] = split
         drop |= (self.get_opacity.detach() < min_opacity)[:, 0]
@@ -161,23 +174,18 @@ class GaussianMap:
     # ---- Adam (torch.optim.Adam(lr per group, eps=1e-15) of gaussian_model.py:374-417, with per-Gaussian step counts so that appended
     #      Gaussians start their own bias correction)
     def zero_grad(self):
-        for t in self.p.values():
-            t.grad = None
+        self.theta.grad = None
 
     @torch.no_grad()
     def step(self, b1=0.9, b2=0.999, eps=1e-15):
-        touched = None
-        for k in self.GROUPS:
-            g = self.p[k].grad
-            if g is None:
-                continue
-            if touched is None:
-                self.step_count += 1
-                touched = True
-            self.m[k].mul_(b1).add_(g, alpha=1 - b1)
-            self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
-            bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
-            self.p[k].sub_(self.lr[k] * (self.m[k] / bc1) / ((self.v[k] / bc2).sqrt() + eps))
+        g = self.theta.grad
+        if g is None:
+            return
+        self.step_count += 1
+        self.m.mul_(b1).add_(g, alpha=1 - b1)
+        self.v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
+        self.theta.sub_(self.lr * (self.m / bc1) / ((self.v / bc2).sqrt() + eps))
 
 
 def SO3_matrix(q):
@@ -200,6 +208,7 @@ class Camera:
         self.FoVx, self.FoVy = 2 * math.atan(self.image_width / (2 * self.fx)), 2 * math.atan(self.image_height / (2 * self.fy))
         w2c = torch.as_tensor(w2c, dtype=torch.float32, device=dev)
         self.R, self.T = w2c[:3, :3].clone(), w2c[:3, 3].clone()
+        self.w2c_data = SE3_from_matrix(w2c).detach()                   # (t, q_xyzw): the pose the lie kernels compose the deltas with
         self.cam_rot_delta = torch.zeros(3, device=dev, requires_grad=True)
         self.cam_trans_delta = torch.zeros(3, device=dev, requires_grad=True)
         # pinhole projection in the rasteriser's NDC (pixel u = ((ndc + 1) W - 1) / 2, forward.cu ndc2Pix): u = fx X/Z + cx exactly;
@@ -210,47 +219,55 @@ class Camera:
         P[0, 2], P[1, 2] = (2 * self.cx + 1) / W - 1, (2 * self.cy + 1) / H - 1
         P[3, 2], P[2, 2], P[2, 3] = 1.0, zfar / (zfar - znear), -(zfar * znear) / (zfar - znear)
         self.projection_matrix = P.T.contiguous().to(dev)
+        self.projection_matrix_host = P.T.contiguous()                  # the rasteriser reads its matrices on the host: no copy back per render
 
-    def update_RT(self, R, T):
+    def update_RT(self, R, T, data=None):
         self.R, self.T = R.detach().clone(), T.detach().clone()
+        M = torch.eye(4, device=self.device)
+        M[:3, :3], M[:3, 3] = self.R, self.T
+        self.w2c_data = data.detach().clone() if data is not None else SE3_from_matrix(M).detach()
 
     @property
     def camera_center(self):
         return -(self.R.T @ self.T)
 
 
-def get_pose(camera):
-    """slam_utils.py:93-102"""
+def get_pose_se3(camera):
+    """slam_utils.py:93-102 on the lie kernels: exp([trans delta, rot delta]) * T_w2c as an SE3 element (autograd to the deltas)"""
     tau = torch.cat([camera.cam_trans_delta, camera.cam_rot_delta], 0)
-    T = torch.eye(4, device=camera.device)
-    T[:3, :3], T[:3, 3] = camera.R, camera.T
-    return SE3.exp(tau[None]).matrix()[0] @ T
+    return SE3.exp(tau[None]) * SE3(camera.w2c_data[None])
+
+
+def get_pose(camera):
+    """slam_utils.py:93-102: the 4x4 world->camera matrix"""
+    return get_pose_se3(camera).matrix()[0]
 
 
 @torch.no_grad()
 def update_pose(camera):
     """slam_utils.py:77-91"""
-    new = get_pose(camera)
-    camera.update_RT(new[:3, :3], new[:3, 3])
+    new = get_pose_se3(camera)
+    M = new.matrix()[0]
+    camera.update_RT(M[:3, :3], M[:3, 3], data=new.data[0])
     camera.cam_rot_delta.data.fill_(0)
     camera.cam_trans_delta.data.fill_(0)
 
 
 def _rotmat_to_quat(R):
-    """renderer/__init__.py:165-195, branch-free through atan-free copysign form (r, x, y, z); differentiable"""
+    """renderer/__init__.py:165-195 as tensor selects (no host round trip): the four largest-diagonal candidates are formed and the
+    reference's branch order picks one; (r, x, y, z), differentiable"""
     m00, m11, m22 = R[0, 0], R[1, 1], R[2, 2]
     r = torch.sqrt(torch.clamp(1 + m00 + m11 + m22, min=1e-12)) / 2
     x = torch.sqrt(torch.clamp(1 + m00 - m11 - m22, min=1e-12)) / 2
     y = torch.sqrt(torch.clamp(1 - m00 + m11 - m22, min=1e-12)) / 2
     z = torch.sqrt(torch.clamp(1 - m00 - m11 + m22, min=1e-12)) / 2
-    m00d, m11d, m22d = float(m00.detach()), float(m11.detach()), float(m22.detach())
-    if m00d + m11d + m22d > 0:
-        return torch.stack([r, (R[2, 1] - R[1, 2]) / (4 * r), (R[0, 2] - R[2, 0]) / (4 * r), (R[1, 0] - R[0, 1]) / (4 * r)])
-    if m00d > m11d and m00d > m22d:
-        return torch.stack([(R[2, 1] - R[1, 2]) / (4 * x), x, (R[0, 1] + R[1, 0]) / (4 * x), (R[0, 2] + R[2, 0]) / (4 * x)])
-    if m11d > m22d:
-        return torch.stack([(R[0, 2] - R[2, 0]) / (4 * y), (R[0, 1] + R[1, 0]) / (4 * y), y, (R[1, 2] + R[2, 1]) / (4 * y)])
-    return torch.stack([(R[1, 0] - R[0, 1]) / (4 * z), (R[0, 2] + R[2, 0]) / (4 * z), (R[1, 2] + R[2, 1]) / (4 * z), z])
+    c0 = torch.stack([r, (R[2, 1] - R[1, 2]) / (4 * r), (R[0, 2] - R[2, 0]) / (4 * r), (R[1, 0] - R[0, 1]) / (4 * r)])
+    c1 = torch.stack([(R[2, 1] - R[1, 2]) / (4 * x), x, (R[0, 1] + R[1, 0]) / (4 * x), (R[0, 2] + R[2, 0]) / (4 * x)])
+    c2 = torch.stack([(R[0, 2] - R[2, 0]) / (4 * y), (R[0, 1] + R[1, 0]) / (4 * y), y, (R[1, 2] + R[2, 1]) / (4 * y)])
+    c3 = torch.stack([(R[1, 0] - R[0, 1]) / (4 * z), (R[0, 2] + R[2, 0]) / (4 * z), (R[1, 2] + R[2, 1]) / (4 * z), z])
+    with torch.no_grad():
+        t0, t1, t2 = (m00 + m11 + m22) > 0, (m00 > m11) & (m00 > m22), m11 > m22
+    return torch.where(t0, c0, torch.where(t1, c1, torch.where(t2, c2, c3)))
 
 
 def _quat_mult(a, b):
@@ -269,16 +286,20 @@ def _quat_mult_xyzw(a, b):
 def render(viewpoint, pc, bg_color, scaling_modifier=1.0):
     """renderer/__init__.py:89-152: the Gaussians are moved into the camera frame (so the pose receives gradients through means and
     rotations) and rasterised with an identity view matrix; returns the reference's dict"""
-    w2c = get_pose(viewpoint)
+    pose = get_pose_se3(viewpoint)
+    w2c = pose.matrix()[0]
     xyz = pc.get_xyz @ w2c[:3, :3].T + w2c[:3, 3]
-    rot = _quat_mult(F.normalize(_rotmat_to_quat(w2c[:3, :3]), dim=-1)[None], pc.get_rotation)
+    q = pose.data[0, 3:]                                                  # (x, y, z, w) of the camera rotation
+    rot = _quat_mult(F.normalize(torch.cat([q[3:], q[:3]]), dim=-1)[None], pc.get_rotation)
     screenspace_points = torch.zeros_like(xyz, requires_grad=True)
-    view = torch.eye(4, device=xyz.device)
+    bg_host = getattr(pc, "_bg_host", None)
+    if bg_host is None or bg_host[0] is not bg_color:
+        bg_host = pc._bg_host = (bg_color, bg_color.detach().cpu())
     st = GaussianRasterizationSettings(image_height=int(viewpoint.image_height), image_width=int(viewpoint.image_width),
-                                       tanfovx=math.tan(viewpoint.FoVx * 0.5), tanfovy=math.tan(viewpoint.FoVy * 0.5), kernel_size=0.0, bg=bg_color,
-                                       scale_modifier=scaling_modifier, viewmatrix=view, projmatrix=view @ viewpoint.projection_matrix, sh_degree=0,
-                                       campos=torch.zeros(3, device=xyz.device), prefiltered=False, require_coord=True, require_depth=True,
-                                       debug=False)
+                                       tanfovx=math.tan(viewpoint.FoVx * 0.5), tanfovy=math.tan(viewpoint.FoVy * 0.5), kernel_size=0.0,
+                                       bg=bg_host[1], scale_modifier=scaling_modifier, viewmatrix=torch.eye(4),
+                                       projmatrix=viewpoint.projection_matrix_host, sh_degree=0, campos=torch.zeros(3), prefiltered=False,
+                                       require_coord=True, require_depth=True, debug=False)
     color, radii, coord, mcoord, depth, mdepth, alpha, normal = GaussianRasterizer(st)(
         means3D=xyz, means2D=screenspace_points, opacities=pc.get_opacity, shs=pc.get_features, scales=pc.get_scaling, rotations=rot)
     return {"render": color, "mask": alpha, "expected_coord": coord, "median_coord": mcoord, "depth": depth, "median_depth": mdepth,
@@ -353,13 +374,13 @@ class GSMapper:
                     gt_depth = v.depth[None]
                     amask = (alpha > alpha_th).detach()
                     ratio = amask.sum() / amask.numel()
-                    dmask = (gt_depth > 0.001) & (depth > 0.001) & amask
-                    rgb = torch.abs((v.original_image - image)[:, amask[0]]).mean() if amask.any() else image.sum() * 0
-                    if dmask.any():
-                        diff = torch.log(depth[dmask]) - torch.log(gt_depth[dmask])
-                        dl = (diff ** 2).mean() - diff.mean() ** 2
-                    else:
-                        dl = depth.sum() * 0
+                    dmask = ((gt_depth > 0.001) & (depth > 0.001) & amask).detach()
+                    # masked means written as sums (no boolean indexing: that would read the count back to the host every iteration)
+                    rgb = (torch.abs(v.original_image - image) * amask).sum() / (3 * amask.sum()).clamp_min(1)
+                    nd = dmask.sum().clamp_min(1)
+                    diff = torch.where(dmask, torch.log(torch.where(dmask, depth, torch.ones_like(depth))) -
+                                       torch.log(torch.where(dmask, gt_depth, torch.ones_like(gt_depth))), torch.zeros_like(depth))
+                    dl = (diff ** 2).sum() / nd - (diff.sum() / nd) ** 2
                     pl = (v.cam_rot_delta ** 2).sum() + (v.cam_trans_delta ** 2).sum()
                     rgb_all, depth_all, pose_all = rgb_all + ratio * rgb, depth_all + ratio * dl, pose_all + (2 - ratio) * pl
                 loss = (5 * rgb_all + depth_all + 0.05 * pose_all) / B
@@ -424,11 +445,17 @@ class GSMapper:
                 gt_image, gt_depth = v.original_image, v.depth[None]
                 rgb = 0.8 * torch.abs(gt_image - image).mean() + 0.2 * (1.0 - ssim(image, gt_image))
                 dmask = ((gt_depth > 0.001) & (depth > 0.001)).detach()
-                dl = torch.abs(1.0 / depth[dmask] - 1.0 / gt_depth[dmask]).mean() if dmask.any() else depth.sum() * 0
-                dn, gn = depth_to_normal(v, depth), depth_to_normal(v, gt_depth)
-                nl = (1 - (dn[:, dmask[0]] * gn[:, dmask[0]]).sum(0)).mean() if dmask.any() else depth.sum() * 0
-                sc = self.gaussians.get_scaling[pkg["visibility_filter"]]
-                iso = torch.abs(sc - sc.mean(dim=1, keepdim=True)).mean() if sc.numel() else depth.sum() * 0
+                nd = dmask.sum().clamp_min(1)
+                one = torch.ones_like(depth)
+                dl = (torch.abs(1.0 / torch.where(dmask, depth, one) - 1.0 / torch.where(dmask, gt_depth, one)) * dmask).sum() / nd
+                gcache = getattr(v, "_gt_normal", None)
+                if gcache is None or gcache[0] is not v.depth:               # the keyframe's own depth normals change only with its depth
+                    gcache = v._gt_normal = (v.depth, depth_to_normal(v, gt_depth).detach())
+                dn, gn = depth_to_normal(v, depth), gcache[1]
+                nl = ((1 - (dn * gn).sum(0, keepdim=True)) * dmask).sum() / nd
+                vis = pkg["visibility_filter"]
+                sc = self.gaussians.get_scaling
+                iso = (torch.abs(sc - sc.mean(dim=1, keepdim=True)) * vis[:, None]).sum() / (3 * vis.sum()).clamp_min(1)
                 loss = loss + rgb + self.lambda_depth * dl + self.lambda_normal * nl + self.lambda_iso * iso
                 stats.append((pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]))
             loss = loss / N
@@ -439,7 +466,7 @@ class GSMapper:
             with torch.no_grad():
                 if densify:
                     for vs, vis, radii in stats:
-                        self.gaussians.max_radii2D[vis] = torch.max(self.gaussians.max_radii2D[vis], radii[vis].float())
+                        self.gaussians.max_radii2D = torch.max(self.gaussians.max_radii2D, radii.float() * vis)
                         self.gaussians.add_densification_stats(vs.grad, vis)
                 self.gaussians.step()
                 if densify and it in (iters // 4, iters // 2):
@@ -542,12 +569,9 @@ class GSMapper:
                     new_rot = _quat_mult_xyzw(q_u, rot)
                 else:
                     new_rot = _quat_mult(torch.cat([q_u[:, 3:], q_u[:, :3]], -1), rot)
-                gm.p["xyz"].data[gi] = xyz
-                gm.p["rotation"].data[gi] = new_rot
-                for k in gm.GROUPS:
-                    gm.m[k][gi] = 0
-                    gm.v[k][gi] = 0
-                gm.step_count[gi] = 0
+                gm.theta.data[gi, 0:3] = xyz
+                gm.theta.data[gi, 10:14] = new_rot
+                gm.reset_moments(gi)
                 gm.grad_accum.zero_()
                 gm.denom.zero_()
                 gm.max_radii2D.zero_()
