@@ -621,6 +621,94 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ pts
     if (live) out[i] = (b0 + b1 + b2) / 3.f;
 }
 
+// ------------------------------------------------------------------------------------------------ SSIM (the mapper's colour loss)
+// hislam2/gaussian/utils/loss_utils.py:129-170 (`ssim`, 11x11 Gaussian window sigma 1.5, zero padding, per channel) as two
+// separable passes through LDS: a 16x16 output tile reads its 26x26 neighbourhood of both images once, filters the five moments
+// (a, b, a^2, b^2, ab) horizontally into LDS and vertically into registers.  The forward pass also stores the three partials the
+// backward pass needs (dS/dmu1, dS/dE[a^2], dS/dE[ab]); the backward pass filters those maps with the same (symmetric) window:
+// dL/da(p) = g * [ (w * dS/dmu1)(p) + 2 a(p) (w * dS/dE[a^2])(p) + b(p) (w * dS/dE[ab])(p) ].
+constexpr int SS_T = 16, SS_R = 5, SS_IN = SS_T + 2 * SS_R;       // tile, window radius, input tile edge
+__constant__ float SS_G[11] = {0.00102838f, 0.00759876f, 0.03600077f, 0.10936069f, 0.21300553f, 0.26601172f,
+                               0.21300553f, 0.10936069f, 0.03600077f, 0.00759876f, 0.00102838f};
+
+template <int NMAP>
+DEVINL void ss_filter(const float (&in)[NMAP][SS_IN][SS_IN + 1], float (&tmp)[NMAP][SS_IN][SS_T + 1], float* out, int tx, int ty) {
+    // horizontal: SS_IN rows x SS_T columns per map, spread over the 256 threads
+    for (int e = ty * SS_T + tx; e < SS_IN * SS_T; e += SS_T * SS_T) {
+        const int r = e / SS_T, c = e - r * SS_T;
+#pragma unroll
+        for (int m = 0; m < NMAP; m++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) acc = fmaf(SS_G[k], in[m][r][c + k], acc);
+            tmp[m][r][c] = acc;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NMAP; m++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) acc = fmaf(SS_G[k], tmp[m][ty + k][tx], acc);
+        out[m] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int H, int W,
+                                                       float* __restrict__ smap, float* __restrict__ dmu1, float* __restrict__ dx11,
+                                                       float* __restrict__ dx12) {
+    __shared__ float in[5][SS_IN][SS_IN + 1];
+    __shared__ float tmp[5][SS_IN][SS_T + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, ch = blockIdx.z;
+    const int x0 = blockIdx.x * SS_T - SS_R, y0 = blockIdx.y * SS_T - SS_R;
+    const float* pa = a + (size_t)ch * H * W;
+    const float* pb = b + (size_t)ch * H * W;
+    for (int e = threadIdx.x; e < SS_IN * SS_IN; e += 256) {
+        const int r = e / SS_IN, c = e - r * SS_IN, y = y0 + r, x = x0 + c;
+        const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+        const float va = ok ? pa[(size_t)y * W + x] : 0.f, vb = ok ? pb[(size_t)y * W + x] : 0.f;
+        in[0][r][c] = va; in[1][r][c] = vb; in[2][r][c] = va * va; in[3][r][c] = vb * vb; in[4][r][c] = va * vb;
+    }
+    __syncthreads();
+    float f[5];
+    ss_filter<5>(in, tmp, f, tx, ty);
+    const int x = blockIdx.x * SS_T + tx, y = blockIdx.y * SS_T + ty;
+    if (x >= W || y >= H) return;
+    const float mu1 = f[0], mu2 = f[1], s11 = f[2] - mu1 * mu1, s22 = f[3] - mu2 * mu2, s12 = f[4] - mu1 * mu2;
+    const float C1 = 0.0001f, C2 = 0.0009f;
+    const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+    const float iB = 1.f / (B1 * B2), S = A1 * A2 * iB;
+    const size_t o = (size_t)ch * H * W + (size_t)y * W + x;
+    smap[o] = S;
+    dmu1[o] = 2.f * mu2 * (A2 - A1) * iB - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);
+    dx11[o] = -S / B2;
+    dx12[o] = 2.f * A1 * iB;
+}
+
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ dmu1, const float* __restrict__ dx11,
+                                                       const float* __restrict__ dx12, int H, int W, const float* __restrict__ gscale,
+                                                       float* __restrict__ grad_a) {
+    __shared__ float in[3][SS_IN][SS_IN + 1];
+    __shared__ float tmp[3][SS_IN][SS_T + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, ch = blockIdx.z;
+    const int x0 = blockIdx.x * SS_T - SS_R, y0 = blockIdx.y * SS_T - SS_R;
+    const size_t plane = (size_t)ch * H * W;
+    for (int e = threadIdx.x; e < SS_IN * SS_IN; e += 256) {
+        const int r = e / SS_IN, c = e - r * SS_IN, y = y0 + r, x = x0 + c;
+        const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+        const size_t o = plane + (size_t)y * W + x;
+        in[0][r][c] = ok ? dmu1[o] : 0.f; in[1][r][c] = ok ? dx11[o] : 0.f; in[2][r][c] = ok ? dx12[o] : 0.f;
+    }
+    __syncthreads();
+    float f[3];
+    ss_filter<3>(in, tmp, f, tx, ty);
+    const int x = blockIdx.x * SS_T + tx, y = blockIdx.y * SS_T + ty;
+    if (x >= W || y >= H) return;
+    const size_t o = plane + (size_t)y * W + x;
+    grad_a[o] = gscale[0] * (f[0] + 2.f * a[o] * f[1] + b[o] * f[2]);
+}
+
 }  // namespace
 
 static int gs_fill_cam(GsCam& cam, const float* view, const float* proj, const float* campos, int W, int H, float tanx, float tany, float ks,
@@ -741,5 +829,21 @@ extern "C" int cut3r_gs_preprocess_backward(int P, const float* means, const flo
 extern "C" int cut3r_knn3_mean_dist2(const float* points, int P, float* out, void* stream) {
     if (!points || !out || P < 4) return CUT3R_ERR_ARG;                      // three OTHER points must exist
     hipLaunchKernelGGL(knn3_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, points, P, out);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_ssim_forward(const float* a, const float* b, int C, int H, int W, float* ssim_map, float* d_mu1, float* d_x11, float* d_x12,
+                                  void* stream) {
+    if (!a || !b || !ssim_map || !d_mu1 || !d_x11 || !d_x12 || C <= 0 || H <= 0 || W <= 0) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C), dim3(256), 0, (hipStream_t)stream, a, b, H, W, ssim_map,
+                       d_mu1, d_x11, d_x12);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_ssim_backward(const float* a, const float* b, const float* d_mu1, const float* d_x11, const float* d_x12, int C, int H,
+                                   int W, const float* grad_scale, float* grad_a, void* stream) {
+    if (!a || !b || !d_mu1 || !d_x11 || !d_x12 || !grad_scale || !grad_a || C <= 0 || H <= 0 || W <= 0) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C), dim3(256), 0, (hipStream_t)stream, a, b, d_mu1, d_x11,
+                       d_x12, H, W, grad_scale, grad_a);
     return cut3r_check_launch();
 }

@@ -204,3 +204,32 @@ def distCUDA2(points):
     out = torch.empty(pts.shape[0], dtype=torch.float32, device=pts.device)
     check(_lib.load().cut3r_knn3_mean_dist2(_p(pts), pts.shape[0], _p(out), _s()), "knn3_mean_dist2")
     return out
+
+
+class _FusedSSIM(torch.autograd.Function):
+    """mean SSIM of a rendered image against a fixed image on the fused HIP kernels (`cut3r_ssim_forward/backward`)"""
+
+    @staticmethod
+    def forward(ctx, img, target):
+        a, b = img.detach().contiguous().float(), target.detach().contiguous().float()
+        Cn, H, W = a.shape
+        smap, d1, d2, d3 = (torch.empty_like(a) for _ in range(4))
+        check(_lib.load().cut3r_ssim_forward(_p(a), _p(b), Cn, H, W, _p(smap), _p(d1), _p(d2), _p(d3), _s()), "ssim_forward")
+        ctx.save_for_backward(a, b, d1, d2, d3)
+        return smap.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, d1, d2, d3 = ctx.saved_tensors
+        Cn, H, W = a.shape
+        scale = (g.detach().float() / a.numel()).reshape(1).contiguous()
+        grad = torch.empty_like(a)
+        check(_lib.load().cut3r_ssim_backward(_p(a), _p(b), _p(d1), _p(d2), _p(d3), Cn, H, W, _p(scale), _p(grad), _s()), "ssim_backward")
+        return grad, None
+
+
+def fused_ssim(img, target):
+    """loss_utils.py:129-170 `ssim(img1, img2)` with size_average=True; img [C,H,W] (gradients flow to it), target [C,H,W] constant"""
+    if img.device.type != "cuda":
+        raise RuntimeError("fused_ssim: tensors must live on the GPU")
+    return _FusedSSIM.apply(img, target)

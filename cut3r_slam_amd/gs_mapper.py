@@ -23,7 +23,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from .gaussian_rasterizer import GaussianRasterizationSettings, GaussianRasterizer, distCUDA2
+from .gaussian_rasterizer import GaussianRasterizationSettings, GaussianRasterizer, distCUDA2, fused_ssim
 from .lietorch import SE3
 
 SH_C0 = 0.28209479177387814
@@ -287,8 +287,7 @@ def render(viewpoint, pc, bg_color, scaling_modifier=1.0):
     """renderer/__init__.py:89-152: the Gaussians are moved into the camera frame (so the pose receives gradients through means and
     rotations) and rasterised with an identity view matrix; returns the reference's dict"""
     pose = get_pose_se3(viewpoint)
-    w2c = pose.matrix()[0]
-    xyz = pc.get_xyz @ w2c[:3, :3].T + w2c[:3, 3]
+    xyz = pose.act(pc.get_xyz)                                            # (a [P,3] x [3,3] product through rocBLAS cost 0.14 ms)
     q = pose.data[0, 3:]                                                  # (x, y, z, w) of the camera rotation
     rot = _quat_mult(F.normalize(torch.cat([q[3:], q[:3]]), dim=-1)[None], pc.get_rotation)
     screenspace_points = torch.zeros_like(xyz, requires_grad=True)
@@ -326,9 +325,14 @@ def depth_to_normal(viewpoint, depth):
     return F.pad(n, (1, 1, 1, 1))
 
 
-def ssim(a, b, window=11, sigma=1.5):
-    """gaussian/utils/loss_utils.py ssim: 11x11 Gaussian window, per-channel, mean over the image"""
-    g = torch.exp(-((torch.arange(window, device=a.device).float() - window // 2) ** 2) / (2 * sigma * sigma))
+def ssim(a, b):
+    """gaussian/utils/loss_utils.py:129-170 ssim on the fused kernels: a = the rendering (receives gradients), b = the keyframe image"""
+    return fused_ssim(a, b)
+
+
+def ssim_torch(a, b, window=11, sigma=1.5):
+    """the same quantity in plain tensor operations (tests compare the fused kernels with it)"""
+    g = torch.exp(-((torch.arange(window, device=a.device).to(a.dtype) - window // 2) ** 2) / (2 * sigma * sigma))
     g = (g / g.sum())[:, None]
     w = (g @ g.T)[None, None].expand(a.shape[0], 1, window, window).contiguous()
     f = lambda t: F.conv2d(t[None], w, padding=window // 2, groups=a.shape[0])[0]

@@ -358,6 +358,14 @@ int cut3r_gs_preprocess_backward(int P, const float* means, const float* scales,
 /* simple_knn._C.distCUDA2 (call sites hislam2/gaussian/scene/gaussian_model.py:191,313; the extension is not vendored in the
  * reference tree): points [P,3] -> out [P], the mean squared distance to the 3 nearest other points.  P >= 4. */
 int cut3r_knn3_mean_dist2(const float* points, int P, float* out, void* stream);
+/* SSIM of the mapper's colour loss (hislam2/gaussian/utils/loss_utils.py:129-170: 11x11 Gaussian window, sigma 1.5, zero padding,
+ * per channel).  forward: a, b [C,H,W] -> ssim_map [C,H,W] and the three partials the backward pass filters (d S / d mu1,
+ * d S / d E[a^2], d S / d E[ab]).  backward: grad_a = grad_scale[0] * d(sum ssim_map)/d a  (grad_scale: ONE device float, e.g. the
+ * upstream gradient over C*H*W for a mean).  b is treated as constant (the keyframe image). */
+int cut3r_ssim_forward(const float* a, const float* b, int C, int H, int W, float* ssim_map, float* d_mu1, float* d_x11, float* d_x12,
+                       void* stream);
+int cut3r_ssim_backward(const float* a, const float* b, const float* d_mu1, const float* d_x11, const float* d_x12, int C, int H, int W,
+                        const float* grad_scale, float* grad_a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -182,3 +182,21 @@ def test_knn_mean_distance_matches_kdtree_and_alias_imports():
         assert d2 is distCUDA2
     finally:
         sys.path.remove(compat)
+
+
+@pytest.mark.parametrize("C,H,W", [(3, 96, 128), (3, 37, 50), (1, 16, 16)])
+def test_fused_ssim_matches_convolutions_forward_and_backward(C, H, W):
+    """cut3r_ssim_forward/backward vs the conv2d formulation of loss_utils.py:140-170 (fp64): value and gradient w.r.t. the first image"""
+    from cut3r_slam_amd.gaussian_rasterizer import fused_ssim
+    from cut3r_slam_amd.gs_mapper import ssim_torch
+    g = torch.Generator().manual_seed(C * H + W)
+    a = torch.rand(C, H, W, generator=g)
+    b = (a + 0.2 * torch.randn(C, H, W, generator=g)).clamp(0, 1)
+    a64 = a.double().requires_grad_(True)
+    ref = ssim_torch(a64, b.double())
+    ref.backward()
+    ag = a.to(DEV).requires_grad_(True)
+    got = fused_ssim(ag, b.to(DEV))
+    (3.0 * got).backward()
+    assert abs(float(got) - float(ref)) < 2e-6
+    np.testing.assert_allclose(ag.grad.cpu().numpy() / 3.0, a64.grad.numpy(), atol=2e-6 * float(a64.grad.abs().max()) + 1e-10)
