@@ -20,7 +20,8 @@ Beside it, in the same JSON line (rank 0, N = 1):
                      (window_batch=1), the default batch over ONE endless stream (no sequence cuts: every keyframe is tested
                      against all earlier ones), and the maintained configs' OVERLAP mode (kf_every=-1, skip=5, thresh=0.9,
                      config/scannet_config.yaml:20-25): encoder + patch-overlap test every 5th frame, one window at a time,
-                     through Cut3rSlam.run -- frame by frame, and with the batched look-ahead of the buffered driver
+                     through Cut3rSlam.run -- frame by frame, and with the batched look-ahead of the buffered driver; and the GS
+                     mapper (BASELINE config 5's backend) on a synthetic 6-keyframe window: seconds, ms per render iteration, PSNR
   trajectory_parity  the metric's second half: Cut3rSlam on HIP vs the CPU restatement of the reference loop
                      (oracle/slam_run.py) on the same seeded stream and weights, medium config, both keyframe modes:
                      Sim(3)-aligned ATE-RMSE (evo_ape -vas semantics), keyframe agreement, edge-list equality
@@ -515,6 +516,8 @@ def main():
             del le
         log("operating points: overlap mode (kf_every=-1, skip=5, thresh=0.9)")
         op_points["overlap_mode"] = overlap_mode_leg(model, Cut3rSlam, dev)
+        log("operating points: GS mapper on a synthetic window (rasteriser forward + backward, pose refinement, mapping)")
+        op_points["gs_mapper_synthetic_window"] = synth.gs_mapper_window_leg(H, W, dev)
     if single and not args.no_trajectory_parity:
         log("trajectory parity leg (medium config, GPU vs CPU oracle)")
         traj = trajectory_parity_leg(dev)

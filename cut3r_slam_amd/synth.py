@@ -70,3 +70,64 @@ def slideshow_stream(n: int, H: int, W: int, hold: int = 10, seed: int = 0, devi
             tex = torch.randint(8, 240, (3, H, W), generator=g, dtype=torch.int16).to(device)
         out[t] = (tex + (t % hold)).to(torch.uint8)
     return out
+
+
+def gs_wall_window(H: int = 384, W: int = 512, focal: float = 440.0, n_views: int = 6, device="cuda:0"):
+    """A synthetic keyframe window for the GS mapper: a textured, gently curved wall modelled by one ground-truth Gaussian per pixel,
+    rendered through the HIP rasteriser from `n_views` poses.  Returns (packet for GSMapper.run, images u8 [n,3,H,W], config dict)."""
+    from . import gs_mapper as GM
+    from .lietorch import SE3
+    cfg = {"Training": {"lambda_depth": 10.0, "lambda_normal": 0.1, "lambda_iso": 10.0, "gaussian_th": 0.05, "gaussian_extent": 1.0, "size_threshold": 20,
+                        "window_size": 10},
+           "opt_params": {"pose_lr": 0.0001, "position_lr_init": 0.0005, "feature_lr": 0.005, "opacity_lr": 0.05, "scaling_lr": 0.001,
+                          "rotation_lr": 0.001, "percent_dense": 0.01, "densify_grad_threshold": 0.0005}}
+    ys, xs = torch.meshgrid(torch.linspace(-1.7, 1.7, H), torch.linspace(-2.3, 2.3, W), indexing="ij")
+    z = 3.0 + 0.2 * torch.sin(xs) * torch.cos(1.3 * ys)
+    col = torch.stack([0.5 + 0.4 * torch.sin(3 * xs), 0.5 + 0.4 * torch.cos(2.5 * ys), 0.5 + 0.4 * torch.sin(2 * xs + 3 * ys)], -1)
+    truth = GM.GaussianMap(cfg["opt_params"], device)
+    truth.extend_from_pcd_seq(0, rgb=col.reshape(-1, 3), pointmap=torch.stack([xs, ys, z], -1).reshape(-1, 3))
+    with torch.no_grad():
+        truth.p["opacity"].fill_(2.2)
+        truth.p["scaling"] += 0.26
+    poses = [SE3.exp(torch.tensor([[0.05 * k, 0.01 * (k % 2), 0.0, 0.0, -0.01 * k, 0.0]], device=device)).data[0].cpu() for k in range(n_views)]
+    imgs, depths, pms = [], [], []
+    yy, xx = torch.meshgrid(torch.arange(H, device=device).float(), torch.arange(W, device=device).float(), indexing="ij")
+    for p in poses:
+        T = GM.pose_vec_to_matrix(p[None].to(device))[0]
+        cam = GM.Camera(0, torch.zeros(3, H, W), torch.ones(H, W), torch.inverse(T), focal, focal, W / 2, H / 2, device=device)
+        with torch.no_grad():
+            pkg = GM.render(cam, truth, torch.zeros(3, device=device))
+        d = pkg["depth"][0]
+        imgs.append((pkg["render"].clamp(0, 1) * 255).round().to(torch.uint8))
+        depths.append(d)
+        pc = torch.stack([(xx - W / 2) / focal * d, (yy - H / 2) / focal * d, d], -1)
+        pms.append((pc @ T[:3, :3].T + T[:3, 3])[::2, ::2])
+    packet = {"viz_idx": list(range(n_views)), "submap_idx": 0, "tstamp": torch.arange(n_views).float(), "poses": torch.stack(poses),
+              "images": torch.stack(imgs), "pointmaps": torch.stack(pms), "confs": torch.ones(n_views, H // 2, W // 2, device=device),
+              "depths": torch.stack(depths), "intrinsics": torch.tensor([focal, focal, W / 2, H / 2])}
+    return packet, torch.stack(imgs), cfg
+
+
+def gs_mapper_window_leg(H: int = 384, W: int = 512, device="cuda:0"):
+    """one synthetic 6-keyframe window through GSMapper.run with the reference's iteration counts (gs_backend_per_frame.py:776-862: 100
+    initial, per new keyframe 50 pose-refine + 20 window + 50 single-view, 10 per view global) -> timing / quality figures"""
+    import time
+    from . import gs_mapper as GM
+    packet, imgs, cfg = gs_wall_window(H, W, device=device)
+    n = len(packet["viz_idx"])
+    mapper = GM.GSMapper(cfg, float(packet["intrinsics"][0]), float(packet["intrinsics"][1]), W / 2, H / 2, downsample_ratio=2, device=device)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    with torch.enable_grad():
+        mapper.run(packet, iterations=100)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    with torch.no_grad():
+        ps = []
+        for k in range(n):
+            r = GM.render(mapper.viewpoints[k], mapper.gaussians, torch.zeros(3, device=device))["render"]
+            ps.append(float(-10 * torch.log10(((r - imgs[k].float() / 255) ** 2).mean())))
+    renders = 100 + (n - 1) * (50 + 50) + sum(20 * min(k + 1, 10) for k in range(1, n)) + 10 * n
+    return {"config": f"synthetic wall, {n} keyframes at {W}x{H}, one Gaussian per stride-2 pixel of the first keyframe, the reference's iteration counts",
+            "seconds": round(dt, 3), "ms_per_keyframe": round(1e3 * dt / n, 1), "render_iterations": renders,
+            "ms_per_render_iteration": round(1e3 * dt / renders, 3), "gaussians": len(mapper.gaussians), "psnr_db": round(sum(ps) / n, 2)}

@@ -79,51 +79,10 @@ for P in args.points:
           f"forward {tf[len(tf) // 2]:7.2f} ms, backward {tb[len(tb) // 2]:7.2f} ms (median of {args.iters}, incl. the host-side read of the instance count)")
 
 # ---- the mapper on a synthetic wall at the tracking resolution (384x512): one 6-keyframe window through GSMapper.run with the
-#      reference's iteration counts (100 initial, per new keyframe 50 pose-refine + 20 window + 50 single-view, 10 per view global)
+#      reference's iteration counts (the same leg bench.py reports as operating_points.gs_mapper_synthetic_window)
 if os.environ.get("CUT3R_BENCH_GS_MAPPER", "1") == "1":
-    import time
-    from cut3r_slam_amd import gs_mapper as GM
-    from cut3r_slam_amd.lietorch import SE3
-    Hm, Wm, F = 384, 512, 440.0
-    cfg = {"Training": {"lambda_depth": 10.0, "lambda_normal": 0.1, "lambda_iso": 10.0, "gaussian_th": 0.05, "gaussian_extent": 1.0, "size_threshold": 20,
-                        "window_size": 10},
-           "opt_params": {"pose_lr": 0.0001, "position_lr_init": 0.0005, "feature_lr": 0.005, "opacity_lr": 0.05, "scaling_lr": 0.001,
-                          "rotation_lr": 0.001, "percent_dense": 0.01, "densify_grad_threshold": 0.0005}}
-    ys, xs = torch.meshgrid(torch.linspace(-1.7, 1.7, 384), torch.linspace(-2.3, 2.3, 512), indexing="ij")
-    z = 3.0 + 0.2 * torch.sin(xs) * torch.cos(1.3 * ys)
-    col = torch.stack([0.5 + 0.4 * torch.sin(3 * xs), 0.5 + 0.4 * torch.cos(2.5 * ys), 0.5 + 0.4 * torch.sin(2 * xs + 3 * ys)], -1)
-    truth = GM.GaussianMap(cfg["opt_params"], DEV)
-    truth.extend_from_pcd_seq(0, rgb=col.reshape(-1, 3), pointmap=torch.stack([xs, ys, z], -1).reshape(-1, 3))
-    with torch.no_grad():
-        truth.p["opacity"].fill_(2.2)
-        truth.p["scaling"] += 0.26
-    poses = [SE3.exp(torch.tensor([[0.05 * k, 0.01 * (k % 2), 0.0, 0.0, -0.01 * k, 0.0]], device=DEV)).data[0].cpu() for k in range(6)]
-    imgs, depths, pms = [], [], []
-    yy, xx = torch.meshgrid(torch.arange(Hm, device=DEV).float(), torch.arange(Wm, device=DEV).float(), indexing="ij")
-    for p in poses:
-        T = GM.pose_vec_to_matrix(p[None].to(DEV))[0]
-        cam = GM.Camera(0, torch.zeros(3, Hm, Wm), torch.ones(Hm, Wm), torch.inverse(T), F, F, Wm / 2, Hm / 2, device=DEV)
-        with torch.no_grad():
-            pkg = GM.render(cam, truth, torch.zeros(3, device=DEV))
-        d = pkg["depth"][0]
-        imgs.append((pkg["render"].clamp(0, 1) * 255).round().to(torch.uint8))
-        depths.append(d)
-        pc = torch.stack([(xx - Wm / 2) / F * d, (yy - Hm / 2) / F * d, d], -1)
-        pms.append((pc @ T[:3, :3].T + T[:3, 3])[::2, ::2])
-    packet = {"viz_idx": list(range(6)), "submap_idx": 0, "tstamp": torch.arange(6).float(), "poses": torch.stack(poses), "images": torch.stack(imgs),
-              "pointmaps": torch.stack(pms), "confs": torch.ones(6, Hm // 2, Wm // 2, device=DEV), "depths": torch.stack(depths),
-              "intrinsics": torch.tensor([F, F, Wm / 2, Hm / 2])}
-    mapper = GM.GSMapper(cfg, F, F, Wm / 2, Hm / 2, downsample_ratio=2, device=DEV)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    mapper.run(packet, iterations=100)
-    torch.cuda.synchronize()
-    dt = time.time() - t0
-    with torch.no_grad():
-        ps = []
-        for k in range(6):
-            r = GM.render(mapper.viewpoints[k], mapper.gaussians, torch.zeros(3, device=DEV))["render"]
-            ps.append(float(-10 * torch.log10(((r - imgs[k].float() / 255) ** 2).mean())))
-    renders = 100 + 5 * (50 + 50) + sum(20 * min(k + 1, 10) for k in range(1, 6)) + 10 * 6
-    print(f"mapper, one 6-keyframe window at {Wm}x{Hm}: {dt:.2f} s = {1e3 * dt / 6:.0f} ms per keyframe, about {renders} forward+backward renders "
-          f"({1e3 * dt / renders:.2f} ms each incl. losses and optimiser), {len(mapper.gaussians)} Gaussians, PSNR {sum(ps) / 6:.1f} dB")
+    from cut3r_slam_amd import synth
+    r = synth.gs_mapper_window_leg(384, 512, DEV)
+    print(f"mapper, one 6-keyframe window at 512x384: {r['seconds']:.2f} s = {r['ms_per_keyframe']:.0f} ms per keyframe, about {r['render_iterations']} "
+          f"forward+backward renders ({r['ms_per_render_iteration']:.2f} ms each incl. losses and optimiser), {r['gaussians']} Gaussians, "
+          f"PSNR {r['psnr_db']:.1f} dB")
