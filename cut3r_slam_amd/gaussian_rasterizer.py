@@ -20,6 +20,7 @@ from . import _lib
 from ._lib import check
 
 GS_REC = 32
+MAX_INSTANCES = 1 << 27          # sort buffers are sized from the data: refuse sizes that only a diverged map produces (3.2 GB at the limit)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -91,6 +92,9 @@ def _forward(means3D, sh, colors_precomp, opacities, scales, rotations, st):
                                   campos, W, H, float(st.tanfovx), float(st.tanfovy), float(st.kernel_size), float(st.scale_modifier), _p(buf.geom),
                                   _p(radii), _p(tiles), _p(offsets), _p(ws), ws.numel(), _s()), "gs_preprocess")
     n_inst = int(offsets[-1].item()) & 0xffffffff                     # the one host read of the pass (rasterizer_impl.cu:346-354)
+    if n_inst > MAX_INSTANCES:
+        raise RuntimeError(f"GaussianRasterizer: {n_inst} Gaussian/tile instances (limit {MAX_INSTANCES}, 24 bytes each): degenerate scales or a "
+                           "diverged map; raise gaussian_rasterizer.MAX_INSTANCES if this is intended")
     gx, gy = (W + 15) // 16, (H + 15) // 16
     buf.ranges = torch.empty(gy * gx, 2, dtype=torch.int32, device=dev)
     buf.n_inst = n_inst
