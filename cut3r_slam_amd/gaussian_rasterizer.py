@@ -20,6 +20,7 @@ from . import _lib
 from ._lib import check
 
 GS_REC = 32
+_ZERO_IMAGES = {}
 MAX_INSTANCES = 1 << 27          # sort buffers are sized from the data: refuse sizes that only a diverged map produces (3.2 GB at the limit)
 
 
@@ -72,12 +73,13 @@ def _forward(means3D, sh, colors_precomp, opacities, scales, rotations, st):
     sh = sh.detach().contiguous().float() if use_sh else None
     colors = None if use_sh else colors_precomp.detach().contiguous().float()
     K = sh.shape[1] if use_sh else 0
-    out = {k: torch.zeros(c, H, W, **f32) for k, c in (("color", 3), ("coord", 3), ("mcoord", 3), ("depth", 1), ("mdepth", 1), ("alpha", 1),
-                                                      ("normal", 3))}
-    radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    # the kernels write every pixel / every Gaussian: no fills (an empty scene is the one case that needs zeros)
+    alloc = torch.zeros if P == 0 else torch.empty
+    out = {k: alloc(c, H, W, **f32) for k, c in (("color", 3), ("coord", 3), ("mcoord", 3), ("depth", 1), ("mdepth", 1), ("alpha", 1), ("normal", 3))}
+    radii = alloc(P, dtype=torch.int32, device=dev)
     buf = _Buffers()
-    buf.n_contrib = torch.zeros(2, H, W, dtype=torch.int32, device=dev)
-    buf.aux = torch.zeros(2, H, W, **f32)
+    buf.n_contrib = alloc(2, H, W, dtype=torch.int32, device=dev)
+    buf.aux = alloc(2, H, W, **f32)
     bg = _host16(st.bg, 3)
     if P == 0:
         out["color"] += torch.as_tensor(list(bg), **f32)[:, None, None]
@@ -120,14 +122,18 @@ def _backward(buf, st, means3D, sh, colors_precomp, opacities, scales, rotations
     H, W = int(st.image_height), int(st.image_width)
     f32 = dict(dtype=torch.float32, device=dev)
     use_sh = colors_precomp is None or colors_precomp.numel() == 0
-    d = {"means": torch.zeros(P, 3, **f32), "scales": torch.zeros(P, 3, **f32), "rots": torch.zeros(P, 4, **f32), "opac": torch.zeros(P, 1, **f32),
-         "means2D": torch.zeros(P, 3, **f32)}
+    flat = torch.zeros(P * 14, **f32)                                  # one fill: culled Gaussians are not written by the kernel
+    d = {"means": flat[0:3 * P].view(P, 3), "scales": flat[3 * P:6 * P].view(P, 3), "rots": flat[6 * P:10 * P].view(P, 4),
+         "opac": flat[10 * P:11 * P].view(P, 1), "means2D": flat[11 * P:14 * P].view(P, 3)}
     d["shs"] = torch.zeros(sh.shape, **f32) if use_sh else None
     d["colors"] = None if use_sh else torch.zeros(P, 3, **f32)
     if P == 0 or buf.geom is None:
         return d
     chans = (3, 3, 3, 1, 1, 1, 3)
-    g = [torch.zeros(c, H, W, **f32) if t is None else t.detach().contiguous().float() for t, c in zip(grads, chans)]
+    zero = _ZERO_IMAGES.get((H, W, dev))
+    if zero is None:
+        zero = _ZERO_IMAGES[(H, W, dev)] = torch.zeros(3, H, W, **f32)  # read-only stand-in for the images the loss did not use
+    g = [zero[:c] if t is None else t.detach().contiguous().float() for t, c in zip(grads, chans)]
     means3D, scales, rotations, opacities = (t.detach().contiguous().float() for t in (means3D, scales, rotations, opacities))
     sh_c = sh.detach().contiguous().float() if use_sh else None
     K = sh_c.shape[1] if use_sh else 0

@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from .gaussian_rasterizer import GaussianRasterizationSettings, GaussianRasterizer, distCUDA2, fused_ssim
-from .lietorch import SE3
+from .lietorch import SE3, SO3
 
 SH_C0 = 0.28209479177387814
 
@@ -288,8 +288,10 @@ def render(viewpoint, pc, bg_color, scaling_modifier=1.0):
     rotations) and rasterised with an identity view matrix; returns the reference's dict"""
     pose = get_pose_se3(viewpoint)
     xyz = pose.act(pc.get_xyz)                                            # (a [P,3] x [3,3] product through rocBLAS cost 0.14 ms)
-    q = pose.data[0, 3:]                                                  # (x, y, z, w) of the camera rotation
-    rot = _quat_mult(F.normalize(torch.cat([q[3:], q[:3]]), dim=-1)[None], pc.get_rotation)
+    # camera rotation x Gaussian rotation on the SO3 kernel (its data order is (x, y, z, w); the Gaussians keep (r, x, y, z))
+    gq = pc.get_rotation
+    rq = (SO3(pose.data[:, 3:]) * SO3(torch.cat([gq[:, 1:], gq[:, :1]], -1))).data
+    rot = torch.cat([rq[:, 3:], rq[:, :3]], -1)
     screenspace_points = torch.zeros_like(xyz, requires_grad=True)
     bg_host = getattr(pc, "_bg_host", None)
     if bg_host is None or bg_host[0] is not bg_color:
