@@ -122,7 +122,8 @@ def _grad_compare(got, ref, name, tol, max_bad):
 
 @pytest.mark.parametrize("H,W,P,deg,ks,cam,precomp", [(40, 56, 60, 3, 0.0, (0.0, 0.0, (0.0, 0.0, 0.0)), False),
                                                       (48, 64, 200, 1, 0.1, (0.15, -0.2, (0.1, -0.05, 0.3)), False),
-                                                      (33, 47, 120, 0, 0.0, (-0.1, 0.1, (0.0, 0.1, 0.0)), True)])
+                                                      (33, 47, 120, 0, 0.0, (-0.1, 0.1, (0.0, 0.1, 0.0)), True),
+                                                      (33, 47, 900, 0, 0.0, (0.0, 0.0, (0.0, 0.0, 0.3)), True)])      # > 256 Gaussians per tile: several staging rounds
 def test_backward_matches_autograd_of_the_restatement(H, W, P, deg, ks, cam, precomp):
     """every output image gets a random cotangent; the gradients of means, scales, rotations, opacities and SH / colours are compared
     with torch autograd through the fp64 restatement (hard per-pixel decisions flip for a few pixels in fp32: bounded fraction)"""
