@@ -13,7 +13,7 @@ rasteriser.  Mirrors, with the same names, argument meaning
 
 The reference's backend cannot run here (CUDA rasteriser, open3d, munch): PARITY UNPINNED, covered by functional tests on a
 synthetic scene (tests/test_gs_mapper_gpu.py).  The rasteriser and the 3-NN search are the HIP kernels of csrc/gs.hip; the loss
-terms and the Adam updates are plain torch tensor arithmetic on the GPU.  Not built: GUI, exposure compensation, opacity reset
+terms and the Adam updates are plain torch tensor arithmetic on the GPU.  Not built: GUI, opacity reset
 schedule, ply export, the TSDF / evaluation utilities.
 `gaussain_update` (the map correction after a loop closure, :701-774) composes rotations consistently by default; see its docstring."""
 from __future__ import annotations
@@ -211,6 +211,9 @@ class Camera:
         self.w2c_data = SE3_from_matrix(w2c).detach()                   # (t, q_xyzw): the pose the lie kernels compose the deltas with
         self.cam_rot_delta = torch.zeros(3, device=dev, requires_grad=True)
         self.cam_trans_delta = torch.zeros(3, device=dev, requires_grad=True)
+        # per-view affine colour model (camera_utils.py exposure_a / exposure_b; used when Training.compensate_exposure)
+        self.exposure_a = torch.eye(3, device=dev).requires_grad_(True)
+        self.exposure_b = torch.zeros(3, device=dev, requires_grad=True)
         # pinhole projection in the rasteriser's NDC (pixel u = ((ndc + 1) W - 1) / 2, forward.cu ndc2Pix): u = fx X/Z + cx exactly;
         # stored transposed like the reference's cameras (graphics_utils.getProjectionMatrix2 + .transpose(0, 1))
         znear, zfar, W, H = 0.01, 100.0, self.image_width, self.image_height
@@ -358,11 +361,14 @@ class GSMapper:
         self.background = torch.zeros(3, device=self.device)
         self.viewpoints = {}
 
-    def _pose_optimizer(self, views):
+    def _pose_optimizer(self, views, exposure=False):
         lr = self.config["opt_params"]["pose_lr"]
         groups = []
         for v in views:
             groups += [{"params": [v.cam_rot_delta], "lr": lr * 2}, {"params": [v.cam_trans_delta], "lr": lr * 10}]
+            if exposure:                                                  # gs_backend_per_frame.py:467-475
+                elr = self.config["opt_params"].get("exposure_lr", 0.0005)
+                groups += [{"params": [v.exposure_a], "lr": elr}, {"params": [v.exposure_b], "lr": elr}]
         return torch.optim.Adam(groups)
 
     def pose_refine(self, BA_window, iters=50, return_args=True, alpha_th=0.5):
@@ -440,7 +446,8 @@ class GSMapper:
         Gaussians (and optionally the window's poses) step together; clone / split / prune at iters/4 and iters/2 when densifying."""
         views = [self.viewpoints[k] for k in current_window]
         N = len(views)
-        opt = self._pose_optimizer(views) if optimize_pose else None
+        exposure = bool(self.config["Training"].get("compensate_exposure", False))
+        opt = self._pose_optimizer(views, exposure) if optimize_pose else None
         last = None
         for it in range(iters):
             loss = 0.0
@@ -448,6 +455,8 @@ class GSMapper:
             for v in views:
                 pkg = render(v, self.gaussians, self.background)
                 image, depth = pkg["render"], pkg["depth"]
+                if exposure:                                              # :513: colours through the view's affine exposure model
+                    image = (image.permute(1, 2, 0) @ v.exposure_a + v.exposure_b).permute(2, 0, 1).contiguous()
                 gt_image, gt_depth = v.original_image, v.depth[None]
                 rgb = 0.8 * torch.abs(gt_image - image).mean() + 0.2 * (1.0 - ssim(image, gt_image))
                 dmask = ((gt_depth > 0.001) & (depth > 0.001)).detach()

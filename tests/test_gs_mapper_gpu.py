@@ -262,3 +262,24 @@ def test_slam_loop_with_the_mapper_attached():
     assert torch.isfinite(slam.keyframes.pose[:nkf - 1]).all() and torch.isfinite(slam.mapper.trajectory()).all()
     print(f"[gs mapper] slam loop: {nkf} keyframes, {len(calls)} windows handed over, {len(slam.mapper.viewpoints)} mapper views, "
           f"{len(slam.mapper.gaussians)} Gaussians")
+
+
+def test_exposure_compensation_absorbs_a_gain_change():
+    """Training.compensate_exposure (gs_backend_per_frame.py:467-475,513): a keyframe observed 15 % darker than the map is explained by
+    its affine exposure parameters rather than by repainting the Gaussians"""
+    truth = _truth()
+    pose = _pose7(0, 0, 0, 0, 0)
+    img, depth = _observe(truth, pose)
+    cfg = dict(CONFIG, Training=dict(CONFIG["Training"], compensate_exposure=True), opt_params=dict(CONFIG["opt_params"], exposure_lr=0.01))
+    mapper = GM.GSMapper(cfg, FX, FY, CX, CY, downsample_ratio=2, device=DEV)
+    mapper.gaussians = truth
+    w2c = torch.inverse(GM.pose_vec_to_matrix(pose[None].to(DEV))[0])
+    mapper.viewpoints[0] = GM.Camera(0, 0.85 * img, depth, w2c, FX, FY, CX, CY, device=DEV)
+    colours0 = truth.p["f_dc"].detach().clone()
+    mapper.gaussians.lr[:, 3:6] = 0.0                                     # keep the map's colours fixed: only the exposure can explain the change
+    first = mapper.optimization(1, optimize_pose=True, current_window=[0])
+    last = mapper.optimization(60, optimize_pose=True, current_window=[0])
+    gain = float(torch.diagonal(mapper.viewpoints[0].exposure_a).mean())
+    print(f"[gs mapper] exposure: loss {first:.4f} -> {last:.4f}, mean diagonal gain {gain:.3f}")
+    assert last < 0.7 * first and 0.8 < gain < 0.95
+    assert torch.equal(truth.p["f_dc"].detach(), colours0)
