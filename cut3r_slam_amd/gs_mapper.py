@@ -14,7 +14,7 @@ rasteriser.  Mirrors, with the same names, argument meaning
 The reference's backend cannot run here (CUDA rasteriser, open3d, munch): PARITY UNPINNED, covered by functional tests on a
 synthetic scene (tests/test_gs_mapper_gpu.py).  The rasteriser and the 3-NN search are the HIP kernels of csrc/gs.hip; the loss
 terms and the Adam updates are plain torch tensor arithmetic on the GPU.  Not built: GUI, opacity reset
-schedule, ply export, the TSDF / evaluation utilities.
+schedule, ply export, LPIPS and the TSDF / mesh evaluation utilities (PSNR / SSIM of the keyframes and a safetensors checkpoint are).
 `gaussain_update` (the map correction after a loop closure, :701-774) composes rotations consistently by default; see its docstring."""
 from __future__ import annotations
 
@@ -621,6 +621,39 @@ class GSMapper:
         depths = F.interpolate(torch.stack(depths)[None], size=size, mode="bilinear", align_corners=False)[0]
         return {"pointmaps": pms, "depths": depths, "poses": torch.stack(poses)}, list(current_window)
 
+
+    # ---- checkpoint / evaluation (gs_backend_per_frame.py:1088-1096; gaussian/utils/eval_utils.py:110-150 without LPIPS, whose
+    #      pretrained network is not available offline)
+    def save(self, path):
+        """the Gaussian map (parameters, optimiser moments, bookkeeping) as a safetensors file: nothing executable in the file"""
+        from safetensors.torch import save_file
+        g = self.gaussians
+        save_file({"theta": g.theta.detach().contiguous(), "m": g.m.contiguous(), "v": g.v.contiguous(), "step_count": g.step_count.contiguous(),
+                   "kf_id": g.kf_id.contiguous(), "max_radii2D": g.max_radii2D.contiguous(), "grad_accum": g.grad_accum.contiguous(),
+                   "denom": g.denom.contiguous()}, path)
+
+    def load(self, path):
+        from safetensors.torch import load_file
+        t = load_file(path, device=str(self.device))
+        g = self.gaussians
+        g.theta = t["theta"].requires_grad_(True)
+        g.m, g.v, g.step_count, g.kf_id = t["m"], t["v"], t["step_count"], t["kf_id"]
+        g.max_radii2D, g.grad_accum, g.denom = t["max_radii2D"], t["grad_accum"], t["denom"]
+
+    @torch.no_grad()
+    def eval_rendering_kf(self):
+        """eval_utils.py:110-150 over the mapper's own keyframes: PSNR on the pixels with a ground-truth colour (gt > 0) and SSIM per
+        view -> dict(mean_psnr, mean_ssim, per_view)"""
+        rows = []
+        for k in sorted(self.viewpoints):
+            v = self.viewpoints[k]
+            img = torch.clamp(render(v, self.gaussians, self.background)["render"], 0.0, 1.0)
+            gt = v.original_image
+            mask = gt > 0
+            mse = ((img[mask] - gt[mask]) ** 2).mean() if mask.any() else torch.zeros((), device=self.device)
+            rows.append((k, float(20 * torch.log10(1.0 / torch.sqrt(mse.clamp_min(1e-12)))), float(ssim(img, gt))))
+        n = max(1, len(rows))
+        return {"mean_psnr": sum(r[1] for r in rows) / n, "mean_ssim": sum(r[2] for r in rows) / n, "per_view": rows}
 
     @torch.no_grad()
     def trajectory(self):

@@ -134,6 +134,17 @@ def test_mapping_from_keyframes_reaches_the_observations():
     assert ba is not None and ba < 1.2 * last
     traj = mapper.trajectory()
     assert traj.shape == (3, 4, 4) and torch.isfinite(traj).all()
+    # evaluation and checkpoint round trip (gs_backend_per_frame.py:1088-1102)
+    ev = mapper.eval_rendering_kf()
+    assert ev["mean_psnr"] > 22.0 and 0.5 < ev["mean_ssim"] <= 1.0 and len(ev["per_view"]) == 3
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        mapper.save(os.path.join(d, "map.safetensors"))
+        other = GM.GSMapper(CONFIG, FX, FY, CX, CY, downsample_ratio=2, device=DEV)
+        other.load(os.path.join(d, "map.safetensors"))
+    assert torch.equal(other.gaussians.theta.detach(), mapper.gaussians.theta.detach()) and torch.equal(other.gaussians.m, mapper.gaussians.m)
+    other.viewpoints = mapper.viewpoints
+    assert abs(other.eval_rendering_kf()["mean_psnr"] - ev["mean_psnr"]) < 1e-3
 
 
 def test_tracker_hand_over_runs_the_mapper_and_writes_back():
