@@ -63,6 +63,8 @@ def main(argv=None):
     p.add_argument("--small", action="store_true", help="debug: tiny architecture (with --synthetic-weights)")
     p.add_argument("--window-batch", type=int, default=1, help="tracking windows decoded together (1 = reference schedule)")
     p.add_argument("--device", default="cuda:0")
+    p.add_argument("--gs", action="store_true", help="attach the Gaussian-splatting mapper (hislam2/hi2.py:47-48 always does; needs the "
+                   "Mapping / Training / opt_params sections of the config, config/scannet_config.yaml:44-79)")
     args = p.parse_args(argv)
     os.makedirs(args.output, exist_ok=True)
 
@@ -95,6 +97,12 @@ def main(argv=None):
                                                                          args.start, args.length, device=args.device):
         if slam is None:
             slam = Cut3rSlam(model, cfg, (image_ds.shape[2], image_ds.shape[3]), buffer=buffer, device=args.device)
+            if args.gs:
+                from cut3r_slam_amd.gs_mapper import GSMapper
+                if "Training" not in cfg or "opt_params" not in cfg:
+                    raise SystemExit("--gs needs the Training and opt_params sections in --config")
+                k = [float(v) for v in intr_ds[0].reshape(-1)[:4]]
+                slam.mapper = GSMapper(cfg, k[0], k[1], k[2], k[3], downsample_ratio=slam.downsample_ratio, device=args.device)
         slam.run(t, image, intr[0].float(), image_ds, intr_ds[0].float(), second_last_frame=(t + args.start == n_files - 2),
                  last_frame=(t + args.start == n_files - 1))      # demo_s.py:158-159: a --length cut does NOT flush the tail window
         nframes += 1
@@ -102,6 +110,11 @@ def main(argv=None):
         raise SystemExit(f"{args.imagedir}: no frames")
     torch.cuda.synchronize()
     traj = stream.save_trajectory(slam, args.imagedir, args.output, start=args.start)
+    if slam.mapper is not None and slam.mapper.viewpoints:
+        ev = slam.mapper.eval_rendering_kf()                              # demo_s.py:175-190 evaluates the renderings of the keyframes
+        slam.mapper.save(os.path.join(args.output, "gaussians.safetensors"))
+        print(f"GS mapper: {len(slam.mapper.gaussians)} Gaussians, {len(slam.mapper.viewpoints)} keyframes, PSNR {ev['mean_psnr']:.2f} dB, "
+              f"SSIM {ev['mean_ssim']:.4f} -> {args.output}/gaussians.safetensors")
     print(f"{nframes} frames, {len(traj)} keyframes, {len(slam.graph.edges_numpy()[0])} graph edges in {time.time() - t0:.1f}s "
           f"-> {args.output}/traj_kf.txt")
     return 0

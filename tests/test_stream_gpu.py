@@ -108,3 +108,31 @@ def test_undistort_remap_bit_exact_vs_oracle_and_through_mono_stream(tmp_path):
     ref = G.resize_linear_u8(np.ascontiguousarray(und), h1, 512)
     assert np.array_equal(image_ds[0].permute(1, 2, 0).cpu().numpy(), ref)
     np.testing.assert_allclose(intr_ds[0, 2].item(), (K4[2] - 4) * 512 / w0)
+
+
+def test_demo_driver_with_the_gs_mapper(tmp_path):
+    """demo.py --gs: the per-frame loop with the Gaussian mapper attached (hi2.py:47-48,133), a config with the Mapping / Training /
+    opt_params sections of the maintained configs (config/scannet_config.yaml:44-79, few iterations); writes the trajectory and the map"""
+    import demo
+    d = tmp_path / "colors"
+    d.mkdir()
+    _write_sequence(str(d), 24)
+    calib = tmp_path / "calib.txt"
+    calib.write_text("600.0 600.0 320.0 240.0")
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text("""
+Mapping: {itr_num: 2}
+Training: {lambda_depth: 10.0, lambda_normal: 0.1, lambda_iso: 10.0, gaussian_th: 0.1, gaussian_extent: 1.0, size_threshold: 20, window_size: 4,
+           compensate_exposure: true}
+opt_params: {pose_lr: 0.0001, position_lr_init: 0.0005, feature_lr: 0.005, opacity_lr: 0.05, scaling_lr: 0.001, rotation_lr: 0.001, exposure_lr: 0.0005,
+             percent_dense: 0.01, densify_grad_threshold: 0.0005}
+""")
+    out = tmp_path / "out"
+    rc = demo.main(["--imagedir", str(d), "--calib", str(calib), "--config", str(cfg), "--output", str(out), "--kf_every", "2", "--synthetic-weights",
+                    "--small", "--seed", "1", "--gs"])
+    assert rc == 0
+    rows = np.loadtxt(out / "traj_kf.txt")
+    assert rows.ndim == 2 and rows.shape[1] == 8 and rows.shape[0] >= 8 and np.isfinite(rows).all()
+    from safetensors.torch import load_file
+    m = load_file(str(out / "gaussians.safetensors"))
+    assert m["theta"].shape[1] == 14 and m["theta"].shape[0] > 1000 and torch.isfinite(m["theta"]).all()
