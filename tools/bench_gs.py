@@ -62,6 +62,10 @@ for P in args.points:
     (outs[0].sum() + outs[4].sum() + outs[7].sum()).backward()
     torch.cuda.synchronize()
     n_inst = int(rast and outs[1].gt(0).sum())
+    from cut3r_slam_amd.gaussian_rasterizer import _forward as _raw_forward
+    with torch.no_grad():
+        _, _, _buf = _raw_forward(means, shs, None, opac, scales, rots, st)
+    pairs = _buf.n_inst * 256                                         # (pixel, Gaussian) pairs the render kernels walk at most
     tf, tb = [], []
     for _ in range(args.iters):
         a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -76,7 +80,8 @@ for P in args.points:
     tf.sort(), tb.sort()
     cover = float((outs[6] > 0.5).float().mean())
     print(f"P={P:8d} {W}x{H}: visible {n_inst:8d}, alpha>0.5 on {100 * cover:5.1f} % of the image, 3-NN scales {t_knn:8.2f} ms, "
-          f"forward {tf[len(tf) // 2]:7.2f} ms, backward {tb[len(tb) // 2]:7.2f} ms (median of {args.iters}, incl. the host-side read of the instance count)")
+          f"forward {tf[len(tf) // 2]:7.2f} ms, backward {tb[len(tb) // 2]:7.2f} ms (median of {args.iters}, incl. the host-side read of the instance count); "
+          f"{_buf.n_inst} tile instances = {pairs / 1e6:.0f} M pixel-Gaussian pairs per pass")
 
 # ---- the mapper on a synthetic wall at the tracking resolution (384x512): one 6-keyframe window through GSMapper.run with the
 #      reference's iteration counts (the same leg bench.py reports as operating_points.gs_mapper_synthetic_window)
