@@ -113,7 +113,8 @@ SIGNATURES = {
     "cut3r_gs_render_forward": [c_void_p] * 3 + [c_int, c_int, c_float, c_float] + [c_void_p] * 11,
     "cut3r_ssim_forward": [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 5,
     "cut3r_ssim_backward": [c_void_p] * 5 + [c_int, c_int, c_int] + [c_void_p] * 3,
-    "cut3r_knn3_mean_dist2": [c_void_p, c_int, c_void_p, c_void_p],
+    "cut3r_knn3_chunks": [c_int],
+    "cut3r_knn3_mean_dist2": [c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "cut3r_gs_render_backward": [c_void_p] * 3 + [c_int, c_int, c_int, c_float, c_float] + [c_void_p] * 16,
     "cut3r_gs_preprocess_backward": [c_int] + [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 3 + [c_int, c_int] + [c_float] * 4 + [c_void_p] * 10,
 }

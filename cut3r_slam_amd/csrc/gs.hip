@@ -597,18 +597,22 @@ __global__ __launch_bounds__(64) void gs_preprocess_bwd_kernel(int P, const floa
 // published operator is restated.  Exhaustive search instead of upstream's Morton-box pruning: candidates stream through LDS in tiles
 // of 256 points and every lane of the wave reads the same candidate (broadcast), 3 compare-exchanges per pair -- exact, no tree
 // to build, and a keyframe's worth of points (<= ~2e5) is a few milliseconds on this chip.
-__global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ pts, int P, float* __restrict__ out) {
+// Candidates are split into `gridDim.y` chunks so that a keyframe's worth of points (5e4) still fills the chip (196 workgroups of 256
+// queries would leave 60 CUs idle and one wave per SIMD): every (query block, chunk) keeps its own best three, knn3_merge_kernel folds
+// the chunks.
+__global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ pts, int P, int chunk, float* __restrict__ part) {
     __shared__ float sx[256], sy[256], sz[256];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < P;
     const float x = live ? pts[3 * (size_t)i] : 0.f, y = live ? pts[3 * (size_t)i + 1] : 0.f, z = live ? pts[3 * (size_t)i + 2] : 0.f;
     float b0 = 3.402823466e38f, b1 = b0, b2 = b0;
-    for (int base = 0; base < P; base += 256) {
+    const int c0 = blockIdx.y * chunk, c1 = min(P, c0 + chunk);
+    for (int base = c0; base < c1; base += 256) {
         const int j = base + threadIdx.x;
         __syncthreads();
-        if (j < P) { sx[threadIdx.x] = pts[3 * (size_t)j]; sy[threadIdx.x] = pts[3 * (size_t)j + 1]; sz[threadIdx.x] = pts[3 * (size_t)j + 2]; }
+        if (j < c1) { sx[threadIdx.x] = pts[3 * (size_t)j]; sy[threadIdx.x] = pts[3 * (size_t)j + 1]; sz[threadIdx.x] = pts[3 * (size_t)j + 2]; }
         __syncthreads();
-        const int cnt = P - base < 256 ? P - base : 256;
+        const int cnt = c1 - base < 256 ? c1 - base : 256;
         for (int k = 0; k < cnt; k++) {
             const float dx = sx[k] - x, dy = sy[k] - y, dz = sz[k] - z;
             float d = dx * dx + dy * dy + dz * dz;
@@ -618,7 +622,27 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ pts
             b2 = fminf(b2, d);
         }
     }
-    if (live) out[i] = (b0 + b1 + b2) / 3.f;
+    if (live) {
+        float* o = part + ((size_t)blockIdx.y * P + i) * 3;
+        o[0] = b0; o[1] = b1; o[2] = b2;
+    }
+}
+
+__global__ __launch_bounds__(256) void knn3_merge_kernel(const float* __restrict__ part, int P, int chunks, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float b0 = 3.402823466e38f, b1 = b0, b2 = b0;
+    for (int c = 0; c < chunks; c++) {
+        const float* o = part + ((size_t)c * P + i) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float d = o[k];
+            const float t0 = fminf(b0, d); d = fmaxf(b0, d); b0 = t0;
+            const float t1 = fminf(b1, d); d = fmaxf(b1, d); b1 = t1;
+            b2 = fminf(b2, d);
+        }
+    }
+    out[i] = (b0 + b1 + b2) / 3.f;
 }
 
 // ------------------------------------------------------------------------------------------------ SSIM (the mapper's colour loss)
@@ -826,9 +850,23 @@ extern "C" int cut3r_gs_preprocess_backward(int P, const float* means, const flo
     return cut3r_check_launch();
 }
 
-extern "C" int cut3r_knn3_mean_dist2(const float* points, int P, float* out, void* stream) {
-    if (!points || !out || P < 4) return CUT3R_ERR_ARG;                      // three OTHER points must exist
-    hipLaunchKernelGGL(knn3_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, points, P, out);
+extern "C" int cut3r_knn3_chunks(int P) {
+    if (P < 4) return 0;
+    const long long blocks = (P + 255) / 256;                                // aim at >= 2048 workgroups, chunks of >= 2048 candidates
+    long long c = (2048 + blocks - 1) / blocks;
+    const long long cmax = (P + 2047) / 2048;
+    if (c > cmax) c = cmax;
+    if (c < 1) c = 1;
+    return (int)c;
+}
+
+extern "C" int cut3r_knn3_mean_dist2(const float* points, int P, float* out, float* workspace, void* stream) {
+    if (!points || !out || !workspace || P < 4) return CUT3R_ERR_ARG;        // three OTHER points must exist; workspace: chunks*P*3 floats
+    const int chunks = cut3r_knn3_chunks(P);
+    const int chunk = ((P + chunks - 1) / chunks + 255) / 256 * 256;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(knn3_kernel, dim3((P + 255) / 256, chunks), dim3(256), 0, s, points, P, chunk, workspace);
+    hipLaunchKernelGGL(knn3_merge_kernel, dim3((P + 255) / 256), dim3(256), 0, s, workspace, P, chunks, out);
     return cut3r_check_launch();
 }
 

@@ -211,8 +211,11 @@ def distCUDA2(points):
     pts = points.detach().contiguous().float()
     if pts.dim() != 2 or pts.shape[1] != 3:
         raise ValueError("distCUDA2: points must be [P,3]")
-    out = torch.empty(pts.shape[0], dtype=torch.float32, device=pts.device)
-    check(_lib.load().cut3r_knn3_mean_dist2(_p(pts), pts.shape[0], _p(out), _s()), "knn3_mean_dist2")
+    lib = _lib.load()
+    P = pts.shape[0]
+    out = torch.empty(P, dtype=torch.float32, device=pts.device)
+    ws = torch.empty(max(1, lib.cut3r_knn3_chunks(P)) * P * 3, dtype=torch.float32, device=pts.device)
+    check(lib.cut3r_knn3_mean_dist2(_p(pts), P, _p(out), _p(ws), _s()), "knn3_mean_dist2")
     return out
 
 

@@ -356,8 +356,10 @@ int cut3r_gs_preprocess_backward(int P, const float* means, const float* scales,
                                  const float* geom, const float* dgeom, float* d_means, float* d_scales, float* d_rots, float* d_opacities,
                                  float* d_shs, float* d_colors, float* d_means2D, void* stream);
 /* simple_knn._C.distCUDA2 (call sites hislam2/gaussian/scene/gaussian_model.py:191,313; the extension is not vendored in the
- * reference tree): points [P,3] -> out [P], the mean squared distance to the 3 nearest other points.  P >= 4. */
-int cut3r_knn3_mean_dist2(const float* points, int P, float* out, void* stream);
+ * reference tree): points [P,3] -> out [P], the mean squared distance to the 3 nearest other points.  P >= 4.
+ * workspace: cut3r_knn3_chunks(P) * P * 3 floats (the candidates are searched in that many chunks, merged by a second kernel). */
+int cut3r_knn3_chunks(int P);
+int cut3r_knn3_mean_dist2(const float* points, int P, float* out, float* workspace, void* stream);
 /* SSIM of the mapper's colour loss (hislam2/gaussian/utils/loss_utils.py:129-170: 11x11 Gaussian window, sigma 1.5, zero padding,
  * per channel).  forward: a, b [C,H,W] -> ssim_map [C,H,W] and the three partials the backward pass filters (d S / d mu1,
  * d S / d E[a^2], d S / d E[ab]).  backward: grad_a = grad_scale[0] * d(sum ssim_map)/d a  (grad_scale: ONE device float, e.g. the
