@@ -491,9 +491,9 @@ class GSMapper:
                 opt.step()
                 for v in views:
                     update_pose(v)
-            last = float(loss.detach())
+            last = loss.detach()                                          # (read back once, after the loop)
         self.gaussians.zero_grad()
-        return last
+        return float(last) if last is not None else None
 
     def global_BA(self, iteration_total, window=8, densify=True):
         """gs_backend_per_frame.py:946-1058 in outline: every keyframe takes part; random windows of keyframes are optimised jointly
