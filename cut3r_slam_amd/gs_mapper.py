@@ -320,10 +320,12 @@ def project2world(c2w, depths, fx, fy, cx, cy):
 
 def depth_to_normal(viewpoint, depth):
     """camera-frame normals from a depth map [1,H,W] (cross product of the back-projected neighbours; borders zero) -> [3,H,W]"""
-    d = depth[0]
-    H, W = d.shape
-    y, x = torch.meshgrid(torch.arange(H, device=d.device).float(), torch.arange(W, device=d.device).float(), indexing="ij")
-    pts = torch.stack([(x - viewpoint.cx) / viewpoint.fx * d, (y - viewpoint.cy) / viewpoint.fy * d, d], 0)
+    rays = getattr(viewpoint, "_rays", None)
+    if rays is None or rays.shape[-2:] != depth.shape[-2:]:               # ((x - cx) / fx, (y - cy) / fy, 1) per pixel: fixed per camera
+        H, W = depth.shape[-2:]
+        y, x = torch.meshgrid(torch.arange(H, device=depth.device).float(), torch.arange(W, device=depth.device).float(), indexing="ij")
+        rays = viewpoint._rays = torch.stack([(x - viewpoint.cx) / viewpoint.fx, (y - viewpoint.cy) / viewpoint.fy, torch.ones_like(x)], 0)
+    pts = rays * depth
     dx = pts[:, 1:-1, 2:] - pts[:, 1:-1, :-2]
     dy = pts[:, 2:, 1:-1] - pts[:, :-2, 1:-1]
     n = F.normalize(torch.cross(dx, dy, dim=0), dim=0)
