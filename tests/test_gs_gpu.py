@@ -51,7 +51,7 @@ def _settings(st):
 
 
 def _compare(got, ref, name, tol, max_bad):
-    g, r = got.double().cpu().numpy(), ref.detach().numpy()
+    g, r = got.detach().double().cpu().numpy(), ref.detach().numpy()
     err = np.abs(g - r)
     bad = (err > tol * (1.0 + np.abs(r))).mean()
     print(f"[gs] {name}: median |err| {np.median(err):.2e}, 99th pct {np.percentile(err, 99):.2e}, beyond tolerance {100 * bad:.3f} %")
@@ -201,3 +201,26 @@ def test_fused_ssim_matches_convolutions_forward_and_backward(C, H, W):
     (3.0 * got).backward()
     assert abs(float(got) - float(ref)) < 2e-6
     np.testing.assert_allclose(ag.grad.cpu().numpy() / 3.0, a64.grad.numpy(), atol=2e-6 * float(a64.grad.abs().max()) + 1e-10)
+
+
+def test_scale_modifier_and_opacity_cap_paths():
+    """scale_modifier (forward.cu:273-276) and the 0.99 alpha cap (forward.cu:545): a scene of large, nearly opaque Gaussians"""
+    H, W, P = 40, 56, 70
+    means, scales, q, op, shs = _scene(P, 77, smin=0.05, smax=0.3)
+    op = torch.full_like(op, 0.999)
+    st = GO.camera_settings(H, W, 1.0, 1.0 * H / W, _w2c(0.0, 0.0, (0.0, 0.0, 0.0)), bg=(0.0, 0.0, 0.0), sh_degree=0)
+    st["scale_modifier"] = 1.7
+    col = torch.rand(P, 3, dtype=torch.float64)
+    lm, lo = means.clone().requires_grad_(True), op.clone().requires_grad_(True)
+    ref = GO.rasterize(lm, lo, scales, q, st, colors_precomp=col)
+    (ref["color"].sum() + ref["depth"].sum()).backward()
+    f = lambda t: t.float().to(DEV)
+    hm, ho = f(means).requires_grad_(True), f(op).requires_grad_(True)
+    outs = GaussianRasterizer(_settings(st))(means3D=hm, means2D=torch.zeros(P, 3, device=DEV), opacities=ho, colors_precomp=f(col), scales=f(scales),
+                                             rotations=f(q))
+    (outs[0].sum() + outs[4].sum()).backward()
+    assert float((ref["alpha"] > 0.98).double().mean()) > 0.3            # the cap is active on a good part of the image
+    _compare(outs[0], ref["color"], "color (scale_modifier 1.7)", 1e-5, 0.004)
+    _compare(outs[4], ref["depth"], "depth (scale_modifier 1.7)", 2e-5, 0.004)
+    _grad_compare(hm.grad, lm.grad, "means3D (capped alphas)", 5e-4, 0.02)
+    _grad_compare(ho.grad, lo.grad, "opacities (capped alphas)", 5e-4, 0.02)
