@@ -109,7 +109,7 @@ SIGNATURES = {
     "cut3r_gs_preprocess": [c_int] + [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_int] + [c_float] * 4 + [c_void_p] * 5
                            + [c_ll, c_void_p],
     "cut3r_gs_workspace_bytes": [c_int, c_ll],
-    "cut3r_gs_bin": [c_int, c_void_p, c_void_p, c_ll, c_int, c_int] + [c_void_p] * 6 + [c_ll, c_void_p],
+    "cut3r_gs_bin": [c_int, c_void_p, c_void_p, c_ll, c_int, c_int] + [c_void_p] * 6 + [c_ll, c_void_p, c_void_p],
     "cut3r_gs_render_forward": [c_void_p] * 3 + [c_int, c_int, c_float, c_float] + [c_void_p] * 11,
     "cut3r_ssim_forward": [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 5,
     "cut3r_ssim_backward": [c_void_p] * 5 + [c_int, c_int, c_int] + [c_void_p] * 3,

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(int P, const float* 
 // rasterizer_impl.cu:70-112: one (tile << 32 | depth bits, id) pair per covered tile
 __global__ __launch_bounds__(256) void gs_duplicate_kernel(int P, const float* __restrict__ geom, const unsigned* __restrict__ offsets, int gx,
                                                            unsigned long long n_inst, unsigned long long* __restrict__ keys,
-                                                           unsigned* __restrict__ vals) {
+                                                           unsigned* __restrict__ vals, int* __restrict__ overflow) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const float* rec = geom + (size_t)i * GS_REC;
@@ -257,7 +257,10 @@ __global__ __launch_bounds__(256) void gs_duplicate_kernel(int P, const float* _
     const unsigned long long dbits = __float_as_uint(rec[G_DEPTH]);
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
-            if (off >= n_inst) return;                                         // (cannot happen when offsets is the scan of `tiles`)
+            if (off >= n_inst) {                                               // only in capacity mode: the buffers were sized by a guess
+                if (overflow) *overflow = 1;
+                return;
+            }
             keys[off] = ((unsigned long long)(y * gx + x) << 32) | dbits;
             vals[off] = (unsigned)i;
             off++;
@@ -270,16 +273,23 @@ __global__ __launch_bounds__(256) void gs_ranges_kernel(unsigned long long n, co
     const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
     if (i >= n) return;
     const unsigned t = (unsigned)(keys[i] >> 32);
-    if (t >= (unsigned)n_tiles) return;
-    if (i == 0) ranges[2 * t] = 0;
-    else {
+    const bool ok = t < (unsigned)n_tiles;                                     // (padding keys of the capacity mode carry tile id n_tiles)
+    if (i == 0) {
+        if (ok) ranges[2 * t] = 0;
+    } else {
         const unsigned tp = (unsigned)(keys[i - 1] >> 32);
         if (tp != t) {
             if (tp < (unsigned)n_tiles) ranges[2 * tp + 1] = (unsigned)i;
-            ranges[2 * t] = (unsigned)i;
+            if (ok) ranges[2 * t] = (unsigned)i;
         }
     }
-    if (i == n - 1) ranges[2 * t + 1] = (unsigned)n;
+    if (i == n - 1 && ok) ranges[2 * t + 1] = (unsigned)n;
+}
+
+__global__ __launch_bounds__(256) void gs_pad_keys_kernel(unsigned long long n, unsigned long long pad, unsigned long long* __restrict__ keys,
+                                                          unsigned* __restrict__ vals) {
+    const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+    if (i < n) { keys[i] = pad; vals[i] = 0; }
 }
 
 // forward.cu:429-692: one 16x16 tile per workgroup, one pixel per thread, front-to-back
@@ -760,10 +770,10 @@ extern "C" int cut3r_gs_preprocess(int P, const float* means, const float* scale
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gs_preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means, scales, rots, opacities, shs, colors_precomp, cam, geom,
                        radii, tiles_touched);
-    size_t need = 0;
-    if (hipcub::DeviceScan::InclusiveSum(nullptr, need, tiles_touched, offsets, P, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
-    if (!scan_ws || (size_t)scan_ws_bytes < need) return CUT3R_ERR_ARG;
-    if (hipcub::DeviceScan::InclusiveSum(scan_ws, need, tiles_touched, offsets, P, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    // (no size query here: the caller sized scan_ws with cut3r_gs_workspace_bytes; the library call refuses a buffer that is too small)
+    if (!scan_ws || scan_ws_bytes <= 0) return CUT3R_ERR_ARG;
+    size_t need = (size_t)scan_ws_bytes;
+    if (hipcub::DeviceScan::InclusiveSum(scan_ws, need, tiles_touched, offsets, P, s) != hipSuccess) return CUT3R_ERR_ARG;
     return cut3r_check_launch();
 }
 
@@ -778,23 +788,24 @@ extern "C" long long cut3r_gs_workspace_bytes(int P, long long n_instances) {
 
 extern "C" int cut3r_gs_bin(int P, const float* geom, const unsigned* offsets, long long n_instances, int W, int H, unsigned long long* keys_tmp,
                             unsigned* vals_tmp, unsigned long long* keys_sorted, unsigned* point_list, unsigned* ranges, void* sort_ws,
-                            long long sort_ws_bytes, void* stream) {
+                            long long sort_ws_bytes, int* overflow, void* stream) {
     if (P <= 0 || !geom || !offsets || W <= 0 || H <= 0 || !ranges || n_instances < 0 || n_instances > 0x7fffffffLL) return CUT3R_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int gx = (W + GS_TILE - 1) / GS_TILE, gy = (H + GS_TILE - 1) / GS_TILE;
     if (hipMemsetAsync(ranges, 0, sizeof(unsigned) * 2 * (size_t)gx * gy, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
     if (n_instances == 0) return CUT3R_OK;
     if (!keys_tmp || !vals_tmp || !keys_sorted || !point_list || !sort_ws) return CUT3R_ERR_ARG;
+    if (overflow)      // capacity mode: n_instances is a guess made without reading the count back; unused entries sort behind every tile
+        hipLaunchKernelGGL(gs_pad_keys_kernel, dim3((unsigned)((n_instances + 255) / 256)), dim3(256), 0, s, (unsigned long long)n_instances,
+                           (unsigned long long)(gx * gy) << 32, keys_tmp, vals_tmp);
     hipLaunchKernelGGL(gs_duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, geom, offsets, gx, (unsigned long long)n_instances, keys_tmp,
-                       vals_tmp);
+                       vals_tmp, overflow);
     int bits = 32;                                                             // tile id bits above the 32 depth bits
     for (int t = gx * gy; t > 0; t >>= 1) bits++;
-    size_t need = 0;
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys_tmp, keys_sorted, vals_tmp, point_list, (int)n_instances, 0, bits, s) != hipSuccess)
-        return CUT3R_ERR_LAUNCH;
-    if ((size_t)sort_ws_bytes < need) return CUT3R_ERR_ARG;
+    if (sort_ws_bytes <= 0) return CUT3R_ERR_ARG;
+    size_t need = (size_t)sort_ws_bytes;
     if (hipcub::DeviceRadixSort::SortPairs(sort_ws, need, keys_tmp, keys_sorted, vals_tmp, point_list, (int)n_instances, 0, bits, s) != hipSuccess)
-        return CUT3R_ERR_LAUNCH;
+        return CUT3R_ERR_ARG;
     hipLaunchKernelGGL(gs_ranges_kernel, dim3((unsigned)((n_instances + 255) / 256)), dim3(256), 0, s, (unsigned long long)n_instances, keys_sorted,
                        gx * gy, ranges);
     return cut3r_check_launch();

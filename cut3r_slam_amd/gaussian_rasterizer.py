@@ -21,6 +21,49 @@ from ._lib import check
 
 GS_REC = 32
 _ZERO_IMAGES = {}
+_CAPACITY = [0]                   # > 0: capacity mode of cut3r_gs_bin (see fixed_capacity)
+LAST_INSTANCES = [0]              # largest instance count read back since it was last reset (sizes a capacity)
+_OVERFLOW = {}
+
+
+def overflow_flag(device):
+    """device int32 [1]: set to 1 by a capacity-mode pass whose scene needed more instances than the capacity"""
+    t = _OVERFLOW.get(device)
+    if t is None:
+        t = _OVERFLOW[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+_WS_BYTES = {}
+
+
+def workspace_bytes(P, n_instances):
+    """scan / sort scratch size for P Gaussians and n instances (cached: the size query itself must not run inside a stream capture)"""
+    key = (int(P), int(n_instances))
+    v = _WS_BYTES.get(key)
+    if v is None:
+        if len(_WS_BYTES) > 4096:
+            _WS_BYTES.clear()
+        v = _WS_BYTES[key] = int(_lib.load().cut3r_gs_workspace_bytes(key[0], key[1]))
+    return v
+
+
+class fixed_capacity:
+    """with fixed_capacity(n): every rasteriser pass inside sizes its binning buffers for n instances WITHOUT reading the count back
+    (no host stop: the pass can be captured in a graph).  The caller checks `overflow_flag(device)` afterwards."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev = _CAPACITY[0]
+        _CAPACITY[0] = self.n
+        return self
+
+    def __exit__(self, *a):
+        _CAPACITY[0] = self.prev
+        return False
+
 MAX_INSTANCES = 1 << 27          # sort buffers are sized from the data: refuse sizes that only a diverged map produces (3.2 GB at the limit)
 
 
@@ -88,12 +131,19 @@ def _forward(means3D, sh, colors_precomp, opacities, scales, rotations, st):
     buf.geom = torch.empty(P, GS_REC, **f32)
     tiles = torch.empty(P, dtype=torch.int32, device=dev)
     offsets = torch.empty(P, dtype=torch.int32, device=dev)
-    ws = torch.empty(int(lib.cut3r_gs_workspace_bytes(P, 0)), dtype=torch.uint8, device=dev)
+    ws = torch.empty(workspace_bytes(P, 0), dtype=torch.uint8, device=dev)
     view, proj, campos = _host16(st.viewmatrix, 16), _host16(st.projmatrix, 16), _host16(st.campos, 3)
     check(lib.cut3r_gs_preprocess(P, _p(means3D), _p(scales), _p(rotations), _p(opacities), _p(sh), int(st.sh_degree), K, _p(colors), view, proj,
                                   campos, W, H, float(st.tanfovx), float(st.tanfovy), float(st.kernel_size), float(st.scale_modifier), _p(buf.geom),
                                   _p(radii), _p(tiles), _p(offsets), _p(ws), ws.numel(), _s()), "gs_preprocess")
-    n_inst = int(offsets[-1].item()) & 0xffffffff                     # the one host read of the pass (rasterizer_impl.cu:346-354)
+    overflow = None
+    if _CAPACITY[0]:
+        # capacity mode (fixed_capacity()): the instance count is NOT read back -- buffers of the given size, padded, overflow flagged
+        n_inst = int(_CAPACITY[0])
+        overflow = overflow_flag(dev)
+    else:
+        n_inst = int(offsets[-1].item()) & 0xffffffff                 # the one host read of the pass (rasterizer_impl.cu:346-354)
+        LAST_INSTANCES[0] = max(LAST_INSTANCES[0], n_inst)
     if n_inst > MAX_INSTANCES:
         raise RuntimeError(f"GaussianRasterizer: {n_inst} Gaussian/tile instances (limit {MAX_INSTANCES}, 24 bytes each): degenerate scales or a "
                            "diverged map; raise gaussian_rasterizer.MAX_INSTANCES if this is intended")
@@ -104,13 +154,15 @@ def _forward(means3D, sh, colors_precomp, opacities, scales, rotations, st):
     keys_sorted = torch.empty_like(keys_tmp)
     vals_tmp = torch.empty(max(1, n_inst), dtype=torch.int32, device=dev)
     buf.point_list = torch.empty_like(vals_tmp)
-    ws2 = torch.empty(int(lib.cut3r_gs_workspace_bytes(P, n_inst)), dtype=torch.uint8, device=dev)
+    ws2 = torch.empty(workspace_bytes(P, n_inst), dtype=torch.uint8, device=dev)
     check(lib.cut3r_gs_bin(P, _p(buf.geom), _p(offsets), n_inst, W, H, _p(keys_tmp), _p(vals_tmp), _p(keys_sorted), _p(buf.point_list),
-                           _p(buf.ranges), _p(ws2), ws2.numel(), _s()), "gs_bin")
+                           _p(buf.ranges), _p(ws2), ws2.numel(), _p(overflow), _s()), "gs_bin")
     check(lib.cut3r_gs_render_forward(_p(buf.ranges), _p(buf.point_list), _p(buf.geom), W, H, float(st.tanfovx), float(st.tanfovy), bg,
                                       _p(out["color"]), _p(out["coord"]), _p(out["mcoord"]), _p(out["depth"]), _p(out["mdepth"]), _p(out["alpha"]),
                                       _p(out["normal"]), _p(buf.n_contrib), _p(buf.aux), _s()), "gs_render_forward")
-    buf.alpha, buf.coord, buf.depth, buf.normal = out["alpha"], out["coord"], out["depth"], out["normal"]
+    # detached aliases: the returned images become outputs of the autograd node that owns `buf`; holding them directly would tie the node
+    # to itself (only the cyclic collector would free the graph -- and keep its gradient accumulators alive until then)
+    buf.alpha, buf.coord, buf.depth, buf.normal = (out[k].detach() for k in ("alpha", "coord", "depth", "normal"))
     return out, radii, buf
 
 

@@ -225,10 +225,14 @@ class Camera:
         self.projection_matrix_host = P.T.contiguous()                  # the rasteriser reads its matrices on the host: no copy back per render
 
     def update_RT(self, R, T, data=None):
-        self.R, self.T = R.detach().clone(), T.detach().clone()
-        M = torch.eye(4, device=self.device)
-        M[:3, :3], M[:3, 3] = self.R, self.T
-        self.w2c_data = data.detach().clone() if data is not None else SE3_from_matrix(M).detach()
+        """in place: a captured iteration (GSMapper.optimization(graph=True)) writes the new pose through these tensors on every replay"""
+        self.R.copy_(R.detach())
+        self.T.copy_(T.detach())
+        if data is None:
+            M = torch.eye(4, device=self.device)
+            M[:3, :3], M[:3, 3] = self.R, self.T
+            data = SE3_from_matrix(M)
+        self.w2c_data.copy_(data.detach())
 
     @property
     def camera_center(self):
@@ -362,8 +366,13 @@ class GSMapper:
         self.gaussians = GaussianMap(config["opt_params"], device)
         self.background = torch.zeros(3, device=self.device)
         self.viewpoints = {}
+        # optimization() / pose_refine(): capture one iteration as a hipGraph and replay it.  Capturing costs tens of eager iterations
+        # (collection, three eager iterations on the capture stream, instantiation), a replayed iteration about 40 % less than an eager one
+        # (tools/bench_gs.py: 2.30 -> 1.41 ms per render iteration over 400 iterations): it pays for long loops over a fixed set of Gaussians (a final refinement), not for the 20-100 iteration calls of run()
+        self.use_graphs = False
+        self.graph_min_iters = 150
 
-    def _pose_optimizer(self, views, exposure=False):
+    def _pose_optimizer(self, views, exposure=False, capturable=False):
         lr = self.config["opt_params"]["pose_lr"]
         groups = []
         for v in views:
@@ -371,16 +380,65 @@ class GSMapper:
             if exposure:                                                  # gs_backend_per_frame.py:467-475
                 elr = self.config["opt_params"].get("exposure_lr", 0.0005)
                 groups += [{"params": [v.exposure_a], "lr": elr}, {"params": [v.exposure_b], "lr": elr}]
-        return torch.optim.Adam(groups)
+        return torch.optim.Adam(groups, capturable=capturable)
 
-    def pose_refine(self, BA_window, iters=50, return_args=True, alpha_th=0.5):
+    def _loop(self, one_iteration, iters, use_graph, opt):
+        """run `one_iteration(it, eager)` iters times; with use_graph: three eager iterations, then ONE captured as a hipGraph and replayed.
+        Returns the last loss (a device tensor)."""
+        last = None
+        if not use_graph:
+            for it in range(iters):
+                last = one_iteration(it, True)                            # (read back once, by the caller)
+            return last
+        import gc
+        from . import gaussian_rasterizer as GR
+        warm = 3
+        GR.LAST_INSTANCES[0] = 0
+        gc.collect()                                                      # no autograd graph of an earlier pass may survive into the capture
+        # the eager iterations run on the stream the capture will use: autograd's gradient accumulators remember the stream of their
+        # first use, and a backward pass inside the capture that has to synchronise with another stream ends the process
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for it in range(warm):
+                last = one_iteration(it, True)
+            cap = int(1.25 * GR.LAST_INSTANCES[0]) + 8192
+            flag = GR.overflow_flag(self.device)
+            flag.zero_()
+            GR.workspace_bytes(len(self.gaussians), 0), GR.workspace_bytes(len(self.gaussians), cap)      # (size queries outside the capture)
+            self.gaussians.zero_grad()
+            if opt is not None:
+                opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        was = gc.isenabled()
+        gc.disable()                                                      # (a collection during capture may free tensors of the graph's pool)
+        try:
+            with GR.fixed_capacity(cap), torch.cuda.graph(g, stream=side):
+                static_loss = one_iteration(warm, False)
+        finally:
+            if was:
+                gc.enable()
+        for _ in range(iters - warm):
+            g.replay()
+        if int(flag):                                                     # one read after all replays
+            import warnings
+            warnings.warn(f"GSMapper: the captured iterations needed more than {cap} tile instances; their tile lists were truncated "
+                          "(falling back to the eager loop for this mapper)", RuntimeWarning)
+            self.use_graphs = False
+            flag.zero_()
+        return static_loss
+
+    def pose_refine(self, BA_window, iters=50, return_args=True, alpha_th=0.5, graph=None):
         """gs_backend_per_frame.py:202-326: the Gaussians stay fixed, the poses of the window move; photometric L1 on the covered pixels,
         scale-invariant log-depth variance, a small pull to the starting pose.  Returns (pointmaps_ds, valid_ds) of the refined poses."""
         views = [self.viewpoints[k] for k in BA_window]
         B = len(views)
         if len(self.gaussians) > 0:
-            opt = self._pose_optimizer(views)
-            for _ in range(iters):
+            use_graph = (graph if graph is not None else (self.use_graphs and iters >= self.graph_min_iters)) and iters >= 8
+            opt = self._pose_optimizer(views, capturable=use_graph)
+
+            def one_iteration(it, eager):
                 rgb_all = depth_all = pose_all = 0.0
                 for v in views:
                     pkg = render(v, self.gaussians, self.background)
@@ -402,6 +460,8 @@ class GSMapper:
                 self.gaussians.zero_grad()
                 loss.backward()
                 opt.step()
+                return loss.detach()
+            self._loop(one_iteration, iters, use_graph, opt)
             self.gaussians.zero_grad()
             for v in views:
                 update_pose(v)
@@ -443,15 +503,21 @@ class GSMapper:
         self.gaussians.extend_from_pcd_seq(submap_idx=kf_sub_idx, rgb=rgb, pointmap=pointmap[0], conf=valid[0])
         return idx
 
-    def optimization(self, iters, optimize_pose=True, current_window=None, densify=False):
+    def optimization(self, iters, optimize_pose=True, current_window=None, densify=False, graph=None):
         """gs_backend_per_frame.py:451-587: L1 + SSIM colour, inverse-depth L1, depth-normal agreement with the keyframe depth, isotropy;
-        Gaussians (and optionally the window's poses) step together; clone / split / prune at iters/4 and iters/2 when densifying."""
+        Gaussians (and optionally the window's poses) step together; clone / split / prune at iters/4 and iters/2 when densifying.
+        graph (default `self.use_graphs`): when the set of Gaussians stays fixed (no densification) and there are enough iterations,
+        ONE iteration -- render, losses, backward, both optimiser steps, pose update -- is captured as a hipGraph after three eager
+        iterations and replayed: the ~300 small launches of an iteration stop costing host time.  The rasteriser runs in capacity mode
+        inside the graph (no instance-count read); its overflow flag is checked once after the replays."""
         views = [self.viewpoints[k] for k in current_window]
         N = len(views)
         exposure = bool(self.config["Training"].get("compensate_exposure", False))
-        opt = self._pose_optimizer(views, exposure) if optimize_pose else None
-        last = None
-        for it in range(iters):
+        use_graph = ((graph if graph is not None else (self.use_graphs and iters >= self.graph_min_iters)) and not densify and iters >= 8
+                     and len(self.gaussians) > 0)
+        opt = self._pose_optimizer(views, exposure, capturable=use_graph) if optimize_pose else None
+
+        def one_iteration(it, eager):
             loss = 0.0
             stats = []
             for v in views:
@@ -481,19 +547,21 @@ class GSMapper:
                 opt.zero_grad(set_to_none=True)
             loss.backward()
             with torch.no_grad():
-                if densify:
+                if densify and eager:
                     for vs, vis, radii in stats:
                         self.gaussians.max_radii2D = torch.max(self.gaussians.max_radii2D, radii.float() * vis)
                         self.gaussians.add_densification_stats(vs.grad, vis)
                 self.gaussians.step()
-                if densify and it in (iters // 4, iters // 2):
+                if densify and eager and it in (iters // 4, iters // 2):
                     self.gaussians.densify_and_prune(self.config["opt_params"]["densify_grad_threshold"], self.gaussian_th, self.gaussian_extent,
                                                      self.size_threshold)
             if opt is not None:
                 opt.step()
                 for v in views:
                     update_pose(v)
-            last = loss.detach()                                          # (read back once, after the loop)
+            return loss.detach()
+
+        last = self._loop(one_iteration, iters, use_graph, opt)
         self.gaussians.zero_grad()
         return float(last) if last is not None else None
 

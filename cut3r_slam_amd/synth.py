@@ -108,7 +108,7 @@ def gs_wall_window(H: int = 384, W: int = 512, focal: float = 440.0, n_views: in
     return packet, torch.stack(imgs), cfg
 
 
-def gs_mapper_window_leg(H: int = 384, W: int = 512, device="cuda:0"):
+def gs_mapper_window_leg(H: int = 384, W: int = 512, device="cuda:0", use_graphs: bool = False):
     """one synthetic 6-keyframe window through GSMapper.run with the reference's iteration counts (gs_backend_per_frame.py:776-862: 100
     initial, per new keyframe 50 pose-refine + 20 window + 50 single-view, 10 per view global) -> timing / quality figures"""
     import time
@@ -116,6 +116,7 @@ def gs_mapper_window_leg(H: int = 384, W: int = 512, device="cuda:0"):
     packet, imgs, cfg = gs_wall_window(H, W, device=device)
     n = len(packet["viz_idx"])
     mapper = GM.GSMapper(cfg, float(packet["intrinsics"][0]), float(packet["intrinsics"][1]), W / 2, H / 2, downsample_ratio=2, device=device)
+    mapper.use_graphs, mapper.graph_min_iters = use_graphs, 12
     torch.cuda.synchronize()
     t0 = time.time()
     with torch.enable_grad():
@@ -128,6 +129,7 @@ def gs_mapper_window_leg(H: int = 384, W: int = 512, device="cuda:0"):
             r = GM.render(mapper.viewpoints[k], mapper.gaussians, torch.zeros(3, device=device))["render"]
             ps.append(float(-10 * torch.log10(((r - imgs[k].float() / 255) ** 2).mean())))
     renders = 100 + (n - 1) * (50 + 50) + sum(20 * min(k + 1, 10) for k in range(1, n)) + 10 * n
-    return {"config": f"synthetic wall, {n} keyframes at {W}x{H}, one Gaussian per stride-2 pixel of the first keyframe, the reference's iteration counts",
+    return {"config": f"synthetic wall, {n} keyframes at {W}x{H}, one Gaussian per stride-2 pixel of the first keyframe, the reference's iteration counts"
+                      + (", iterations without densification replayed from a captured hipGraph" if use_graphs else ""),
             "seconds": round(dt, 3), "ms_per_keyframe": round(1e3 * dt / n, 1), "render_iterations": renders,
             "ms_per_render_iteration": round(1e3 * dt / renders, 3), "gaussians": len(mapper.gaussians), "psnr_db": round(sum(ps) / n, 2)}

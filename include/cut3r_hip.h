@@ -324,6 +324,9 @@ int cut3r_remap_linear_u8(const void* src, int H, int W, int C, const int32_t* m
  *   preprocess: forward.cu:308-421 per Gaussian + inclusive scan of the covered-tile counts -> offsets[P] (offsets[P-1] = number of
  *               instances, read back by the caller to size the binning buffers, as rasterizer_impl.cu:346-354 does).
  *   bin:        rasterizer_impl.cu:70-112,151-176: instance keys (tile << 32 | depth bits), radix sort, per-tile [start, end).
+ *               overflow == NULL: n_instances is offsets[P-1] read back by the caller.  overflow != NULL (capacity mode, for callers
+ *               that must not stop the host, e.g. inside a captured graph): n_instances is a capacity, unused entries are padded
+ *               behind the last tile, *overflow is set to 1 on the device if the scene needed more.
  *   render:     forward.cu:429-692.  color/coord/mcoord/normal [3,H,W]; depth/mdepth/alpha [1,H,W]; n_contrib uint32 [2,H,W];
  *               aux float [2,H,W] (final transmittance, normal length: kept for the backward pass). */
 int cut3r_gs_preprocess(int P, const float* means, const float* scales, const float* rots, const float* opacities, const float* shs,
@@ -333,7 +336,7 @@ int cut3r_gs_preprocess(int P, const float* means, const float* scales, const fl
 long long cut3r_gs_workspace_bytes(int P, long long n_instances);
 int cut3r_gs_bin(int P, const float* geom, const unsigned* offsets, long long n_instances, int W, int H, unsigned long long* keys_tmp,
                  unsigned* vals_tmp, unsigned long long* keys_sorted, unsigned* point_list, unsigned* ranges, void* sort_ws,
-                 long long sort_ws_bytes, void* stream);
+                 long long sort_ws_bytes, int* overflow, void* stream);
 int cut3r_gs_render_forward(const unsigned* ranges, const unsigned* point_list, const float* geom, int W, int H, float tanfovx, float tanfovy,
                             const float* bg_host, float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth,
                             float* out_alpha, float* out_normal, unsigned* n_contrib, float* aux, void* stream);

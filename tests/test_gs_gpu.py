@@ -224,3 +224,36 @@ def test_scale_modifier_and_opacity_cap_paths():
     _compare(outs[4], ref["depth"], "depth (scale_modifier 1.7)", 2e-5, 0.004)
     _grad_compare(hm.grad, lm.grad, "means3D (capped alphas)", 5e-4, 0.02)
     _grad_compare(ho.grad, lo.grad, "opacities (capped alphas)", 5e-4, 0.02)
+
+
+def test_capacity_mode_equals_the_counted_pass_and_flags_overflow():
+    """cut3r_gs_bin with a capacity instead of the read-back instance count (for callers that must not stop the host): same images and
+    gradients bit for bit when the capacity suffices; the device flag is raised when it does not"""
+    from cut3r_slam_amd import gaussian_rasterizer as GR
+    H, W, P = 64, 80, 300
+    means, scales, q, op, shs = _scene(P, 5)
+    st = GO.camera_settings(H, W, 1.0, 1.0 * H / W, _w2c(0.1, -0.1, (0.0, 0.0, 0.2)), bg=(0.1, 0.2, 0.3), sh_degree=1)
+    f = lambda t: t.float().to(DEV)
+    rast = GaussianRasterizer(_settings(st))
+
+    def run():
+        leaves = [f(t).requires_grad_(True) for t in (means, op, shs, scales, q)]
+        outs = rast(means3D=leaves[0], means2D=torch.zeros(P, 3, device=DEV), opacities=leaves[1], shs=leaves[2], scales=leaves[3], rotations=leaves[4])
+        (outs[0].sum() + 2.0 * outs[4].sum() + outs[7].sum()).backward()
+        return [o.detach().clone() for o in outs], [l.grad.clone() for l in leaves]
+    GR.LAST_INSTANCES[0] = 0
+    o0, g0 = run()
+    n = GR.LAST_INSTANCES[0]
+    assert n > 1000
+    GR.overflow_flag(torch.device(DEV)).zero_()
+    with GR.fixed_capacity(int(1.5 * n) + 7):
+        o1, g1 = run()
+    assert int(GR.overflow_flag(torch.device(DEV))) == 0
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    for a, b in zip(g0[2:], g1[2:]):                                     # (atomics: means / opacities may differ in the last bits)
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+    with GR.fixed_capacity(n // 2):
+        run()
+    assert int(GR.overflow_flag(torch.device(DEV))) == 1
+    GR.overflow_flag(torch.device(DEV)).zero_()

@@ -294,3 +294,26 @@ def test_exposure_compensation_absorbs_a_gain_change():
     print(f"[gs mapper] exposure: loss {first:.4f} -> {last:.4f}, mean diagonal gain {gain:.3f}")
     assert last < 0.7 * first and 0.8 < gain < 0.95
     assert torch.equal(truth.p["f_dc"].detach(), colours0)
+
+
+def test_captured_iterations_follow_the_eager_loop():
+    """GSMapper.optimization(graph=True): one iteration captured as a hipGraph and replayed (rasteriser in capacity mode) reaches the same
+    loss and poses as the eager loop, within the noise of the atomics"""
+    truth = _truth()
+    poses = [_pose7(0, 0, 0, 0, 0), _pose7(0.15, 0.0, 0.0, 0.0, -0.04)]
+    obs = [_observe(truth, p) for p in poses]
+    res = {}
+    for mode in (False, True):
+        m = GM.GSMapper(CONFIG, FX, FY, CX, CY, downsample_ratio=2, device=DEV)
+        g = torch.Generator().manual_seed(4)
+        for k, (p, (img, depth)) in enumerate(zip(poses, obs)):
+            m.add_new_view(img, p, depth.cpu().mul(1 + 0.01 * torch.randn(H, W, generator=g)).to(DEV), kf_sub_idx=k, iters=5)
+        loss = m.optimization(40, optimize_pose=True, current_window=[0, 1], graph=mode)
+        res[mode] = (loss, m.trajectory().cpu(), m.gaussians.theta.detach().cpu().clone(), m.use_graphs)
+    print(f"[gs mapper] 40 iterations: eager loss {res[False][0]:.5f}, captured {res[True][0]:.5f}")
+    assert abs(res[True][0] - res[False][0]) < 0.02 * res[False][0]
+    torch.testing.assert_close(res[True][1], res[False][1], atol=2e-4, rtol=0)
+    # (Adam with eps 1e-15 turns the last-bit noise of the atomics into +-lr steps on parameters whose gradient is ~0: compare in the mean)
+    dth = (res[True][2] - res[False][2]).abs()
+    print(f"[gs mapper] parameters, captured vs eager: mean |diff| {float(dth.mean()):.2e}, max {float(dth.max()):.2e}")
+    assert float(dth.mean()) < 1e-3 and float(dth.max()) < 0.2

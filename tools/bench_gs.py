@@ -88,8 +88,21 @@ for P in args.points:
 # ---- the mapper on a synthetic wall at the tracking resolution (384x512): one 6-keyframe window through GSMapper.run with the
 #      reference's iteration counts (the same leg bench.py reports as operating_points.gs_mapper_synthetic_window)
 if os.environ.get("CUT3R_BENCH_GS_MAPPER", "1") == "1":
-    from cut3r_slam_amd import synth
+    import time
+    from cut3r_slam_amd import synth, gs_mapper as GM
     r = synth.gs_mapper_window_leg(384, 512, DEV)
     print(f"mapper, one 6-keyframe window at 512x384: {r['seconds']:.2f} s = {r['ms_per_keyframe']:.0f} ms per keyframe, about {r['render_iterations']} "
           f"forward+backward renders ({r['ms_per_render_iteration']:.2f} ms each incl. losses and optimiser), {r['gaussians']} Gaussians, "
           f"PSNR {r['psnr_db']:.1f} dB")
+    # a long loop over a fixed set of Gaussians (a final refinement): eager vs one captured iteration replayed
+    packet, imgs, cfg = synth.gs_wall_window(384, 512, device=DEV)
+    for graphs in (False, True):
+        m = GM.GSMapper(cfg, 440.0, 440.0, 256.0, 192.0, downsample_ratio=2, device=DEV)
+        m.run(packet, iterations=5, init_iters=20, gba_per_view=1)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        loss = m.optimization(400, optimize_pose=True, current_window=[0, 1, 2], graph=graphs)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        print(f"mapper, 400 iterations over 3 views, {'captured and replayed' if graphs else 'eager'}: {dt:.2f} s = {1e3 * dt / 1200:.2f} ms per render "
+              f"iteration, loss {loss:.4f}")
