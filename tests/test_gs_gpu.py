@@ -199,7 +199,7 @@ def test_fused_ssim_matches_convolutions_forward_and_backward(C, H, W):
     ag = a.to(DEV).requires_grad_(True)
     got = fused_ssim(ag, b.to(DEV))
     (3.0 * got).backward()
-    assert abs(float(got) - float(ref)) < 2e-6
+    assert abs(float(got.detach()) - float(ref.detach())) < 2e-6
     np.testing.assert_allclose(ag.grad.cpu().numpy() / 3.0, a64.grad.numpy(), atol=2e-6 * float(a64.grad.abs().max()) + 1e-10)
 
 
