@@ -9,12 +9,12 @@ rasteriser.  Mirrors, with the same names, argument meaning
   GSMapper.pose_refine   hislam2/gs_backend_per_frame.py:202-326
   GSMapper.optimization  hislam2/gs_backend_per_frame.py:451-587
   GSMapper.add_new_view  hislam2/gs_backend_per_frame.py:87-121
-  GSMapper.global_BA     hislam2/gs_backend_per_frame.py:946-1058 (all keyframes, poses and Gaussians together; simplified schedule)
+  GSMapper.global_BA     hislam2/gs_backend_per_frame.py:946-1062 (all keyframes, poses and Gaussians together, one random keyframe per
+                         iteration, densification / opacity-reset / learning-rate schedule)
 
 The reference's backend cannot run here (CUDA rasteriser, open3d, munch): PARITY UNPINNED, covered by functional tests on a
 synthetic scene (tests/test_gs_mapper_gpu.py).  The rasteriser and the 3-NN search are the HIP kernels of csrc/gs.hip; the loss
-terms and the Adam updates are plain torch tensor arithmetic on the GPU.  Not built: GUI, opacity reset
-schedule, ply export, LPIPS and the TSDF / mesh evaluation utilities (PSNR / SSIM of the keyframes and a safetensors checkpoint are).
+terms and the Adam updates are plain torch tensor arithmetic on the GPU.  Not built: GUI, ply export, LPIPS and the TSDF / mesh evaluation utilities (PSNR / SSIM of the keyframes and a safetensors checkpoint are).
 `gaussain_update` (the map correction after a loop closure, :701-774) composes rotations consistently by default; see its docstring."""
 from __future__ import annotations
 
@@ -126,6 +126,13 @@ class GaussianMap:
         self.m, self.v = self.m[keep], self.v[keep]
         self.step_count, self.kf_id, self.max_radii2D = self.step_count[keep], self.kf_id[keep], self.max_radii2D[keep]
         self.grad_accum, self.denom = self.grad_accum[keep], self.denom[keep]
+
+    def reset_opacity(self):
+        """gaussian_model.py:483-486: every opacity back to 0.15, its optimiser state cleared"""
+        with torch.no_grad():
+            self.theta[:, 6:7] = float(inverse_sigmoid(torch.tensor(0.15)))
+            self.m[:, 6:7] = 0
+            self.v[:, 6:7] = 0
 
     def reset_moments(self, rows):
         """optimiser state of the given Gaussians back to that of new ones (what the reference's prune + re-append does)"""
@@ -366,6 +373,7 @@ class GSMapper:
         self.gaussians = GaussianMap(config["opt_params"], device)
         self.background = torch.zeros(3, device=self.device)
         self.viewpoints = {}
+        self.iteration_count = 0
         # optimization() / pose_refine(): capture one iteration as a hipGraph and replay it.  Capturing costs tens of eager iterations
         # (collection, three eager iterations on the capture stream, instantiation), a replayed iteration about 40 % less than an eager one
         # (tools/bench_gs.py: 2.30 -> 1.41 ms per render iteration over 400 iterations): it pays for long loops over a fixed set of Gaussians (a final refinement), not for the 20-100 iteration calls of run()
@@ -565,17 +573,73 @@ class GSMapper:
         self.gaussians.zero_grad()
         return float(last) if last is not None else None
 
-    def global_BA(self, iteration_total, window=8, densify=True):
-        """gs_backend_per_frame.py:946-1058 in outline: every keyframe takes part; random windows of keyframes are optimised jointly
-        (Gaussians + poses) until iteration_total renders have been spent"""
-        keys = list(self.viewpoints.keys())
-        g = torch.Generator().manual_seed(0)
-        spent, last = 0, None
-        while spent < iteration_total and keys:
-            pick = [keys[i] for i in torch.randperm(len(keys), generator=g)[:window].tolist()]
-            n = max(1, min(10, (iteration_total - spent) // len(pick)))
-            last = self.optimization(n, optimize_pose=True, current_window=pick, densify=densify and spent < iteration_total // 2)
-            spent += n * len(pick)
+    def global_BA(self, iteration_total, densify=True, densify_every=None, opacity_reset=True, seed=0):
+        """gs_backend_per_frame.py:946-1058: Gaussians and ALL keyframe poses (and exposures) together, one randomly drawn keyframe per
+        iteration; colour, inverse-depth (only with densify_every), agreement of the rendered normal with the normal of the rendered
+        depth, and of that with the keyframe depth's normal; clone / split / prune at half time (densify_every) or every
+        Training.gaussian_update_every iterations, opacity reset every Training.gaussian_reset iterations, position learning-rate decay."""
+        import random
+        views = list(self.viewpoints.values())
+        if not views or len(self.gaussians) == 0:
+            return None
+        exposure = bool(self.config["Training"].get("compensate_exposure", False))
+        opt = self._pose_optimizer(views, exposure)
+        rng = random.Random(seed)
+        tr, op = self.config["Training"], self.config["opt_params"]
+        update_every, reset_every = tr.get("gaussian_update_every", 200), tr.get("gaussian_reset", 3001)
+        last = None
+        for iteration in range(iteration_total):
+            self.iteration_count += 1
+            v = views[rng.randint(0, len(views) - 1)]
+            pkg = render(v, self.gaussians, self.background)
+            image, depth = pkg["render"], pkg["depth"]
+            if exposure:
+                image = (image.permute(1, 2, 0) @ v.exposure_a + v.exposure_b).permute(2, 0, 1).contiguous()
+            gt_image, gt_depth = v.original_image, v.depth[None]
+            rgb = 0.8 * torch.abs(gt_image - image).mean() + 0.2 * (1.0 - ssim(image, gt_image))
+            dmask = ((gt_depth > 0.001) & (depth > 0.001)).detach()
+            nd = dmask.sum().clamp_min(1)
+            one = torch.ones_like(depth)
+            dl = (torch.abs(1.0 / torch.where(dmask, depth, one) - 1.0 / torch.where(dmask, gt_depth, one)) * dmask).sum() / nd
+            gcache = getattr(v, "_gt_normal", None)
+            if gcache is None or gcache[0] is not v.depth:
+                gcache = v._gt_normal = (v.depth, depth_to_normal(v, gt_depth).detach())
+            dn = depth_to_normal(v, depth)
+            nl = (1 - (pkg["normal"] * dn).sum(0)).mean()
+            gnl = ((1 - (dn * gcache[1]).sum(0, keepdim=True)) * dmask).sum() / nd
+            if densify_every is not None:
+                loss = rgb + self.lambda_depth / 10 * dl + self.lambda_normal * nl + self.lambda_normal * gnl
+            else:
+                loss = rgb + self.lambda_normal / 2 * nl + self.lambda_normal / 2 * gnl
+            self.gaussians.zero_grad()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            with torch.no_grad():
+                if iteration < 10000 and densify:
+                    vis = pkg["visibility_filter"]
+                    self.gaussians.max_radii2D = torch.max(self.gaussians.max_radii2D, pkg["radii"].float() * vis)
+                    self.gaussians.add_densification_stats(pkg["viewspace_points"].grad, vis)
+                self.gaussians.step()
+                if iteration < 10000 and densify:
+                    do_densify = (iteration == iteration_total // 2) if densify_every is not None else ((self.iteration_count + 1) % update_every == 0)
+                    if do_densify:
+                        self.gaussians.densify_and_prune(op["densify_grad_threshold"], self.gaussian_th, self.gaussian_extent, self.size_threshold)
+                    if (self.iteration_count + 1) % reset_every == 0 and opacity_reset:
+                        self.gaussians.reset_opacity()
+                    if "position_lr_final" in op:                           # gaussian_model.py:419-431, general_utils.py:41-56
+                        t = min(max(iteration / (op.get("position_lr_max_steps", 20000) + 1000), 0.0), 1.0)
+                        self.gaussians.lr[0, 0:3] = math.exp(math.log(op["position_lr_init"]) * (1 - t) + math.log(op["position_lr_final"]) * t)
+            opt.step()
+            update_pose(v)
+            last = loss.detach()
+        self.gaussians.zero_grad()
+        return float(last) if last is not None else None
+
+    def global_pose_refine(self, iters=5):
+        """gs_backend_per_frame.py:1060-1062"""
+        last = None
+        for _ in range(iters):
+            last = self.global_BA(iteration_total=5 * len(self.viewpoints), densify=True, opacity_reset=False)
         return last
 
     # ---- the tracker-facing entry points (hi2.py:56-99 calls run() once per tracked window)
@@ -619,7 +683,8 @@ class GSMapper:
                 self.gaussians.extend_from_pcd_seq(submap_idx=submap_idx, rgb=imgs[i, :, ::ds, ::ds].permute(1, 2, 0), pointmap=pm[0], conf=valid[0])
                 self.optimization(min(20, iterations), current_window=self.current_window)
                 self.optimization(min(50, iterations), current_window=[idx], optimize_pose=False)
-        self.global_BA(gba_per_view * len(self.viewpoints), densify=True)
+        gba_iters = gba_per_view * len(self.viewpoints)
+        self.global_BA(iteration_total=gba_iters, densify=True, densify_every=gba_iters // 2, opacity_reset=False)      # :860-861
         return self.data_update(self.h, self.w, self.current_window)
 
     def gaussain_update(self, packet, reference_quat_order=False, refine_iters=50):

@@ -130,8 +130,14 @@ def test_mapping_from_keyframes_reaches_the_observations():
     print(f"[gs mapper] mapping: {n0} -> {len(mapper.gaussians)} Gaussians, loss {first:.4f} -> {last:.4f}, PSNR {before:.2f} -> {after:.2f} dB, "
           f"median depth error {100 * derr:.2f} cm")
     assert last < 0.6 * first and after > before + 3.0 and after > 22.0 and derr < 0.05
-    ba = mapper.global_BA(60, window=3, densify=False)
-    assert ba is not None and ba < 1.2 * last
+    # global BA (one random keyframe per iteration, the rendered-normal terms, densification at half time): stays at the optimum
+    n_before = len(mapper.gaussians)
+    ba = mapper.global_BA(60, densify=True, densify_every=30, opacity_reset=False)
+    with torch.no_grad():
+        after_ba = np.mean([_psnr(GM.render(mapper.viewpoints[k], mapper.gaussians, bg)["render"], obs[k][0]) for k in range(3)])
+    print(f"[gs mapper] global BA: loss {ba:.4f}, PSNR {after_ba:.2f} dB, {n_before} -> {len(mapper.gaussians)} Gaussians")
+    assert ba is not None and np.isfinite(ba) and after_ba > after - 3.0
+    assert mapper.global_pose_refine(iters=1) is not None
     traj = mapper.trajectory()
     assert traj.shape == (3, 4, 4) and torch.isfinite(traj).all()
     # evaluation and checkpoint round trip (gs_backend_per_frame.py:1088-1102)
