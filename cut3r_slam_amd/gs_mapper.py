@@ -635,6 +635,20 @@ class GSMapper:
         self.gaussians.zero_grad()
         return float(last) if last is not None else None
 
+    def finalize(self, iteration_total=None, path=None):
+        """gs_backend_per_frame.py:1067-1086: the closing global BA (the reference runs `max_steps` = position_lr_max_steps iterations),
+        an optional checkpoint, and the keyframe poses camera->world [n,7] (t, q_xyzw) in keyframe order (the views added by
+        terminate() come after the tracker's keyframes, as in the reference's dict order)"""
+        self.iteration_count = 0
+        if iteration_total is None:
+            iteration_total = int(self.config["opt_params"].get("position_lr_max_steps", 20000))
+        if iteration_total > 0:
+            self.global_BA(iteration_total=iteration_total)
+        if path is not None:
+            self.save(path)
+        with torch.no_grad():
+            return torch.stack([SE3_from_matrix(torch.inverse(get_pose(v))) for v in self.viewpoints.values()])
+
     def global_pose_refine(self, iters=5):
         """gs_backend_per_frame.py:1060-1062"""
         last = None

@@ -134,8 +134,10 @@ class Cut3rSlam:
                     on_frame(t_start + i, out)
 
     @torch.no_grad()
-    def terminate(self, add_kf=False, gap=30):
-        """hi2.py:152-229 without the Gaussian mapper.  With add_kf (demo_s.py:171 passes True) every pair of consecutive
+    def terminate(self, add_kf=False, gap=30, finalize_iters=None):
+        """hi2.py:152-229.  With the Gaussian mapper attached (`self.mapper`) the extra views go to `mapper.add_new_view`, the mapper
+        finalises (`GSMapper.finalize`: a global BA of `finalize_iters` iterations, default the configured position_lr_max_steps as the
+        reference's `max_steps`; 0 skips it) and its poses are written back (hi2.py:214-216).  With add_kf (demo_s.py:171 passes True) every pair of consecutive
         keyframes more than `gap` frames apart gets ONE extra view at the middle frame: the kept full-resolution frame is resized
         to the tracking resolution (bilinear, align_corners=False, hi2.py:198) and relocalised against the earlier keyframe by a
         2-view inference (TrackFrontend.predict, track_frontend.py:102-162).  The reference hands these views to
@@ -161,7 +163,15 @@ class Cut3rSlam:
                         img = f.round().clamp(0, 255).to(torch.uint8)
                     pose, depth, pm, conf = self.tracker.predict(img.to(self.device), kf.image[i], kf.pose[i], kf.depth[i],
                                                                  kf.submap_ds[i // 5, i % 5])
-                    views.append({"tstamp": t_new, "pose": pose, "depth": depth, "pointmap": pm, "conf": conf, "submap": i // 5})
+                    views.append({"tstamp": t_new, "pose": pose, "depth": depth, "pointmap": pm, "conf": conf, "submap": i // 5, "image": img})
+        if self.mapper is not None and getattr(self.mapper, "initialized", False):
+            with torch.enable_grad():
+                for v in views:                                           # hi2.py:203-211
+                    self.mapper.add_new_view(v["image"], torch.as_tensor(v["pose"]), v["depth"], v["tstamp"], v["submap"])
+                poses = self.mapper.finalize(finalize_iters)
+            n = min(max(last - 1, 0), poses.shape[0])
+            if n:
+                kf.set_poses_at(range(n), poses[:n].cpu().numpy())
         return kf.pose.numpy().copy(), views
 
     def trajectory(self):

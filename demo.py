@@ -63,6 +63,8 @@ def main(argv=None):
     p.add_argument("--small", action="store_true", help="debug: tiny architecture (with --synthetic-weights)")
     p.add_argument("--window-batch", type=int, default=1, help="tracking windows decoded together (1 = reference schedule)")
     p.add_argument("--device", default="cuda:0")
+    p.add_argument("--gs-final-iters", type=int, default=None, help="iterations of the mapper's closing global BA (default: the configured "
+                   "position_lr_max_steps, as the reference; 0 skips it)")
     p.add_argument("--gs", action="store_true", help="attach the Gaussian-splatting mapper (hislam2/hi2.py:47-48 always does; needs the "
                    "Mapping / Training / opt_params sections of the config, config/scannet_config.yaml:44-79)")
     args = p.parse_args(argv)
@@ -111,6 +113,7 @@ def main(argv=None):
     torch.cuda.synchronize()
     traj = stream.save_trajectory(slam, args.imagedir, args.output, start=args.start)
     if slam.mapper is not None and slam.mapper.viewpoints:
+        slam.terminate(add_kf=False, finalize_iters=args.gs_final_iters)  # demo_s.py:171 (the trajectory above is the tracker's, as demo_s.py:168-169)
         ev = slam.mapper.eval_rendering_kf()                              # demo_s.py:175-190 evaluates the renderings of the keyframes
         slam.mapper.save(os.path.join(args.output, "gaussians.safetensors"))
         print(f"GS mapper: {len(slam.mapper.gaussians)} Gaussians, {len(slam.mapper.viewpoints)} keyframes, PSNR {ev['mean_psnr']:.2f} dB, "

@@ -129,7 +129,7 @@ opt_params: {pose_lr: 0.0001, position_lr_init: 0.0005, feature_lr: 0.005, opaci
 """)
     out = tmp_path / "out"
     rc = demo.main(["--imagedir", str(d), "--calib", str(calib), "--config", str(cfg), "--output", str(out), "--kf_every", "2", "--synthetic-weights",
-                    "--small", "--seed", "1", "--gs"])
+                    "--small", "--seed", "1", "--gs", "--gs-final-iters", "20"])
     assert rc == 0
     rows = np.loadtxt(out / "traj_kf.txt")
     assert rows.ndim == 2 and rows.shape[1] == 8 and rows.shape[0] >= 8 and np.isfinite(rows).all()
