@@ -743,6 +743,114 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
     grad_a[o] = gscale[0] * (f[0] + 2.f * a[o] * f[1] + b[o] * f[2]);
 }
 
+// ------------------------------------------------------------------------------------------------ pixel losses of the mapper
+// The colour L1, inverse-depth L1 and depth-normal terms of gs_backend_per_frame.py:516-531 in one forward and one backward kernel.
+//   sums[0] = sum |gt - img| (3 channels), sums[1] = sum_mask |1/d - 1/gt_d|, sums[2] = sum_mask (1 - n(d) . g), sums[3] = |mask|
+//   mask = gt_d > 0.001 and d > 0.001;  n(d) = normalised cross product of the central differences of the back-projected depth
+//   (zero on the image border, as the padded tensor of the tensor formulation), g = the keyframe depth's own normal (constant).
+// Backward: grad_img = c_rgb sign(img - gt);  grad_d(p) = c_d(p) + sum over the four neighbours q whose normal uses d(p) of
+//   h_q . d c_q / d d(p),  h_q = -(g_q - n_q (n_q . g_q)) / |c_q|,  c_q = dx_q x dy_q,  dx_q = P(q + ex) - P(q - ex),  P(r) = ray(r) d(r).
+struct PixCam { float fx, fy, cx, cy; };
+
+DEVINL void pl_ray(const PixCam& k, int x, int y, float* r) { r[0] = ((float)x - k.cx) / k.fx; r[1] = ((float)y - k.cy) / k.fy; r[2] = 1.f; }
+DEVINL void pl_cross(const float* a, const float* b, float* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+// central differences of the back-projected points around interior pixel (x, y)
+DEVINL void pl_diffs(const float* __restrict__ d, const PixCam& k, int W, int x, int y, float* dx, float* dy) {
+    float ra[3], rb[3];
+    pl_ray(k, x + 1, y, ra); pl_ray(k, x - 1, y, rb);
+    const float da = d[(size_t)y * W + x + 1], db = d[(size_t)y * W + x - 1];
+#pragma unroll
+    for (int i = 0; i < 3; i++) dx[i] = ra[i] * da - rb[i] * db;
+    pl_ray(k, x, y + 1, ra); pl_ray(k, x, y - 1, rb);
+    const float dc = d[(size_t)(y + 1) * W + x], dd = d[(size_t)(y - 1) * W + x];
+#pragma unroll
+    for (int i = 0; i < 3; i++) dy[i] = ra[i] * dc - rb[i] * dd;
+}
+
+__global__ __launch_bounds__(256) void pixel_loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, const float* __restrict__ d,
+                                                             const float* __restrict__ gd, const float* __restrict__ gn, int H, int W, PixCam k,
+                                                             float* __restrict__ sums) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int HW = H * W;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[0] += fabsf(gt[(size_t)c * HW + p] - img[(size_t)c * HW + p]);
+        const float dp = d[p], gp = gd[p];
+        if (gp > 0.001f && dp > 0.001f) {
+            v[1] = fabsf(1.f / dp - 1.f / gp);
+            float dot = 0.f;
+            if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
+                float dx[3], dy[3], c[3];
+                pl_diffs(d, k, W, x, y, dx, dy);
+                pl_cross(dx, dy, c);
+                const float il = 1.f / fmaxf(sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]), 1e-12f);
+                dot = (c[0] * gn[p] + c[1] * gn[HW + p] + c[2] * gn[2 * HW + p]) * il;
+            }
+            v[2] = 1.f - dot;
+            v[3] = 1.f;
+        }
+    }
+    __shared__ float red[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float t = wave_sum(v[i]);
+        if (lane == 0) red[wave][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// coef (device): [c_rgb, c_depth, c_normal] = upstream gradient times weight over the normaliser of each term
+__global__ __launch_bounds__(256) void pixel_loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, const float* __restrict__ d,
+                                                             const float* __restrict__ gd, const float* __restrict__ gn, int H, int W, PixCam k,
+                                                             const float* __restrict__ coef, float* __restrict__ g_img, float* __restrict__ g_d) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int HW = H * W;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float c_rgb = coef[0], c_dep = coef[1], c_nrm = coef[2];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float e = img[(size_t)c * HW + p] - gt[(size_t)c * HW + p];
+        g_img[(size_t)c * HW + p] = e > 0.f ? c_rgb : (e < 0.f ? -c_rgb : 0.f);
+    }
+    float g = 0.f;
+    const float dp = d[p], gp = gd[p];
+    if (gp > 0.001f && dp > 0.001f) {
+        const float e = 1.f / dp - 1.f / gp;
+        g = (e > 0.f ? c_dep : (e < 0.f ? -c_dep : 0.f)) * (-1.f / (dp * dp));
+    }
+    float rp[3];
+    pl_ray(k, x, y, rp);
+    // the four pixels q whose normal reads d(p):  (qx, qy, sign, which): p = q + ex, q - ex, q + ey, q - ey
+    const int qx[4] = {x - 1, x + 1, x, x}, qy[4] = {y, y, y - 1, y + 1};
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const int xx = qx[n], yy = qy[n];
+        if (xx < 1 || xx > W - 2 || yy < 1 || yy > H - 2) continue;
+        const int q = yy * W + xx;
+        if (!(gd[q] > 0.001f && d[q] > 0.001f)) continue;
+        float dx[3], dy[3], c[3], dc[3];
+        pl_diffs(d, k, W, xx, yy, dx, dy);
+        pl_cross(dx, dy, c);
+        const float len = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        if (!(len > 1e-12f)) continue;                                         // (the clamped normalisation has no gradient through the norm there)
+        const float il = 1.f / len;
+        const float nq[3] = {c[0] * il, c[1] * il, c[2] * il}, gq[3] = {gn[q], gn[HW + q], gn[2 * HW + q]};
+        const float ng = nq[0] * gq[0] + nq[1] * gq[1] + nq[2] * gq[2];
+        const float h[3] = {-(gq[0] - nq[0] * ng) * il, -(gq[1] - nq[1] * ng) * il, -(gq[2] - nq[2] * ng) * il};
+        if (n < 2) pl_cross(rp, dy, dc); else pl_cross(dx, rp, dc);            // d c_q / d d(p) up to the sign of the difference
+        const float sgn = (n == 0 || n == 2) ? 1.f : -1.f;
+        g += c_nrm * sgn * (h[0] * dc[0] + h[1] * dc[1] + h[2] * dc[2]);
+    }
+    g_d[p] = g;
+}
+
 }  // namespace
 
 static int gs_fill_cam(GsCam& cam, const float* view, const float* proj, const float* campos, int W, int H, float tanx, float tany, float ks,
@@ -894,5 +1002,24 @@ extern "C" int cut3r_ssim_backward(const float* a, const float* b, const float* 
     if (!a || !b || !d_mu1 || !d_x11 || !d_x12 || !grad_scale || !grad_a || C <= 0 || H <= 0 || W <= 0) return CUT3R_ERR_ARG;
     hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C), dim3(256), 0, (hipStream_t)stream, a, b, d_mu1, d_x11,
                        d_x12, H, W, grad_scale, grad_a);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_pixel_loss_forward(const float* img, const float* gt_img, const float* depth, const float* gt_depth, const float* gt_normal,
+                                        int H, int W, float fx, float fy, float cx, float cy, float* sums, void* stream) {
+    if (!img || !gt_img || !depth || !gt_depth || !gt_normal || !sums || H < 3 || W < 3) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, 4 * sizeof(float), s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    hipLaunchKernelGGL(pixel_loss_fwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, img, gt_img, depth, gt_depth, gt_normal, H, W,
+                       PixCam{fx, fy, cx, cy}, sums);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_pixel_loss_backward(const float* img, const float* gt_img, const float* depth, const float* gt_depth, const float* gt_normal,
+                                         int H, int W, float fx, float fy, float cx, float cy, const float* coef, float* grad_img,
+                                         float* grad_depth, void* stream) {
+    if (!img || !gt_img || !depth || !gt_depth || !gt_normal || !coef || !grad_img || !grad_depth || H < 3 || W < 3) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(pixel_loss_bwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, img, gt_img, depth, gt_depth, gt_normal, H,
+                       W, PixCam{fx, fy, cx, cy}, coef, grad_img, grad_depth);
     return cut3r_check_launch();
 }

@@ -298,3 +298,41 @@ def fused_ssim(img, target):
     if img.device.type != "cuda":
         raise RuntimeError("fused_ssim: tensors must live on the GPU")
     return _FusedSSIM.apply(img, target)
+
+
+class _PixelLosses(torch.autograd.Function):
+    """colour L1 + inverse-depth L1 + depth-normal agreement in one kernel each way (`cut3r_pixel_loss_forward/backward`)"""
+
+    @staticmethod
+    def forward(ctx, image, depth, gt_image, gt_depth, gt_normal, K, w_rgb, w_depth, w_normal):
+        img, d = image.detach().contiguous().float(), depth.detach().contiguous().float()
+        H, W = img.shape[-2:]
+        sums = torch.empty(4, dtype=torch.float32, device=img.device)
+        check(_lib.load().cut3r_pixel_loss_forward(_p(img), _p(gt_image), _p(d), _p(gt_depth), _p(gt_normal), H, W, K[0], K[1], K[2], K[3], _p(sums),
+                                                   _s()), "pixel_loss_forward")
+        nd = sums[3].clamp_min(1.0)
+        ctx.save_for_backward(img, d, gt_image, gt_depth, gt_normal, nd)
+        ctx.K, ctx.w = K, (w_rgb, w_depth, w_normal)
+        return w_rgb * sums[0] / (3 * H * W) + (w_depth * sums[1] + w_normal * sums[2]) / nd
+
+    @staticmethod
+    def backward(ctx, g):
+        img, d, gt_image, gt_depth, gt_normal, nd = ctx.saved_tensors
+        H, W = img.shape[-2:]
+        w_rgb, w_depth, w_normal = ctx.w
+        coef = torch.stack([g * (w_rgb / (3 * H * W)), g * w_depth / nd, g * w_normal / nd]).float().contiguous()
+        g_img, g_d = torch.empty_like(img), torch.empty_like(d)
+        K = ctx.K
+        check(_lib.load().cut3r_pixel_loss_backward(_p(img), _p(gt_image), _p(d), _p(gt_depth), _p(gt_normal), H, W, K[0], K[1], K[2], K[3], _p(coef),
+                                                    _p(g_img), _p(g_d), _s()), "pixel_loss_backward")
+        return g_img, g_d, None, None, None, None, None, None, None
+
+
+def pixel_losses(image, depth, gt_image, gt_depth, gt_normal, K, w_rgb, w_depth, w_normal):
+    """w_rgb * mean|gt - image| + w_depth * mean_mask |1/depth - 1/gt_depth| + w_normal * mean_mask (1 - n(depth) . gt_normal), mask =
+    (gt_depth > 0.001) & (depth > 0.001)  (hislam2/gs_backend_per_frame.py:516-531).  image [3,H,W] and depth [1,H,W] or [H,W] receive
+    gradients; gt_image [3,H,W], gt_depth [H,W], gt_normal [3,H,W] are constants (contiguous float32); K = (fx, fy, cx, cy)."""
+    if image.device.type != "cuda":
+        raise RuntimeError("pixel_losses: tensors must live on the GPU")
+    return _PixelLosses.apply(image, depth, gt_image.contiguous(), gt_depth.contiguous(), gt_normal.contiguous(), tuple(float(v) for v in K),
+                              float(w_rgb), float(w_depth), float(w_normal))

@@ -23,7 +23,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from .gaussian_rasterizer import GaussianRasterizationSettings, GaussianRasterizer, distCUDA2, fused_ssim
+from .gaussian_rasterizer import GaussianRasterizationSettings, GaussianRasterizer, distCUDA2, fused_ssim, pixel_losses
 from .lietorch import SE3, SO3
 
 SH_C0 = 0.28209479177387814
@@ -534,20 +534,17 @@ class GSMapper:
                 if exposure:                                              # :513: colours through the view's affine exposure model
                     image = (image.permute(1, 2, 0) @ v.exposure_a + v.exposure_b).permute(2, 0, 1).contiguous()
                 gt_image, gt_depth = v.original_image, v.depth[None]
-                rgb = 0.8 * torch.abs(gt_image - image).mean() + 0.2 * (1.0 - ssim(image, gt_image))
-                dmask = ((gt_depth > 0.001) & (depth > 0.001)).detach()
-                nd = dmask.sum().clamp_min(1)
-                one = torch.ones_like(depth)
-                dl = (torch.abs(1.0 / torch.where(dmask, depth, one) - 1.0 / torch.where(dmask, gt_depth, one)) * dmask).sum() / nd
                 gcache = getattr(v, "_gt_normal", None)
                 if gcache is None or gcache[0] is not v.depth:               # the keyframe's own depth normals change only with its depth
-                    gcache = v._gt_normal = (v.depth, depth_to_normal(v, gt_depth).detach())
-                dn, gn = depth_to_normal(v, depth), gcache[1]
-                nl = ((1 - (dn * gn).sum(0, keepdim=True)) * dmask).sum() / nd
+                    gcache = v._gt_normal = (v.depth, depth_to_normal(v, gt_depth).detach().contiguous())
+                # :516-531 -- 0.8 L1 + 0.2 (1 - SSIM) colour, lambda_depth inverse-depth L1, lambda_normal depth-normal agreement: the three
+                # per-pixel terms in one fused kernel each way, SSIM in its own
+                pix = pixel_losses(image, depth, gt_image, v.depth, gcache[1], (v.fx, v.fy, v.cx, v.cy), 0.8, self.lambda_depth, self.lambda_normal)
+                rgb_dl_nl = pix + 0.2 * (1.0 - ssim(image, gt_image))
                 vis = pkg["visibility_filter"]
                 sc = self.gaussians.get_scaling
                 iso = (torch.abs(sc - sc.mean(dim=1, keepdim=True)) * vis[:, None]).sum() / (3 * vis.sum()).clamp_min(1)
-                loss = loss + rgb + self.lambda_depth * dl + self.lambda_normal * nl + self.lambda_iso * iso
+                loss = loss + rgb_dl_nl + self.lambda_iso * iso
                 stats.append((pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]))
             loss = loss / N
             self.gaussians.zero_grad()
@@ -596,21 +593,14 @@ class GSMapper:
             if exposure:
                 image = (image.permute(1, 2, 0) @ v.exposure_a + v.exposure_b).permute(2, 0, 1).contiguous()
             gt_image, gt_depth = v.original_image, v.depth[None]
-            rgb = 0.8 * torch.abs(gt_image - image).mean() + 0.2 * (1.0 - ssim(image, gt_image))
-            dmask = ((gt_depth > 0.001) & (depth > 0.001)).detach()
-            nd = dmask.sum().clamp_min(1)
-            one = torch.ones_like(depth)
-            dl = (torch.abs(1.0 / torch.where(dmask, depth, one) - 1.0 / torch.where(dmask, gt_depth, one)) * dmask).sum() / nd
             gcache = getattr(v, "_gt_normal", None)
             if gcache is None or gcache[0] is not v.depth:
-                gcache = v._gt_normal = (v.depth, depth_to_normal(v, gt_depth).detach())
-            dn = depth_to_normal(v, depth)
-            nl = (1 - (pkg["normal"] * dn).sum(0)).mean()
-            gnl = ((1 - (dn * gcache[1]).sum(0, keepdim=True)) * dmask).sum() / nd
-            if densify_every is not None:
-                loss = rgb + self.lambda_depth / 10 * dl + self.lambda_normal * nl + self.lambda_normal * gnl
-            else:
-                loss = rgb + self.lambda_normal / 2 * nl + self.lambda_normal / 2 * gnl
+                gcache = v._gt_normal = (v.depth, depth_to_normal(v, gt_depth).detach().contiguous())
+            nl = (1 - (pkg["normal"] * depth_to_normal(v, depth)).sum(0)).mean()          # rendered normal vs normal of the rendered depth
+            # :1003-1006: with densify_every  rgb + lambda_depth/10 depth + lambda_normal (nl + gt normal);  else  rgb + lambda_normal/2 (nl + gt normal)
+            w_d, w_n = (self.lambda_depth / 10, self.lambda_normal) if densify_every is not None else (0.0, self.lambda_normal / 2)
+            loss = (pixel_losses(image, depth, gt_image, v.depth, gcache[1], (v.fx, v.fy, v.cx, v.cy), 0.8, w_d, w_n)
+                    + 0.2 * (1.0 - ssim(image, gt_image)) + w_n * nl)
             self.gaussians.zero_grad()
             opt.zero_grad(set_to_none=True)
             loss.backward()

@@ -371,6 +371,16 @@ int cut3r_ssim_forward(const float* a, const float* b, int C, int H, int W, floa
                        void* stream);
 int cut3r_ssim_backward(const float* a, const float* b, const float* d_mu1, const float* d_x11, const float* d_x12, int C, int H, int W,
                         const float* grad_scale, float* grad_a, void* stream);
+/* the mapper's per-pixel loss terms (hislam2/gs_backend_per_frame.py:516-531: colour L1, inverse-depth L1, agreement of the normals
+ * of the rendered depth with those of the keyframe depth) in one pass.  img, gt_img [3,H,W]; depth, gt_depth [H,W]; gt_normal [3,H,W]
+ * (camera-frame normals of gt_depth, borders zero).  forward: sums[4] = {sum |gt - img|, sum_mask |1/d - 1/gt_d|,
+ * sum_mask (1 - n(d) . gt_normal), |mask|}, mask = gt_d > 0.001 and d > 0.001.  backward: coef[3] (device) = upstream gradient times
+ * weight over the normaliser of each term -> grad_img [3,H,W], grad_depth [H,W]. */
+int cut3r_pixel_loss_forward(const float* img, const float* gt_img, const float* depth, const float* gt_depth, const float* gt_normal, int H,
+                             int W, float fx, float fy, float cx, float cy, float* sums, void* stream);
+int cut3r_pixel_loss_backward(const float* img, const float* gt_img, const float* depth, const float* gt_depth, const float* gt_normal, int H,
+                              int W, float fx, float fy, float cx, float cy, const float* coef, float* grad_img, float* grad_depth,
+                              void* stream);
 
 #ifdef __cplusplus
 }

@@ -257,3 +257,40 @@ def test_capacity_mode_equals_the_counted_pass_and_flags_overflow():
         run()
     assert int(GR.overflow_flag(torch.device(DEV))) == 1
     GR.overflow_flag(torch.device(DEV)).zero_()
+
+
+@pytest.mark.parametrize("H,W", [(48, 64), (37, 50)])
+def test_fused_pixel_losses_match_the_tensor_formulation(H, W):
+    """cut3r_pixel_loss_forward/backward vs the tensor formulation of the mapper's colour-L1 / inverse-depth / depth-normal terms
+    (gs_backend_per_frame.py:516-531) in fp64: value, and gradients w.r.t. the rendered image and depth"""
+    from types import SimpleNamespace
+    from cut3r_slam_amd.gaussian_rasterizer import pixel_losses
+    from cut3r_slam_amd.gs_mapper import depth_to_normal
+    g = torch.Generator().manual_seed(H)
+    K = (60.0, 62.0, W / 2 - 0.3, H / 2 + 0.2)
+    ys, xs = torch.meshgrid(torch.arange(H).double(), torch.arange(W).double(), indexing="ij")
+    gt_depth = 2.0 + 0.3 * torch.sin(xs / 7) + 0.2 * torch.cos(ys / 5)
+    gt_depth[3:6, 4:9] = 0.0                                               # invalid keyframe depth: masked out
+    depth = (gt_depth + 0.05 * torch.randn(H, W, generator=g, dtype=torch.float64)).clamp_min(0.0)
+    depth[10:12, 20:25] = 0.0                                              # no rendered depth there
+    image, gt_image = torch.rand(3, H, W, generator=g, dtype=torch.float64), torch.rand(3, H, W, generator=g, dtype=torch.float64)
+    cam = SimpleNamespace(fx=K[0], fy=K[1], cx=K[2], cy=K[3])
+    gn = depth_to_normal(cam, gt_depth[None])
+    w = (0.8, 10.0, 0.1)
+    im64, d64 = image.clone().requires_grad_(True), depth[None].clone().requires_grad_(True)
+    dmask = (gt_depth[None] > 0.001) & (d64 > 0.001)
+    nd = dmask.sum().clamp_min(1)
+    one = torch.ones_like(d64)
+    ref = (w[0] * torch.abs(gt_image - im64).mean() + w[1] * (torch.abs(1 / torch.where(dmask, d64, one) - 1 / torch.where(dmask, gt_depth[None], one)) * dmask).sum() / nd
+           + w[2] * ((1 - (depth_to_normal(SimpleNamespace(fx=K[0], fy=K[1], cx=K[2], cy=K[3]), d64) * gn).sum(0, keepdim=True)) * dmask).sum() / nd)
+    ref.backward()
+    f = lambda t: t.float().to(DEV)
+    im, dd = f(image).requires_grad_(True), f(depth[None]).requires_grad_(True)
+    got = pixel_losses(im, dd, f(gt_image), f(gt_depth), f(gn), K, *w)
+    (2.0 * got).backward()
+    assert abs(float(got.detach()) - float(ref.detach())) < 2e-5 * abs(float(ref.detach()))
+    np.testing.assert_allclose(im.grad.cpu().numpy() / 2.0, im64.grad.numpy(), atol=1e-9)
+    gd, rd = dd.grad.cpu().numpy()[0] / 2.0, d64.grad.numpy()[0]
+    err = np.abs(gd - rd)
+    print(f"[gs] pixel losses: value {float(got.detach()):.6f} vs {float(ref.detach()):.6f}, depth-gradient max |err| {err.max():.2e} (scale {np.abs(rd).max():.2e})")
+    assert err.max() < 2e-4 * np.abs(rd).max()
