@@ -851,6 +851,51 @@ __global__ __launch_bounds__(256) void pixel_loss_bwd_kernel(const float* __rest
     g_d[p] = g;
 }
 
+// pose refinement (gs_backend_per_frame.py:240-262): colour L1 over the covered pixels (alpha > th) and the variance of
+// log d - log gt_d over the covered pixels with both depths valid.  sums[5] = {sum_a |gt - img|, |a|, sum_m diff, sum_m diff^2, |m|}.
+// backward: coef[3] (device) = {c_rgb, c_var, mean diff}:  grad_img = c_rgb sign(img - gt) on a;  grad_d = c_var 2 (diff - mean) / d on m.
+__global__ __launch_bounds__(256) void refine_loss_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, const float* __restrict__ d,
+                                                              const float* __restrict__ gd, const float* __restrict__ alpha, float alpha_th, int HW,
+                                                              float* __restrict__ sums) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p < HW && alpha[p] > alpha_th) {
+        v[1] = 1.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[0] += fabsf(gt[(size_t)c * HW + p] - img[(size_t)c * HW + p]);
+        const float dp = d[p], gp = gd[p];
+        if (gp > 0.001f && dp > 0.001f) {
+            const float diff = logf(dp) - logf(gp);
+            v[2] = diff; v[3] = diff * diff; v[4] = 1.f;
+        }
+    }
+    __shared__ float red[4][5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const float t = wave_sum(v[i]);
+        if (lane == 0) red[wave][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void refine_loss_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt, const float* __restrict__ d,
+                                                              const float* __restrict__ gd, const float* __restrict__ alpha, float alpha_th, int HW,
+                                                              const float* __restrict__ coef, float* __restrict__ g_img, float* __restrict__ g_d) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const bool a = alpha[p] > alpha_th;
+    const float c_rgb = coef[0], c_var = coef[1], mean = coef[2];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float e = img[(size_t)c * HW + p] - gt[(size_t)c * HW + p];
+        g_img[(size_t)c * HW + p] = !a ? 0.f : (e > 0.f ? c_rgb : (e < 0.f ? -c_rgb : 0.f));
+    }
+    const float dp = d[p], gp = gd[p];
+    g_d[p] = (a && gp > 0.001f && dp > 0.001f) ? c_var * 2.f * (logf(dp) - logf(gp) - mean) / dp : 0.f;
+}
+
 }  // namespace
 
 static int gs_fill_cam(GsCam& cam, const float* view, const float* proj, const float* campos, int W, int H, float tanx, float tany, float ks,
@@ -1021,5 +1066,22 @@ extern "C" int cut3r_pixel_loss_backward(const float* img, const float* gt_img, 
     if (!img || !gt_img || !depth || !gt_depth || !gt_normal || !coef || !grad_img || !grad_depth || H < 3 || W < 3) return CUT3R_ERR_ARG;
     hipLaunchKernelGGL(pixel_loss_bwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, img, gt_img, depth, gt_depth, gt_normal, H,
                        W, PixCam{fx, fy, cx, cy}, coef, grad_img, grad_depth);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_refine_loss_forward(const float* img, const float* gt_img, const float* depth, const float* gt_depth, const float* alpha,
+                                         float alpha_th, int H, int W, float* sums, void* stream) {
+    if (!img || !gt_img || !depth || !gt_depth || !alpha || !sums || H <= 0 || W <= 0) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, 5 * sizeof(float), s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    hipLaunchKernelGGL(refine_loss_fwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, img, gt_img, depth, gt_depth, alpha, alpha_th, H * W, sums);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_refine_loss_backward(const float* img, const float* gt_img, const float* depth, const float* gt_depth, const float* alpha,
+                                          float alpha_th, int H, int W, const float* coef, float* grad_img, float* grad_depth, void* stream) {
+    if (!img || !gt_img || !depth || !gt_depth || !alpha || !coef || !grad_img || !grad_depth || H <= 0 || W <= 0) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(refine_loss_bwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, img, gt_img, depth, gt_depth, alpha,
+                       alpha_th, H * W, coef, grad_img, grad_depth);
     return cut3r_check_launch();
 }

@@ -336,3 +336,39 @@ def pixel_losses(image, depth, gt_image, gt_depth, gt_normal, K, w_rgb, w_depth,
         raise RuntimeError("pixel_losses: tensors must live on the GPU")
     return _PixelLosses.apply(image, depth, gt_image.contiguous(), gt_depth.contiguous(), gt_normal.contiguous(), tuple(float(v) for v in K),
                               float(w_rgb), float(w_depth), float(w_normal))
+
+
+class _RefineLosses(torch.autograd.Function):
+    """(ratio * rgb, ratio * log-depth variance, ratio) of the pose refinement on `cut3r_refine_loss_forward/backward`"""
+
+    @staticmethod
+    def forward(ctx, image, depth, gt_image, gt_depth, alpha, alpha_th):
+        img, d, a = image.detach().contiguous().float(), depth.detach().contiguous().float(), alpha.detach().contiguous().float()
+        H, W = img.shape[-2:]
+        sums = torch.empty(5, dtype=torch.float32, device=img.device)
+        check(_lib.load().cut3r_refine_loss_forward(_p(img), _p(gt_image), _p(d), _p(gt_depth), _p(a), float(alpha_th), H, W, _p(sums), _s()),
+              "refine_loss_forward")
+        na, nm = sums[1].clamp_min(1.0), sums[4].clamp_min(1.0)
+        ratio = sums[1] / (H * W)
+        mean = sums[2] / nm
+        ctx.save_for_backward(img, d, gt_image, gt_depth, a, ratio, na, nm, mean)
+        ctx.alpha_th = float(alpha_th)
+        return ratio * sums[0] / (3 * na), ratio * (sums[3] / nm - mean * mean), ratio
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_var, g_ratio):
+        img, d, gt_image, gt_depth, a, ratio, na, nm, mean = ctx.saved_tensors
+        H, W = img.shape[-2:]
+        coef = torch.stack([g_rgb * ratio / (3 * na), g_var * ratio / nm, mean]).float().contiguous()
+        g_img, g_d = torch.empty_like(img), torch.empty_like(d)
+        check(_lib.load().cut3r_refine_loss_backward(_p(img), _p(gt_image), _p(d), _p(gt_depth), _p(a), ctx.alpha_th, H, W, _p(coef), _p(g_img), _p(g_d),
+                                                     _s()), "refine_loss_backward")
+        return g_img, g_d, None, None, None, None
+
+
+def refine_losses(image, depth, gt_image, gt_depth, alpha, alpha_th):
+    """hislam2/gs_backend_per_frame.py:240-262: with a = alpha > alpha_th (treated as constant) and ratio = |a| / HW returns
+    (ratio * mean_a |gt - image|, ratio * var_m (log depth - log gt_depth), ratio), m = a & depth > 0.001 & gt_depth > 0.001."""
+    if image.device.type != "cuda":
+        raise RuntimeError("refine_losses: tensors must live on the GPU")
+    return _RefineLosses.apply(image, depth, gt_image.contiguous(), gt_depth.contiguous(), alpha, float(alpha_th))

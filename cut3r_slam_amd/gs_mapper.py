@@ -23,7 +23,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from .gaussian_rasterizer import GaussianRasterizationSettings, GaussianRasterizer, distCUDA2, fused_ssim, pixel_losses
+from .gaussian_rasterizer import GaussianRasterizationSettings, GaussianRasterizer, distCUDA2, fused_ssim, pixel_losses, refine_losses
 from .lietorch import SE3, SO3
 
 SH_C0 = 0.28209479177387814
@@ -451,18 +451,10 @@ class GSMapper:
                 for v in views:
                     pkg = render(v, self.gaussians, self.background)
                     image, depth, alpha = pkg["render"], pkg["depth"], pkg["mask"]
-                    gt_depth = v.depth[None]
-                    amask = (alpha > alpha_th).detach()
-                    ratio = amask.sum() / amask.numel()
-                    dmask = ((gt_depth > 0.001) & (depth > 0.001) & amask).detach()
-                    # masked means written as sums (no boolean indexing: that would read the count back to the host every iteration)
-                    rgb = (torch.abs(v.original_image - image) * amask).sum() / (3 * amask.sum()).clamp_min(1)
-                    nd = dmask.sum().clamp_min(1)
-                    diff = torch.where(dmask, torch.log(torch.where(dmask, depth, torch.ones_like(depth))) -
-                                       torch.log(torch.where(dmask, gt_depth, torch.ones_like(gt_depth))), torch.zeros_like(depth))
-                    dl = (diff ** 2).sum() / nd - (diff.sum() / nd) ** 2
+                    # :240-262 -- colour L1 over the covered pixels, variance of the log-depth difference, both weighted by the covered share
+                    r_rgb, r_var, ratio = refine_losses(image, depth, v.original_image, v.depth, alpha, alpha_th)
                     pl = (v.cam_rot_delta ** 2).sum() + (v.cam_trans_delta ** 2).sum()
-                    rgb_all, depth_all, pose_all = rgb_all + ratio * rgb, depth_all + ratio * dl, pose_all + (2 - ratio) * pl
+                    rgb_all, depth_all, pose_all = rgb_all + r_rgb, depth_all + r_var, pose_all + (2 - ratio) * pl
                 loss = (5 * rgb_all + depth_all + 0.05 * pose_all) / B
                 opt.zero_grad(set_to_none=True)
                 self.gaussians.zero_grad()

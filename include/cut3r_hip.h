@@ -381,6 +381,13 @@ int cut3r_pixel_loss_forward(const float* img, const float* gt_img, const float*
 int cut3r_pixel_loss_backward(const float* img, const float* gt_img, const float* depth, const float* gt_depth, const float* gt_normal, int H,
                               int W, float fx, float fy, float cx, float cy, const float* coef, float* grad_img, float* grad_depth,
                               void* stream);
+/* the pose-refinement loss terms (hislam2/gs_backend_per_frame.py:240-262) in one pass: a = alpha > alpha_th, m = a and both depths >
+ * 0.001.  forward: sums[5] = {sum_a |gt - img|, |a|, sum_m diff, sum_m diff^2, |m|}, diff = log d - log gt_d.  backward: coef[3] (device)
+ * = {c_rgb, c_var, mean diff} -> grad_img = c_rgb sign(img - gt) on a, grad_depth = 2 c_var (diff - mean) / d on m. */
+int cut3r_refine_loss_forward(const float* img, const float* gt_img, const float* depth, const float* gt_depth, const float* alpha,
+                              float alpha_th, int H, int W, float* sums, void* stream);
+int cut3r_refine_loss_backward(const float* img, const float* gt_img, const float* depth, const float* gt_depth, const float* alpha,
+                               float alpha_th, int H, int W, const float* coef, float* grad_img, float* grad_depth, void* stream);
 
 #ifdef __cplusplus
 }

@@ -294,3 +294,32 @@ def test_fused_pixel_losses_match_the_tensor_formulation(H, W):
     err = np.abs(gd - rd)
     print(f"[gs] pixel losses: value {float(got.detach()):.6f} vs {float(ref.detach()):.6f}, depth-gradient max |err| {err.max():.2e} (scale {np.abs(rd).max():.2e})")
     assert err.max() < 2e-4 * np.abs(rd).max()
+
+
+def test_fused_refine_losses_match_the_tensor_formulation():
+    """cut3r_refine_loss_forward/backward vs the tensor formulation of the pose-refinement terms (gs_backend_per_frame.py:240-262), fp64"""
+    from cut3r_slam_amd.gaussian_rasterizer import refine_losses
+    H, W = 41, 53
+    g = torch.Generator().manual_seed(9)
+    image, gt_image = torch.rand(3, H, W, generator=g, dtype=torch.float64), torch.rand(3, H, W, generator=g, dtype=torch.float64)
+    gt_depth = 1.5 + torch.rand(H, W, generator=g, dtype=torch.float64)
+    gt_depth[2:5, 3:9] = 0.0
+    depth = (gt_depth * (1 + 0.1 * torch.randn(H, W, generator=g, dtype=torch.float64))).clamp_min(0.0)[None]
+    depth[0, 20:23, 10:14] = 0.0
+    alpha = torch.rand(1, H, W, generator=g, dtype=torch.float64)
+    th = 0.4
+    im64, d64 = image.clone().requires_grad_(True), depth.clone().requires_grad_(True)
+    amask = alpha > th
+    ratio = amask.sum() / amask.numel()
+    dmask = (gt_depth[None] > 0.001) & (d64 > 0.001) & amask
+    rgb = torch.abs((gt_image - im64)[:, amask[0]]).mean()
+    diff = torch.log(d64[dmask]) - torch.log(gt_depth[None][dmask])
+    var = (diff ** 2).mean() - diff.mean() ** 2
+    (5 * ratio * rgb + ratio * var).backward()
+    f = lambda t: t.float().to(DEV)
+    im, dd = f(image).requires_grad_(True), f(depth).requires_grad_(True)
+    r_rgb, r_var, r = refine_losses(im, dd, f(gt_image), f(gt_depth), f(alpha), th)
+    (5 * r_rgb + r_var).backward()
+    assert abs(float(r) - float(ratio)) < 1e-6 and abs(float(r_rgb.detach()) - float(ratio * rgb)) < 1e-6 and abs(float(r_var.detach()) - float(ratio * var)) < 1e-6
+    np.testing.assert_allclose(im.grad.cpu().numpy(), im64.grad.numpy(), atol=1e-9)
+    np.testing.assert_allclose(dd.grad.cpu().numpy(), d64.grad.numpy(), atol=2e-9, rtol=2e-4)
