@@ -320,6 +320,7 @@ def test_fused_refine_losses_match_the_tensor_formulation():
     im, dd = f(image).requires_grad_(True), f(depth).requires_grad_(True)
     r_rgb, r_var, r = refine_losses(im, dd, f(gt_image), f(gt_depth), f(alpha), th)
     (5 * r_rgb + r_var).backward()
-    assert abs(float(r) - float(ratio)) < 1e-6 and abs(float(r_rgb.detach()) - float(ratio * rgb)) < 1e-6 and abs(float(r_var.detach()) - float(ratio * var)) < 1e-6
+    assert (abs(float(r.detach()) - float(ratio)) < 1e-6 and abs(float(r_rgb.detach()) - float((ratio * rgb).detach())) < 1e-6
+            and abs(float(r_var.detach()) - float((ratio * var).detach())) < 1e-6)
     np.testing.assert_allclose(im.grad.cpu().numpy(), im64.grad.numpy(), atol=1e-9)
     np.testing.assert_allclose(dd.grad.cpu().numpy(), d64.grad.numpy(), atol=2e-9, rtol=2e-4)
