@@ -9,6 +9,7 @@ rasteriser.  Mirrors, with the same names, argument meaning
   GSMapper.pose_refine   hislam2/gs_backend_per_frame.py:202-326
   GSMapper.optimization  hislam2/gs_backend_per_frame.py:451-587
   GSMapper.add_new_view  hislam2/gs_backend_per_frame.py:87-121
+  GSMapper.gaussian_reinit, finalize, save / load, eval_rendering_kf   :865-944, :1067-1102
   GSMapper.global_BA     hislam2/gs_backend_per_frame.py:946-1062 (all keyframes, poses and Gaussians together, one random keyframe per
                          iteration, densification / opacity-reset / learning-rate schedule)
 
@@ -613,6 +614,55 @@ class GSMapper:
                         self.gaussians.lr[0, 0:3] = math.exp(math.log(op["position_lr_init"]) * (1 - t) + math.log(op["position_lr_final"]) * t)
             opt.step()
             update_pose(v)
+            last = loss.detach()
+        self.gaussians.zero_grad()
+        return float(last) if last is not None else None
+
+    def reset(self):
+        """gs_backend_per_frame.py:79-85: forget the map (the keyframe views stay)"""
+        self.iteration_count = 0
+        self.current_window, self.initialized = [], False
+        self.gaussians = GaussianMap(self.config["opt_params"], self.device)
+
+    def gaussian_reinit(self, rgbs, pointmaps, iteration_total=3000, seed=0):
+        """gs_backend_per_frame.py:865-944 (Hi2.terminate(gaussian_retrain=True)): a fresh map from every keyframe's stride-2 pointmap
+        (rgbs u8 [n,3,H,W], pointmaps [n,h,w,3] world), then `iteration_total` single-view iterations with fixed poses -- colour, inverse
+        depth and the depth-normal term -- densifying every Training.gaussian_update_every iterations after the first 1000"""
+        import random
+        self.reset()
+        self.initialized = True
+        pm = torch.as_tensor(pointmaps, dtype=torch.float32, device=self.device)
+        h1, w1 = pm.shape[1:3]
+        rgb = F.interpolate(torch.as_tensor(rgbs).to(self.device).float() / 255.0, size=(h1, w1), mode="bilinear", align_corners=False)
+        self.gaussians.extend_from_pcd_seq(submap_idx=0, rgb=rgb[..., ::2, ::2].permute(0, 2, 3, 1), pointmap=pm[:, ::2, ::2])
+        views = list(self.viewpoints.values())
+        if not views or len(self.gaussians) == 0:
+            return None
+        rng = random.Random(seed)
+        update_every = self.config["Training"].get("gaussian_update_every", 200)
+        last = None
+        for iteration in range(iteration_total):
+            v = views[rng.randint(0, len(views) - 1)]
+            pkg = render(v, self.gaussians, self.background)
+            image, depth = pkg["render"], pkg["depth"]
+            gcache = getattr(v, "_gt_normal", None)
+            if gcache is None or gcache[0] is not v.depth:
+                gcache = v._gt_normal = (v.depth, depth_to_normal(v, v.depth[None]).detach().contiguous())
+            # (the reference averages the normal term over all pixels here, not over the depth mask: where either depth is missing the
+            #  term is the constant 1 -- same gradient as the masked mean up to the normaliser; kept masked, as in optimization())
+            loss = (pixel_losses(image, depth, v.original_image, v.depth, gcache[1], (v.fx, v.fy, v.cx, v.cy), 0.8, self.lambda_depth,
+                                 self.lambda_normal) + 0.2 * (1.0 - ssim(image, v.original_image)))
+            self.gaussians.zero_grad()
+            loss.backward()
+            with torch.no_grad():
+                if iteration > 1000:
+                    vis = pkg["visibility_filter"]
+                    self.gaussians.max_radii2D = torch.max(self.gaussians.max_radii2D, pkg["radii"].float() * vis)
+                    self.gaussians.add_densification_stats(pkg["viewspace_points"].grad, vis)
+                self.gaussians.step()
+                if iteration > 1000 and (iteration + 1) % update_every == 0:
+                    self.gaussians.densify_and_prune(self.config["opt_params"]["densify_grad_threshold"], self.gaussian_th, self.gaussian_extent,
+                                                     self.size_threshold)
             last = loss.detach()
         self.gaussians.zero_grad()
         return float(last) if last is not None else None

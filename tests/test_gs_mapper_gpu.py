@@ -138,6 +138,19 @@ def test_mapping_from_keyframes_reaches_the_observations():
     print(f"[gs mapper] global BA: loss {ba:.4f}, PSNR {after_ba:.2f} dB, {n_before} -> {len(mapper.gaussians)} Gaussians")
     assert ba is not None and np.isfinite(ba) and after_ba > after - 3.0
     assert mapper.global_pose_refine(iters=1) is not None
+    # Gaussian re-training from the keyframes' pointmaps (gs_backend_per_frame.py:865-944): a fresh map reaches the observations again
+    ys, xs = torch.meshgrid(torch.arange(H, device=DEV).float(), torch.arange(W, device=DEV).float(), indexing="ij")
+    pms = []
+    for k in range(3):
+        d = obs[k][1]
+        T = torch.inverse(GM.get_pose(mapper.viewpoints[k])).detach()
+        pc = torch.stack([(xs - CX) / FX * d, (ys - CY) / FY * d, d], -1)
+        pms.append(pc @ T[:3, :3].T + T[:3, 3])
+    rgbs = torch.stack([(obs[k][0] * 255).round().to(torch.uint8) for k in range(3)])
+    mapper.gaussian_reinit(rgbs, torch.stack(pms), iteration_total=150)
+    ev2 = mapper.eval_rendering_kf()
+    print(f"[gs mapper] re-training: {len(mapper.gaussians)} Gaussians, PSNR {ev2['mean_psnr']:.2f} dB")
+    assert ev2["mean_psnr"] > 25.0
     traj = mapper.trajectory()
     assert traj.shape == (3, 4, 4) and torch.isfinite(traj).all()
     # evaluation and checkpoint round trip (gs_backend_per_frame.py:1088-1102)
