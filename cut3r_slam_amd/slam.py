@@ -134,10 +134,11 @@ class Cut3rSlam:
                     on_frame(t_start + i, out)
 
     @torch.no_grad()
-    def terminate(self, add_kf=False, gap=30, finalize_iters=None):
+    def terminate(self, add_kf=False, gap=30, finalize_iters=None, gaussian_retrain=False, retrain_iters=10000):
         """hi2.py:152-229.  With the Gaussian mapper attached (`self.mapper`) the extra views go to `mapper.add_new_view`, the mapper
         finalises (`GSMapper.finalize`: a global BA of `finalize_iters` iterations, default the configured position_lr_max_steps as the
-        reference's `max_steps`; 0 skips it) and its poses are written back (hi2.py:214-216).  With add_kf (demo_s.py:171 passes True) every pair of consecutive
+        reference's `max_steps`; 0 skips it) and its poses are written back (hi2.py:214-216); `gaussian_retrain` rebuilds the map from all
+        keyframes first (hi2.py:155-170).  With add_kf (demo_s.py:171 passes True) every pair of consecutive
         keyframes more than `gap` frames apart gets ONE extra view at the middle frame: the kept full-resolution frame is resized
         to the tracking resolution (bilinear, align_corners=False, hi2.py:198) and relocalised against the earlier keyframe by a
         2-view inference (TrackFrontend.predict, track_frontend.py:102-162).  The reference hands these views to
@@ -146,6 +147,11 @@ class Cut3rSlam:
         kf = self.keyframes
         last = kf.counter.value
         views = []
+        if gaussian_retrain and self.mapper is not None and last > 1:        # hi2.py:155-170: a fresh map from every keyframe's pointmap
+            n = last - 1
+            pms = kf.submap_ds[:(n + 4) // 5, :-1].flatten(0, 1)[:n]
+            with torch.enable_grad():
+                self.mapper.gaussian_reinit(kf.image[:n], pms, iteration_total=retrain_iters)
         if add_kf:
             if not self.images:
                 raise RuntimeError("terminate(add_kf=True) needs the frames: set slam.keep_images = True before run()")

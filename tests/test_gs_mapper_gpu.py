@@ -292,7 +292,7 @@ def test_slam_loop_with_the_mapper_attached():
     assert torch.isfinite(slam.keyframes.pose[:nkf - 1]).all() and torch.isfinite(slam.mapper.trajectory()).all()
     # hi2.py:152-229: closing global BA of the mapper, its poses written back into the keyframe table
     before = slam.keyframes.pose[:nkf - 1].clone()
-    poses, _ = slam.terminate(add_kf=False, finalize_iters=12)
+    poses, _ = slam.terminate(add_kf=False, finalize_iters=12, gaussian_retrain=True, retrain_iters=8)
     assert np.isfinite(poses[:nkf - 1]).all() and not np.array_equal(poses[:nkf - 1], before.numpy())
     print(f"[gs mapper] slam loop: {nkf} keyframes, {len(calls)} windows handed over, {len(slam.mapper.viewpoints)} mapper views, "
           f"{len(slam.mapper.gaussians)} Gaussians")
