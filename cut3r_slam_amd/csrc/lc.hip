@@ -28,6 +28,27 @@ DEVINL void apply34(const float* __restrict__ T, float x, float y, float z, floa
 }
 DEVINL float sgn(float r) { return r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f); }
 
+// 25 sums over the 64 lanes as a transposing butterfly (each step a lane keeps half of its slots and hands the other half to its
+// partner: 16 + 8 + 4 + 2 + 1 + 1 exchanges instead of 25 x 6); fixed order, so the result is deterministic.  acc has LC_ROW >= 25 slots.
+DEVINL void lc_wave_reduce25(float* acc, int lane, float* out) {
+    float r[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) r[k] = k < 25 ? acc[k] : 0.f;
+#define LC_BFLY(HALF, BIT)                                                                  \
+    {                                                                                       \
+        const bool up = (lane & BIT) != 0;                                                  \
+        _Pragma("unroll") for (int k = 0; k < HALF; k++) {                                  \
+            const float send = up ? r[k] : r[k + HALF], keep = up ? r[k + HALF] : r[k];     \
+            r[k] = keep + __shfl_xor(send, BIT);                                            \
+        }                                                                                   \
+    }
+    LC_BFLY(16, 1) LC_BFLY(8, 2) LC_BFLY(4, 4) LC_BFLY(2, 8) LC_BFLY(1, 16)
+#undef LC_BFLY
+    const float total = r[0] + __shfl_xor(r[0], 32);
+    const int slot = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+    if (lane < 32 && slot < 25) out[slot] = total;
+}
+
 // pair p in [0, B-2]: a = T_p * last_p, c = T_{p+1} * first_{p+1} (masked);  pair B-1: a = T_{B-1} * cur, c = cur_lc (fixed)
 __global__ __launch_bounds__(LC_BLOCK) void lc_accum_kernel(const float* __restrict__ first, const float* __restrict__ last,
                                                             long long sub_stride, const unsigned char* __restrict__ mask,
@@ -70,11 +91,7 @@ __global__ __launch_bounds__(LC_BLOCK) void lc_accum_kernel(const float* __restr
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 25; k++) {
-        const float v = wave_sum(acc[k]);
-        if (lane == 0) red[wave][k] = v;
-    }
+    lc_wave_reduce25(acc, lane, red[wave]);
     __syncthreads();
     if (threadIdx.x < 25) {
         const int k = threadIdx.x;
@@ -191,11 +208,7 @@ __global__ __launch_bounds__(LC_BLOCK) void lc_terms_accum_kernel(const LcTerm* 
         acc[20] -= s2 * cx; acc[21] -= s2 * cy; acc[22] -= s2 * cz; acc[23] -= s2;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 25; k++) {
-        const float v = wave_sum(acc[k]);
-        if (lane == 0) red[wave][k] = v;
-    }
+    lc_wave_reduce25(acc, lane, red[wave]);
     __syncthreads();
     if (threadIdx.x < 25) {
         const int k = threadIdx.x;
