@@ -313,7 +313,7 @@ def test_exposure_compensation_absorbs_a_gain_change():
     mapper.gaussians.lr[:, 3:6] = 0.0                                     # keep the map's colours fixed: only the exposure can explain the change
     first = mapper.optimization(1, optimize_pose=True, current_window=[0])
     last = mapper.optimization(60, optimize_pose=True, current_window=[0])
-    gain = float(torch.diagonal(mapper.viewpoints[0].exposure_a).mean())
+    gain = float(torch.diagonal(mapper.viewpoints[0].exposure_a.detach()).mean())
     print(f"[gs mapper] exposure: loss {first:.4f} -> {last:.4f}, mean diagonal gain {gain:.3f}")
     assert last < 0.7 * first and 0.8 < gain < 0.95
     assert torch.equal(truth.p["f_dc"].detach(), colours0)
