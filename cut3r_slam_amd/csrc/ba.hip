@@ -86,6 +86,48 @@ __global__ __launch_bounds__(256) void corr_index_bwd_kernel(const float* __rest
 constexpr int BA_BLOCK = 256;
 constexpr int BA_HROW = 120;        // Hii(36) Hij(36) Hjj(36) vi(6) vj(6)   (Hji = Hij^T)
 
+// the same for the 42 sums of a Schur block (64 slots: 32 + 16 + 8 + 4 + 2 + 1 exchanges; one slot per lane at the end)
+DEVINL void ba_wave_reduce42(float* acc, int lane, float* out) {
+    float r[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) r[k] = k < 42 ? acc[k] : 0.f;
+#define BA_BFLY(HALF, BIT)                                                                  \
+    {                                                                                       \
+        const bool up = (lane & BIT) != 0;                                                  \
+        _Pragma("unroll") for (int k = 0; k < HALF; k++) {                                  \
+            const float send = up ? r[k] : r[k + HALF], keep = up ? r[k + HALF] : r[k];     \
+            r[k] = keep + __shfl_xor(send, BIT);                                            \
+        }                                                                                   \
+    }
+    BA_BFLY(32, 1) BA_BFLY(16, 2) BA_BFLY(8, 4) BA_BFLY(4, 8) BA_BFLY(2, 16) BA_BFLY(1, 32)
+#undef BA_BFLY
+    const int slot = ((lane & 1) << 5) | ((lane & 2) << 3) | ((lane & 4) << 1) | ((lane & 8) >> 1) | ((lane & 16) >> 3) | ((lane & 32) >> 5);
+    if (slot < 42) out[slot] = r[0];
+}
+
+// the 120 per-wave sums of an edge's Hessian blocks as ONE transposing butterfly over 128 slots (at each of six steps a lane keeps half
+// of its slots and hands the other half to its partner: 64 + 32 + 16 + 8 + 4 + 2 = 126 exchanges instead of 120 x 6 shuffle-adds);
+// every lane ends with the wave totals of two slots.  Fixed order: deterministic.
+DEVINL void ba_wave_reduce120(float* loc, int lane, float* out) {
+    float r[128];
+#pragma unroll
+    for (int k = 0; k < 128; k++) r[k] = k < BA_HROW ? loc[k] : 0.f;
+#define BA_BFLY(HALF, BIT)                                                                  \
+    {                                                                                       \
+        const bool up = (lane & BIT) != 0;                                                  \
+        _Pragma("unroll") for (int k = 0; k < HALF; k++) {                                  \
+            const float send = up ? r[k] : r[k + HALF], keep = up ? r[k + HALF] : r[k];     \
+            r[k] = keep + __shfl_xor(send, BIT);                                            \
+        }                                                                                   \
+    }
+    BA_BFLY(64, 1) BA_BFLY(32, 2) BA_BFLY(16, 4) BA_BFLY(8, 8) BA_BFLY(4, 16) BA_BFLY(2, 32)
+#undef BA_BFLY
+    const int slot = ((lane & 1) << 6) | ((lane & 2) << 4) | ((lane & 4) << 2) | (lane & 8) | ((lane & 16) >> 2) | ((lane & 32) >> 4);
+    if (slot < BA_HROW) out[slot] = r[0];
+    if (slot + 1 < BA_HROW) out[slot + 1] = r[1];
+}
+
+
 struct BaGeom {
     int P, ht, wd, N, M, fixedp;
 };
@@ -184,11 +226,7 @@ __global__ __launch_bounds__(BA_BLOCK) void ba_edge_kernel(const float* __restri
             loc[108 + a] = w[0] * Ji[0][a] * r[0] + w[1] * Ji[1][a] * r[1];
             loc[114 + a] = w[0] * Jj[0][a] * r[0] + w[1] * Jj[1][a] * r[1];
         }
-#pragma unroll
-        for (int c = 0; c < BA_HROW; c++) {
-            const float sv = wave_sum(loc[c]);
-            if (lane == 0) red[wave][c] = sv;
-        }
+        ba_wave_reduce120(loc, lane, red[wave]);
         __syncthreads();
         if (threadIdx.x < BA_HROW)
             Hpart[((size_t)e * gridDim.x + blockIdx.x) * BA_HROW + threadIdx.x] =
@@ -274,11 +312,7 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
             }
         }
     }
-#pragma unroll
-    for (int c = 0; c < 42; c++) {
-        const float sv = wave_sum(acc[c]);
-        if (lane == 0) red[wave][c] = sv;
-    }
+    ba_wave_reduce42(acc, lane, red[wave]);
     __syncthreads();
     const int n = Pf * 6;
     if (threadIdx.x < 36) {
@@ -293,54 +327,65 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
 }
 
 // in-LDS Cholesky (lower) of S [n,n] (n <= 192) and solve S x = b.  flag[0] = 1 on a non-positive pivot (x = 0).
+// One thread per ROW (n <= 192 < 256): per column two barriers -- every thread takes the pivot from LDS itself, scales its own
+// element of the column into a shared vector, then updates its own row against that vector (rows padded to n + 1 floats: threads
+// walking down a column hit 32 different banks).  No index arithmetic in the update (the earlier element-cyclic form spent its
+// time in idx / rem, idx % rem and three barriers per column: 587 us at n = 132, now see tools/bench_ba.py).  The two triangular
+// solves keep y[i] in the owning thread's register: one barrier per step.
 constexpr int CHOL_MAXN = 192;
 __global__ __launch_bounds__(256) void ba_chol_solve_kernel(const float* __restrict__ S, const float* __restrict__ b, int n,
                                                             float* __restrict__ x, float* __restrict__ Lout, int* __restrict__ flag) {
     extern __shared__ float sm[];
-    float* A = sm;                 // n*n
-    float* y = sm + n * n;         // n
+    const int ld = n + 1;
+    float* A = sm;                 // n rows of ld floats
+    float* col = sm + n * ld;      // n: the scaled column of the current step / the solved entries of the triangular solves
     __shared__ int bad;
     const int tid = threadIdx.x;
     if (tid == 0) bad = 0;
-    for (int i = tid; i < n * n; i += 256) A[i] = S[i];
-    for (int i = tid; i < n; i += 256) y[i] = b[i];
+    for (int i = tid; i < n * n; i += 256) { const int r = i / n, c = i - r * n; A[r * ld + c] = S[i]; }
     __syncthreads();
+    float* row = A + tid * ld;     // (only threads tid < n touch it)
     for (int k = 0; k < n; k++) {
-        if (tid == 0) {
-            const float d = A[k * n + k];
-            if (!(d > 0.f)) bad = 1;
-            A[k * n + k] = sqrtf(d > 0.f ? d : 1.f);
-        }
+        const float d = A[k * ld + k];                                     // final since the barrier that ended step k - 1
+        const bool okp = d > 0.f;
+        const float dk = sqrtf(okp ? d : 1.f);
+        if (tid == k) { if (!okp) bad = 1; }
+        float lik = 0.f;
+        if (tid > k && tid < n) { lik = row[k] / dk; col[tid] = lik; }
         __syncthreads();
-        const float dk = A[k * n + k];
-        for (int i = k + 1 + tid; i < n; i += 256) A[i * n + k] /= dk;
-        __syncthreads();
-        const int rem = n - k - 1;
-        for (int idx = tid; idx < rem * rem; idx += 256) {
-            const int i = k + 1 + idx / rem, j = k + 1 + idx % rem;
-            if (j <= i) A[i * n + j] -= A[i * n + k] * A[j * n + k];
+        if (tid == k) row[k] = dk;
+        if (tid > k && tid < n) {
+            row[k] = lik;
+            int j = k + 1;
+            for (; j + 7 <= tid; j += 8) {                               // eight independent LDS round trips in flight (row / col may alias
+                float r[8], c[8];                                          // as far as the compiler knows: read everything first)
+#pragma unroll
+                for (int u = 0; u < 8; u++) { r[u] = row[j + u]; c[u] = col[j + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) row[j + u] = fmaf(-lik, c[u], r[u]);
+            }
+            for (; j <= tid; j++) row[j] = fmaf(-lik, col[j], row[j]);
         }
         __syncthreads();
     }
-    // forward: L y = b
+    // forward: L y = b (y[i] in thread i's register), then backward: L^T x = y
+    float yi = tid < n ? b[tid] : 0.f;
     for (int k = 0; k < n; k++) {
-        if (tid == 0) y[k] /= A[k * n + k];
+        if (tid == k) col[k] = yi / row[k];
         __syncthreads();
-        const float yk = y[k];
-        for (int i = k + 1 + tid; i < n; i += 256) y[i] -= A[i * n + k] * yk;
-        __syncthreads();
+        if (tid > k && tid < n) yi = fmaf(-row[k], col[k], yi);
     }
-    // backward: L^T x = y
+    if (tid < n) yi = col[tid];
+    __syncthreads();
     for (int k = n - 1; k >= 0; k--) {
-        if (tid == 0) y[k] /= A[k * n + k];
+        if (tid == k) col[k] = yi / row[k];
         __syncthreads();
-        const float xk = y[k];
-        for (int i = tid; i < k; i += 256) y[i] -= A[k * n + i] * xk;
-        __syncthreads();
+        if (tid < k) yi = fmaf(-A[k * ld + tid], col[k], yi);
     }
-    for (int i = tid; i < n; i += 256) x[i] = bad ? 0.f : y[i];
+    __syncthreads();
+    if (tid < n) x[tid] = bad ? 0.f : col[tid];
     if (Lout)
-        for (int i = tid; i < n * n; i += 256) { const int r = i / n, c = i % n; Lout[i] = (c <= r) ? A[i] : 0.f; }
+        for (int i = tid; i < n * n; i += 256) { const int r = i / n, c = i % n; Lout[i] = (c <= r) ? A[r * ld + c] : 0.f; }
     if (tid == 0) flag[0] = bad;
 }
 
@@ -598,7 +643,7 @@ extern "C" int cut3r_ba_solve(const float* S, const float* vS, const float* hdia
     if (!S || !vS || !hdiag || !scratch || !dx || !flag || n <= 0 || n > CHOL_MAXN) return CUT3R_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(ba_damp_kernel, dim3((n * n + 255) / 256), dim3(256), 0, s, S, hdiag, n, ep, lm, scratch);
-    const size_t chol_lds = sizeof(float) * ((size_t)n * n + n);
+    const size_t chol_lds = sizeof(float) * ((size_t)n * (n + 1) + n);
     if (hipFuncSetAttribute((const void*)ba_chol_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds) != hipSuccess)
         return CUT3R_ERR_LAUNCH;
     hipLaunchKernelGGL(ba_chol_solve_kernel, dim3(1), dim3(256), chol_lds, s, scratch, vS, n, dx, (float*)nullptr, flag);
