@@ -327,63 +327,159 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
 }
 
 // in-LDS Cholesky (lower) of S [n,n] (n <= 192) and solve S x = b.  flag[0] = 1 on a non-positive pivot (x = 0).
-// One thread per ROW (n <= 192 < 256): per column two barriers -- every thread takes the pivot from LDS itself, scales its own
-// element of the column into a shared vector, then updates its own row against that vector (rows padded to n + 1 floats: threads
-// walking down a column hit 32 different banks).  No index arithmetic in the update (the earlier element-cyclic form spent its
-// time in idx / rem, idx % rem and three barriers per column: 587 us at n = 132, now see tools/bench_ba.py).  The two triangular
-// solves keep y[i] in the owning thread's register: one barrier per step.
+// Blocked, one thread per ROW, panels of CB = 8 columns, three barriers per PANEL:
+//   * every thread factors the panel's 8x8 diagonal block itself, in registers (broadcast LDS reads, ~150 flops): nobody waits for
+//     a designated thread and no barrier separates it from the next stage;
+//   * a thread below the panel solves its own 8 panel entries against that block (registers), the panel rows store theirs;  -- barrier
+//   * every thread updates its own row of the trailing matrix with the 8 panel columns at once (the partner row's 8 entries are a
+//     broadcast read; rows padded to n + 1 floats so threads walking down a column hit different banks).                -- barrier
+// The triangular solves are blocked the same way (the panel's 8 unknowns are solved redundantly by every thread).
+// History (n = 132, tools/bench_ba.py): element-cyclic with idx / rem arithmetic and three barriers per column 587 us; one thread per row,
+// column by column 242 us; this form: see profiles.
 constexpr int CHOL_MAXN = 192;
+constexpr int CB = 8;
 __global__ __launch_bounds__(256) void ba_chol_solve_kernel(const float* __restrict__ S, const float* __restrict__ b, int n,
                                                             float* __restrict__ x, float* __restrict__ Lout, int* __restrict__ flag) {
     extern __shared__ float sm[];
     const int ld = n + 1;
     float* A = sm;                 // n rows of ld floats
-    float* col = sm + n * ld;      // n: the scaled column of the current step / the solved entries of the triangular solves
+    float* ys = sm + n * ld;       // n (+CB): right-hand side entries as the panels see them
+    float* xs = ys + n + CB;       // n (+CB): solved entries
     __shared__ int bad;
     const int tid = threadIdx.x;
     if (tid == 0) bad = 0;
     for (int i = tid; i < n * n; i += 256) { const int r = i / n, c = i - r * n; A[r * ld + c] = S[i]; }
     __syncthreads();
-    float* row = A + tid * ld;     // (only threads tid < n touch it)
-    for (int k = 0; k < n; k++) {
-        const float d = A[k * ld + k];                                     // final since the barrier that ended step k - 1
-        const bool okp = d > 0.f;
-        const float dk = sqrtf(okp ? d : 1.f);
-        if (tid == k) { if (!okp) bad = 1; }
-        float lik = 0.f;
-        if (tid > k && tid < n) { lik = row[k] / dk; col[tid] = lik; }
-        __syncthreads();
-        if (tid == k) row[k] = dk;
-        if (tid > k && tid < n) {
-            row[k] = lik;
-            int j = k + 1;
-            for (; j + 7 <= tid; j += 8) {                               // eight independent LDS round trips in flight (row / col may alias
-                float r[8], c[8];                                          // as far as the compiler knows: read everything first)
+    float* row = A + (tid < n ? tid : 0) * ld;
+    int mybad = 0;
+    for (int k0 = 0; k0 < n; k0 += CB) {
+        // ---- the diagonal block, in registers (entries beyond n: identity)
+        float D[CB][CB];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { r[u] = row[j + u]; c[u] = col[j + u]; }
+        for (int r = 0; r < CB; r++)
 #pragma unroll
-                for (int u = 0; u < 8; u++) row[j + u] = fmaf(-lik, c[u], r[u]);
+            for (int c = 0; c <= r; c++) D[r][c] = (k0 + r < n) ? A[(k0 + r) * ld + k0 + c] : (r == c ? 1.f : 0.f);
+#pragma unroll
+        for (int c = 0; c < CB; c++) {
+            const float d = D[c][c];
+            const bool okp = d > 0.f;
+            if (!okp) mybad = 1;
+            const float dc = sqrtf(okp ? d : 1.f);
+            D[c][c] = dc;
+#pragma unroll
+            for (int r = c + 1; r < CB; r++) D[r][c] = D[r][c] / dc;
+#pragma unroll
+            for (int r = c + 1; r < CB; r++)
+#pragma unroll
+                for (int c2 = c + 1; c2 <= r; c2++) D[r][c2] = fmaf(-D[r][c], D[c2][c], D[r][c2]);
+        }
+        // ---- panel entries of this thread's row
+        float a[CB];
+#pragma unroll
+        for (int c = 0; c < CB; c++) a[c] = 0.f;
+        const bool below = tid >= k0 + CB && tid < n;
+        if (below) {
+#pragma unroll
+            for (int c = 0; c < CB; c++) a[c] = row[k0 + c];
+#pragma unroll
+            for (int c = 0; c < CB; c++) {
+                float v = a[c];
+#pragma unroll
+                for (int c2 = 0; c2 < c; c2++) v = fmaf(-a[c2], D[c][c2], v);
+                a[c] = v / D[c][c];
             }
-            for (; j <= tid; j++) row[j] = fmaf(-lik, col[j], row[j]);
+        }
+        __syncthreads();                                                   // every thread has read the old diagonal block / its old panel entries
+        if (below) {
+#pragma unroll
+            for (int c = 0; c < CB; c++) row[k0 + c] = a[c];
+        }
+#pragma unroll
+        for (int r = 0; r < CB; r++)
+            if (tid == k0 + r && tid < n) {
+#pragma unroll
+                for (int c = 0; c <= r; c++) row[k0 + c] = D[r][c];
+            }
+        __syncthreads();                                                   // the panel columns are final
+        // ---- trailing update of this thread's row: columns k0 + CB .. tid
+        if (below) {
+            int j = k0 + CB;
+            for (; j + 3 <= tid; j += 4) {                                 // four columns at a time: all 36 LDS reads before the first write
+                float l[4][CB], acc[4];                                    // (row / A alias as far as the compiler knows)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    acc[u] = row[j + u];
+#pragma unroll
+                    for (int c = 0; c < CB; c++) l[u][c] = A[(j + u) * ld + k0 + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+#pragma unroll
+                    for (int c = 0; c < CB; c++) acc[u] = fmaf(-a[c], l[u][c], acc[u]);
+                    row[j + u] = acc[u];
+                }
+            }
+            for (; j <= tid; j++) {
+                const float* lj = A + j * ld + k0;
+                float acc = row[j];
+#pragma unroll
+                for (int c = 0; c < CB; c++) acc = fmaf(-a[c], lj[c], acc);
+                row[j] = acc;
+            }
         }
         __syncthreads();
     }
-    // forward: L y = b (y[i] in thread i's register), then backward: L^T x = y
+    if (mybad && tid == 0) bad = 1;                                        // (every thread saw the same pivots)
+    // ---- forward: L y = b, panel by panel; y[i] lives in thread i's register until its panel comes up
     float yi = tid < n ? b[tid] : 0.f;
-    for (int k = 0; k < n; k++) {
-        if (tid == k) col[k] = yi / row[k];
-        __syncthreads();
-        if (tid > k && tid < n) yi = fmaf(-row[k], col[k], yi);
-    }
-    if (tid < n) yi = col[tid];
+    for (int i = tid; i < n + CB; i += 256) { ys[i] = 0.f; xs[i] = 0.f; }
     __syncthreads();
-    for (int k = n - 1; k >= 0; k--) {
-        if (tid == k) col[k] = yi / row[k];
+    for (int k0 = 0; k0 < n; k0 += CB) {
+        if (tid >= k0 && tid < k0 + CB && tid < n) ys[tid] = yi;
         __syncthreads();
-        if (tid < k) yi = fmaf(-A[k * ld + tid], col[k], yi);
+        float z[CB];
+#pragma unroll
+        for (int c = 0; c < CB; c++) {                                     // the panel's unknowns, solved by every thread for itself
+            float v = ys[k0 + c];
+#pragma unroll
+            for (int c2 = 0; c2 < c; c2++) v = fmaf(-((k0 + c < n) ? A[(k0 + c) * ld + k0 + c2] : 0.f), z[c2], v);
+            z[c] = (k0 + c < n) ? v / A[(k0 + c) * ld + k0 + c] : 0.f;
+        }
+        if (tid >= k0 + CB && tid < n) {
+#pragma unroll
+            for (int c = 0; c < CB; c++) yi = fmaf(-row[k0 + c], z[c], yi);
+        }
+#pragma unroll
+        for (int c = 0; c < CB; c++)
+            if (tid == k0 + c && tid < n) { yi = z[c]; xs[tid] = z[c]; }
     }
     __syncthreads();
-    if (tid < n) x[tid] = bad ? 0.f : col[tid];
+    // ---- backward: L^T x = y, panels from the end; thread i accumulates  y_i - sum_{j > i's panel} L_ji x_j
+    if (tid < n) yi = xs[tid];
+    __syncthreads();
+    const int last0 = ((n - 1) / CB) * CB;
+    for (int k0 = last0; k0 >= 0; k0 -= CB) {
+        if (tid >= k0 && tid < k0 + CB && tid < n) ys[tid] = yi;
+        __syncthreads();
+        float z[CB];
+#pragma unroll
+        for (int c = CB - 1; c >= 0; c--) {
+            float v = ys[k0 + c];
+#pragma unroll
+            for (int c2 = CB - 1; c2 > c; c2--) v = fmaf(-((k0 + c2 < n) ? A[(k0 + c2) * ld + k0 + c] : 0.f), z[c2], v);
+            z[c] = (k0 + c < n) ? v / A[(k0 + c) * ld + k0 + c] : 0.f;
+        }
+        if (tid < k0) {
+#pragma unroll
+            for (int c = 0; c < CB; c++)
+                if (k0 + c < n) yi = fmaf(-A[(k0 + c) * ld + tid], z[c], yi);
+        }
+#pragma unroll
+        for (int c = 0; c < CB; c++)
+            if (tid == k0 + c && tid < n) xs[tid] = z[c];
+        __syncthreads();
+    }
+    if (tid < n) x[tid] = bad ? 0.f : xs[tid];
     if (Lout)
         for (int i = tid; i < n * n; i += 256) { const int r = i / n, c = i % n; Lout[i] = (c <= r) ? A[r * ld + c] : 0.f; }
     if (tid == 0) flag[0] = bad;
@@ -643,7 +739,7 @@ extern "C" int cut3r_ba_solve(const float* S, const float* vS, const float* hdia
     if (!S || !vS || !hdiag || !scratch || !dx || !flag || n <= 0 || n > CHOL_MAXN) return CUT3R_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(ba_damp_kernel, dim3((n * n + 255) / 256), dim3(256), 0, s, S, hdiag, n, ep, lm, scratch);
-    const size_t chol_lds = sizeof(float) * ((size_t)n * (n + 1) + n);
+    const size_t chol_lds = sizeof(float) * ((size_t)n * (n + 1) + 2 * (n + 8));
     if (hipFuncSetAttribute((const void*)ba_chol_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds) != hipSuccess)
         return CUT3R_ERR_LAUNCH;
     hipLaunchKernelGGL(ba_chol_solve_kernel, dim3(1), dim3(256), chol_lds, s, scratch, vS, n, dx, (float*)nullptr, flag);
