@@ -245,24 +245,36 @@ __global__ __launch_bounds__(BA_BLOCK) void ba_edge_kernel(const float* __restri
     (void)Pf;
 }
 
-// H [Pf,Pf,6,6], v [Pf,6] (zeroed by the launcher): one thread per (edge-independent) output element, edges in order
+// the pixel-block partial rows of every edge folded first (block order, one thread per edge and entry): Hedge [N, BA_HROW], written over
+// the first partial row of each edge
+__global__ __launch_bounds__(128) void ba_fold_edges_kernel(float* __restrict__ Hpart, int nblk) {
+    const int e = blockIdx.x, c = threadIdx.x;
+    if (c >= BA_HROW) return;
+    float* row = Hpart + (size_t)e * nblk * BA_HROW;
+    float s = 0.f;
+    for (int k = 0; k < nblk; k++) s += row[k * BA_HROW + c];
+    row[c] = s;                                                            // (thread c only ever reads column c)
+}
+
+// H [Pf,Pf,6,6], v [Pf,6]: one thread per output element, edges in order (the same sums in the same order as folding inside this loop)
 __global__ void ba_reduce_H_kernel(const float* __restrict__ Hpart, int nblk, const int* __restrict__ ii, const int* __restrict__ jj,
                                    int N, int Pf, int fixedp, float* __restrict__ H, float* __restrict__ v) {
     // block = one (p,q) pair [or the gradient row when q == Pf]; thread = one of the 36 (or 6) entries
     const int p = blockIdx.x, q = blockIdx.y, tix = threadIdx.x;
+    const size_t estride = (size_t)nblk * BA_HROW;
     if (q < Pf) {
         if (tix >= 36) return;
         const int a = tix / 6, b = tix % 6;
         float s = 0.f;
         for (int e = 0; e < N; e++) {
             const int i = ii[e] - fixedp, j = jj[e] - fixedp;
-            const float* row = Hpart + (size_t)e * nblk * BA_HROW;
+            const float* row = Hpart + (size_t)e * estride;
             float c = 0.f;
             bool hit = false;
-            if (i == p && i == q && i >= 0) { for (int k = 0; k < nblk; k++) c += row[k * BA_HROW + a * 6 + b]; hit = true; }
-            if (i == p && j == q && i >= 0 && j >= 0) { for (int k = 0; k < nblk; k++) c += row[k * BA_HROW + 36 + a * 6 + b]; hit = true; }
-            if (j == p && i == q && i >= 0 && j >= 0) { for (int k = 0; k < nblk; k++) c += row[k * BA_HROW + 36 + b * 6 + a]; hit = true; }
-            if (j == p && j == q && j >= 0) { for (int k = 0; k < nblk; k++) c += row[k * BA_HROW + 72 + a * 6 + b]; hit = true; }
+            if (i == p && i == q && i >= 0) { c += row[a * 6 + b]; hit = true; }
+            if (i == p && j == q && i >= 0 && j >= 0) { c += row[36 + a * 6 + b]; hit = true; }
+            if (j == p && i == q && i >= 0 && j >= 0) { c += row[36 + b * 6 + a]; hit = true; }
+            if (j == p && j == q && j >= 0) { c += row[72 + a * 6 + b]; hit = true; }
             if (hit) s += c;
         }
         H[(((size_t)p * Pf + q) * 6 + a) * 6 + b] = s;
@@ -271,9 +283,9 @@ __global__ void ba_reduce_H_kernel(const float* __restrict__ Hpart, int nblk, co
         float s = 0.f;
         for (int e = 0; e < N; e++) {
             const int i = ii[e] - fixedp, j = jj[e] - fixedp;
-            const float* row = Hpart + (size_t)e * nblk * BA_HROW;
-            if (i == p) for (int k = 0; k < nblk; k++) s += row[k * BA_HROW + 108 + tix];
-            if (j == p) for (int k = 0; k < nblk; k++) s += row[k * BA_HROW + 114 + tix];
+            const float* row = Hpart + (size_t)e * estride;
+            if (i == p) s += row[108 + tix];
+            if (j == p) s += row[114 + tix];
         }
         v[(size_t)p * 6 + tix] = s;
     }
@@ -726,6 +738,7 @@ extern "C" int cut3r_ba_assemble(const float* Gij, const float* disps, const flo
     BaGeom g{P, ht, wd, N, M, fixedp};
     hipLaunchKernelGGL(ba_edge_kernel, dim3(w.nblk, M), dim3(BA_BLOCK), 0, s, Gij, disps, intr, target, weight, ii, jj, src_ptr, src_edges,
                        kx, g, w.Hpart, w.E, w.Cm, w.wm, eta);
+    hipLaunchKernelGGL(ba_fold_edges_kernel, dim3(N), dim3(128), 0, s, w.Hpart, w.nblk);
     hipLaunchKernelGGL(ba_reduce_H_kernel, dim3(Pf, Pf + 1), dim3(64), 0, s, w.Hpart, w.nblk, ii, jj, N, Pf, fixedp, w.H, w.v);
     // undamped reduced system of THESE edges (motion only: no Schur correction, i.e. M = 0 for the reduction)
     hipLaunchKernelGGL(ba_schur_kernel, dim3(Pf, Pf), dim3(256), 0, s, w.H, w.v, w.E, w.Cm, w.wm, present, Pf, motion_only ? 0 : M, (int)HW,
