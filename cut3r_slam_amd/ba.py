@@ -45,6 +45,9 @@ def edge_structure(ii, jj, P, fixedp):
     return kx, kk, order.astype(np.int32), src_ptr, present
 
 
+_EDGE_TABLES = {}
+
+
 def _prepare(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp):
     dev = disps.device
     B, P, ht, wd = disps.shape
@@ -52,12 +55,23 @@ def _prepare(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp):
         raise NotImplementedError("batch 1 (the only use in the reference)")
     N = ii.shape[0]
     HW = ht * wd
-    kx, kk, order, src_ptr, present = edge_structure(ii, jj, P, fixedp)
+    # the graph's index tables (host analysis + six small uploads) are kept per topology: Gauss-Newton runs several steps on one graph
+    ii_h, jj_h = np.ascontiguousarray(np.asarray(ii.cpu())), np.ascontiguousarray(np.asarray(jj.cpu()))
+    key = (ii_h.tobytes(), jj_h.tobytes(), P, fixedp, str(dev))
+    tab = _EDGE_TABLES.get(key)
+    if tab is None:
+        if len(_EDGE_TABLES) >= 16:
+            _EDGE_TABLES.clear()
+        kx, kk, order, src_ptr, present = edge_structure(ii, jj, P, fixedp)
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+        tab = _EDGE_TABLES[key] = dict(kx=kx, ii=ii.to(dev, torch.int32).contiguous(), jj=jj.to(dev, torch.int32).contiguous(),
+                                       ii_l=ii.to(dev), jj_l=jj.to(dev), src_ptr=t(src_ptr, torch.int32), order=t(order, torch.int32),
+                                       kx_d=t(kx, torch.int32), present=t(present, torch.uint8))
+    kx = tab["kx"]
     M = len(kx)
-    ii_d = ii.to(dev, torch.int32).contiguous()
-    jj_d = jj.to(dev, torch.int32).contiguous()
+    ii_d, jj_d = tab["ii"], tab["jj"]
     G = poses[0] if isinstance(poses, SE3) else SE3(poses[0])
-    Gij = (G[jj.to(dev)] * G[ii.to(dev)].inv()).data.contiguous().float()               # projective_ops.py:51
+    Gij = (G[tab["jj_l"]] * G[tab["ii_l"]].inv()).data.contiguous().float()               # projective_ops.py:51
     intr = intrinsics.reshape(-1, 4).float()
     if intr.shape[0] == 1:
         intr = intr.expand(P, 4)
@@ -65,12 +79,10 @@ def _prepare(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp):
     eta_d = None
     if eta is not None:
         eta_d = eta.to(dev).float().expand(M, ht, wd).reshape(M, HW).contiguous() if eta.numel() != M * HW else eta.reshape(M, HW).float().contiguous()
-    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
     return dict(dev=dev, P=P, ht=ht, wd=wd, N=N, HW=HW, M=M, kx=kx, G=G, Gij=Gij, intr=intr, eta=eta_d, ii=ii_d, jj=jj_d,
                 tgt=target.reshape(N, HW, 2).float().contiguous(), wgt=weight.reshape(N, HW, 2).float().contiguous(),
                 dsp=disps.reshape(P, HW).float().contiguous(),
-                # index tensors kept alive until the launches are enqueued (a temporary would be recycled by the allocator)
-                src_ptr=t(src_ptr, torch.int32), order=t(order, torch.int32), kx_d=t(kx, torch.int32), present=t(present, torch.uint8))
+                src_ptr=tab["src_ptr"], order=tab["order"], kx_d=tab["kx_d"], present=tab["present"])
 
 
 def _assemble(c, fixedp, motion_only=False):
