@@ -63,6 +63,28 @@ def synth_frames(n, H, W, device, seed=0):
     return frames
 
 
+H0, W0 = 480, 640          # the camera's frame size (BASELINE metric: "on 640x480"); demo_s.py:69-73 resizes to 384x512 for tracking
+
+
+def synth_camera_frames(n, device, seed=0):
+    """the same panned texture as raw camera frames: u8 [n,480,640,3] (cv2.imread layout) resident on the GPU"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    base = torch.rand(3, H0 // 8 + 64, W0 // 8 + 64, generator=g)
+    base = torch.nn.functional.interpolate(base[None], scale_factor=8, mode="bilinear", align_corners=False)[0]
+    base = (base * 255).round().clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous().to(device)
+    frames = torch.empty(n, H0, W0, 3, dtype=torch.uint8, device=device)
+    for t in range(n):
+        dx, dy = int(2 * t) % 400, int(1 * t) % 300
+        frames[t] = base[dy:dy + H0, dx:dx + W0]
+    return frames
+
+
+def to_tracking(frame_hwc):
+    """one raw frame u8 [1,H0,W0,3] -> [1,3,384,512] (cut3r_resize_linear_u8 = cv2.resize INTER_LINEAR)"""
+    from cut3r_slam_amd import ops
+    return ops.resize_linear_u8(frame_hwc[0].contiguous(), H, W, chw_out=True)[None]
+
+
 class FrameLoop:
     """a resident recording of `base.shape[0]` frames read as an endless stream: frame f is base[f % period] (slices may not wrap:
     the drivers read single frames and short runs)"""
@@ -202,13 +224,13 @@ def fixed_cadence_leg(model, slam_cls, cdist, dev, wb, steps, warmup, world=1, r
     runner = cdist.ShardedTracker(slam, world, rank, wb=wb, pipelined=os.environ.get("CUT3R_PIPELINE", "1") == "1", force_collective=dist_on)
     runner.emulate_gather = emu > 1
     need = runner.frames_needed(total_steps + probe_steps, KF_EVERY, WIN)
-    if seq_windows > 0:      # the sequences repeat one synthetic recording: a period of frames resident, indexed modulo the period
-        frames = FrameLoop(synth_frames(seq_windows * WIN * KF_EVERY, H, W, dev, seed=0), need)
-    else:
-        frames = synth_frames(need, H, W, dev, seed=0)
+    # one synthetic 640x480 recording of a Replica-shaped sequence (2000 frames), resident in HBM as RAW camera frames and read
+    # cyclically; every keyframe is resized to the tracking resolution INSIDE the timed region (ShardedTracker._append)
+    frames = FrameLoop(synth_camera_frames((seq_windows if seq_windows > 0 else 40) * WIN * KF_EVERY, dev, seed=0), need)
     t = 0
     while not slam.keyframes.is_initialized:          # prologue (untimed): the 6-keyframe initialisation window
-        slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+        f = to_tracking(frames[t:t + 1])
+        slam.run(t, f, intr, f, intr)
         t += 1
     torch.cuda.synchronize()
     for _ in range(warmup):
@@ -224,7 +246,18 @@ def fixed_cadence_leg(model, slam_cls, cdist, dev, wb, steps, warmup, world=1, r
     barrier()
     elapsed = time.perf_counter() - tic
     return {"elapsed": elapsed, "slam": slam, "runner": runner, "frames": frames, "t": t, "intr": intr,
-            "frames_per_step": KF_EVERY * WIN * wb}
+            "frames_per_step": KF_EVERY * WIN * wb, "health": tracking_health(slam)}
+
+
+def tracking_health(slam):
+    """is the leg's result a valid trajectory?  chained-scale book-keeping of the tracker + finiteness of every tracked pose"""
+    st = dict(slam.tracker.scale_stats)
+    k = int(slam.tracker.t1)
+    poses = slam.keyframes.pose[:k].numpy()
+    bad = np.flatnonzero(~np.isfinite(poses).all(axis=1))
+    return {"tracked_keyframes": k, "poses_finite": bool(bad.size == 0), "first_nonfinite_keyframe": (int(bad[0]) if bad.size else None),
+            "nonfinite_windows": int(st["nonfinite_windows"]), "steady_windows": int(st["windows"]),
+            "log_scale_absmax": round(float(st["log_scale_absmax"]), 4), "log_scale_last": round(float(st["log_scale_last"]), 4)}
 
 
 def overlap_mode_leg(model, slam_cls, dev, n_frames=800, lookahead=16, plain_frames=200):
@@ -412,7 +445,8 @@ def main():
     torch.set_num_threads(host_cores())
     # random init through the reference key schema; the encoder's residual branches are damped so that patch features stay
     # content dependent (the overlap-mode keyframe test needs that; cut3r_slam_amd/synth.py) -- no effect on the arithmetic
-    sd = synth.tracking_state_dict(cfg, seed=0, enc_residual_gain=0.1)
+    # depth_relief: see synth.tracking_state_dict (keeps the chained scale of an uncut synthetic stream in range)
+    sd = synth.tracking_state_dict(cfg, seed=0, enc_residual_gain=0.1, depth_relief=float(os.environ.get("CUT3R_DEPTH_RELIEF", "0.02")))
     log(f"weights synthesised in {time.time() - t0:.1f}s")
     model = Cut3rModel(cfg, sd, dev, minimal=True)
     torch.cuda.synchronize()
@@ -438,10 +472,14 @@ def main():
                             seq_windows=SEQ)
     elapsed, slam, runner, frames, t, intr = (leg[k] for k in ("elapsed", "slam", "runner", "frames", "t", "intr"))
     frames_per_step = leg["frames_per_step"]
+    health = leg["health"]
+    if not health["poses_finite"] or health["nonfinite_windows"]:
+        raise SystemExit(f"bench: the headline leg produced non-finite poses: {health}")      # never report a throughput for it
     if dist_on:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    hbm_peak = torch.cuda.max_memory_allocated()            # weights + graphs' static buffers + activations + this leg's stores
     frames_total = frames_per_step * args.steps * world
     value = frames_total / elapsed
     log(f"timed region done: {elapsed:.3f}s for {frames_total} frames -> {value:.1f} frames/s")
@@ -503,7 +541,8 @@ def main():
         l1 = fixed_cadence_leg(model, Cut3rSlam, cdist, dev, 1, 16, 4, barrier=barrier)
         op_points["fixed_cadence_window_batch_1"] = {
             "config": "kf_every=10, window_batch=1: the reference's one-window-at-a-time schedule (50 frames of buffering)",
-            "frames_per_s": round(16 * l1["frames_per_step"] / l1["elapsed"], 1), "ms_per_window": round(1e3 * l1["elapsed"] / 16, 3), "windows": 16}
+            "frames_per_s": round(16 * l1["frames_per_step"] / l1["elapsed"], 1), "ms_per_window": round(1e3 * l1["elapsed"] / 16, 3), "windows": 16,
+            "health": l1["health"]}
         del l1
         if SEQ > 0:
             log("operating points: the same schedule over ONE endless stream (covisibility tests against every earlier keyframe)")
@@ -512,7 +551,8 @@ def main():
                 "config": f"kf_every=10, window_batch={WB}, no sequence cuts: one stream of {(args.steps + args.warmup) * le['frames_per_step']} frames; every new keyframe "
                           "is tested against ALL earlier ones (factor_graph.py:148-197), so the step time grows with the stream",
                 "frames_per_s": round(args.steps * le["frames_per_step"] / le["elapsed"], 1), "ms_per_step": round(1e3 * le["elapsed"] / args.steps, 3),
-                "keyframes_at_end": int(le["slam"].tracker.t1)}
+                "keyframes_at_end": int(le["slam"].tracker.t1), "valid": bool(le["health"]["poses_finite"] and not le["health"]["nonfinite_windows"]),
+                "health": le["health"]}
             del le
         log("operating points: overlap mode (kf_every=-1, skip=5, thresh=0.9)")
         op_points["overlap_mode"] = overlap_mode_leg(model, Cut3rSlam, dev)
@@ -523,16 +563,18 @@ def main():
         traj = trajectory_parity_leg(dev)
     if single and not args.no_cpu_baseline and not args.small:
         log("cpu baseline (oracle on host cores)")
-        cpu_base = cpu_baseline(cfg, sd, frames[:2].cpu())
+        cpu_base = cpu_baseline(cfg, sd, torch.cat([to_tracking(frames[i:i + 1]) for i in range(2)], 0).cpu())
         log("cpu baseline done")
 
     if rank == 0:
         out = {
             "metric": "frames/sec (ViT pointmap + covisibility-graph tracking step) on 640x480" + (f" [DEBUG: rank {emu_rank} of an emulated {emu}-GPU job]" if emu > 1 else ""), "value": round(value, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "keyframes_per_s": round(value / KF_EVERY, 2),
+            "nonfinite_windows": health["nonfinite_windows"], "health": health, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"BUFFERED FIXED-CADENCE mode: Replica-shaped 640x480 sequences -> 384x512 tracking res; kf_every=10; "
+            "config": {"workload": f"BUFFERED FIXED-CADENCE mode: Replica-shaped 640x480 sequences (raw u8 frames resident in HBM; every keyframe resized to the 384x512 "
+                                   "tracking resolution inside the timed region, cv2.resize INTER_LINEAR semantics); kf_every=10; "
                                    + (f"a sequence = {SEQ} windows = {SEQ * 50} frames (Replica room0: 2000 frames, x{world} GPUs), sequences follow each other without "
                                       "a gap (the last keyframe of one is keyframe 0 of the next: initialisation window, empty graph); " if SEQ > 0 else "ONE endless stream; ")
                                    + f"step = {WB} window(s) "
@@ -545,6 +587,9 @@ def main():
                        "frames_per_step": frames_per_step, "window_views": 6, "window_batch": WB, "sequence_windows": SEQ, "parallelism": f"window-sharded x{world}"},
             "roofline": roofline, "cpu_baseline": cpu_base, "operating_points": op_points, "trajectory_parity": traj,
             "ate_rmse_m": (traj or {}).get("fixed_cadence_kf_every_2", {}).get("ate_rmse_m"),
+            "hbm_peak_gb": round(hbm_peak / 1e9, 2),
+            "memory_plan_8_gpus_25_steps_gb": {k: (round(v / 1e9, 2) if isinstance(v, int) and k != "keyframes" else v) for k, v in
+                                               cdist.memory_plan(8, 25, WB, H, W, workspace_bytes=max(0, hbm_peak - cdist.memory_plan(1, args.steps + args.warmup + (probe_steps or 0), WB, H, W, weights_bytes=0)["total"])).items()},
             "build_s": round(t_build, 1), "git_sha": git_sha(),
         }
         print(json.dumps(out))

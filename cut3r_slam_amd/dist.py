@@ -57,6 +57,36 @@ def all_gather_outputs(outs: Sequence[torch.Tensor], world: int, force_collectiv
     return res
 
 
+def memory_plan(world: int, steps: int, wb: int = 28, H: int = 384, W: int = 512, win: int = 5, ds: int = 2, feat_dim: int = 1024, patch: int = 16,
+                weights_bytes: int = 1_610_000_000, workspace_bytes: int = 0, frames_resident: int = 2000, frame_bytes: int = 480 * 640 * 3,
+                hbm_bytes: int = 288 * 10**9):
+    """HBM bytes PER RANK of a `world`-GPU run of `steps` (timed + warm-up) steps of `wb` windows per rank, as bench.py sets the job up
+    (every rank holds the REPLICATED keyframe store of the whole job: the covisibility tests of a window read every earlier stride-2
+    pointmap of its sequence; images and depths are allocated for every keyframe although a rank only fills its own).  Returns a dict
+    of the stores, their sum, and whether it fits."""
+    n_kf = 7 + win * wb * world * steps + 2 + 8
+    nsub = n_kf // win + 1
+    h, w = H // ds, W // ds
+    tokens = (H // patch) * (W // patch)
+    feat_rows = max(64, 2 * (win * wb * world + 1)) + 6
+    plan = {
+        "keyframes": n_kf,
+        "image_u8": n_kf * 3 * H * W,
+        "depth_f32": n_kf * H * W * 4,
+        "submap_ds_f32": nsub * (win + 1) * h * w * 3 * 4,
+        "conf_ds_f32": nsub * (win + 1) * h * w * 4,
+        "w2c_f32": n_kf * 12 * 4,
+        "encoder_feature_ring_f32": feat_rows * tokens * feat_dim * 4,
+        "camera_frames_u8": frames_resident * frame_bytes,
+        "weights_f16": int(weights_bytes),
+        "network_workspaces": int(workspace_bytes),
+    }
+    plan["total"] = sum(v for k, v in plan.items() if k != "keyframes")
+    plan["hbm"] = int(hbm_bytes)
+    plan["fits"] = plan["total"] <= 0.9 * hbm_bytes
+    return plan
+
+
 class ShardedTracker:
     """Drives a replicated `Cut3rSlam` with window-sharded, batched, pipelined network inference."""
 
@@ -97,7 +127,17 @@ class ShardedTracker:
     def _append(self, kf_index: int, frame, tstamp, intr, mine: bool):
         # fixed cadence: the encoder pass of a keyframe is deferred to the rank that owns its window; the other ranks register the
         # keyframe (time stamp, calibration, counter) without copying pixels they never read (at 8 GPUs: 7 of 8 keyframes)
-        self.slam.keyframes.append(tstamp, frame[0] if (mine and frame is not None) else None, None, None, None, None, intr, None, None)
+        kf = self.slam.keyframes
+        if mine and frame is not None and frame.dim() == 4 and frame.shape[-1] == 3 and frame.shape[1] != 3:
+            # a raw camera frame u8 [1,H0,W0,3] (cv2.imread layout, e.g. 480x640): demo_s.py:69-73 resizes it to the tracking resolution
+            # with cv2.resize; here the keyframe is resized on the GPU straight into its row of the store (non-keyframes of a
+            # fixed-cadence stream are never read)
+            from . import ops
+            i = kf.counter.value
+            kf.append(tstamp, None, None, None, None, None, intr, None, None)
+            ops.resize_linear_u8(frame[0], kf.ht, kf.wd, chw_out=True, out=kf.image[i])
+            return
+        kf.append(tstamp, frame[0] if (mine and frame is not None) else None, None, None, None, None, intr, None, None)
 
     def _encode(self, ranges):
         """encoder pass over this rank's not-yet-encoded keyframes (batched) -> window features [wb,V,N,E]"""

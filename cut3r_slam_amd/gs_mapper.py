@@ -41,8 +41,10 @@ def pose_vec_to_matrix(p):
 
 class GaussianMap:
     """Parameters of all Gaussians in ONE [P,14] block (xyz 3 | DC colour 3 | opacity logit 1 | log scale 3 | quaternion 4) with its Adam
-    moments and per-Gaussian step counts beside it: growth and pruning are row operations on three tensors, the optimiser step is one
-    pass over the block with a per-column learning rate, `p[name]` are column views."""
+    moments beside it and ONE step count (torch.optim.Adam keeps one `step` per parameter group and the reference's
+    cat_tensors_to_optimizer / _prune_optimizer / replace_tensor_to_optimizer, gaussian_model.py:510-599, zero-pad or cut the moments
+    but keep that count: appended Gaussians get no bias correction of their own): growth and pruning are row operations on three
+    tensors, the optimiser step is one pass over the block with a per-column learning rate, `p[name]` are column views."""
     GROUPS = ("xyz", "f_dc", "opacity", "scaling", "rotation")
     COLS = {"xyz": (0, 3), "f_dc": (3, 6), "opacity": (6, 7), "scaling": (7, 10), "rotation": (10, 14)}
 
@@ -57,7 +59,7 @@ class GaussianMap:
         for k, (a, b) in self.COLS.items():
             self.lr[0, a:b] = lr[k]
         self.percent_dense = opt.get("percent_dense", 0.01)
-        self.step_count = z(0, 1)
+        self.step_count = z(1)                                            # device scalar: a captured iteration increments it in place
         self.kf_id = torch.zeros(0, dtype=torch.int32, device=self.device)
         self.max_radii2D = z(0)
         self.grad_accum, self.denom = z(0, 1), z(0, 1)
@@ -97,7 +99,6 @@ class GaussianMap:
         z = lambda *s: torch.zeros(*s, device=self.device)
         self.theta = torch.cat([self.theta.detach(), rows], 0).requires_grad_(True)
         self.m, self.v = torch.cat([self.m, z(n, 14)], 0), torch.cat([self.v, z(n, 14)], 0)
-        self.step_count = torch.cat([self.step_count, z(n, 1)], 0)
         self.kf_id = torch.cat([self.kf_id, kf_id.to(self.device, torch.int32)], 0)
         self.max_radii2D = torch.cat([self.max_radii2D, z(n)], 0)
         self.grad_accum, self.denom = torch.cat([self.grad_accum, z(n, 1)], 0), torch.cat([self.denom, z(n, 1)], 0)
@@ -125,7 +126,7 @@ class GaussianMap:
         keep = ~mask
         self.theta = self.theta.detach()[keep].requires_grad_(True)
         self.m, self.v = self.m[keep], self.v[keep]
-        self.step_count, self.kf_id, self.max_radii2D = self.step_count[keep], self.kf_id[keep], self.max_radii2D[keep]
+        self.kf_id, self.max_radii2D = self.kf_id[keep], self.max_radii2D[keep]
         self.grad_accum, self.denom = self.grad_accum[keep], self.denom[keep]
 
     def reset_opacity(self):
@@ -136,10 +137,10 @@ class GaussianMap:
             self.v[:, 6:7] = 0
 
     def reset_moments(self, rows):
-        """optimiser state of the given Gaussians back to that of new ones (what the reference's prune + re-append does)"""
+        """optimiser moments of the given Gaussians back to those of new ones (what the reference's prune + re-append does; the step
+        count of the group is kept, as there)"""
         self.m[rows] = 0
         self.v[rows] = 0
-        self.step_count[rows] = 0
 
     def add_densification_stats(self, viewspace_grad, update_filter):
         """gaussian_model.py:779-790: norm of the screen-space gradient (x, y) per visible Gaussian"""
@@ -179,8 +180,8 @@ class GaussianMap:
         self.denom.zero_()
         self.max_radii2D.zero_()
 
-    # ---- Adam (torch.optim.Adam(lr per group, eps=1e-15) of gaussian_model.py:374-417, with per-Gaussian step counts so that appended
-    #      Gaussians start their own bias correction)
+    # ---- Adam (torch.optim.Adam(lr per group, eps=1e-15) of gaussian_model.py:374-417; one step count for the block, see the class
+    #      docstring)
     def zero_grad(self):
         self.theta.grad = None
 
@@ -196,6 +197,13 @@ class GaussianMap:
         self.theta.sub_(self.lr * (self.m / bc1) / ((self.v / bc2).sqrt() + eps))
 
 
+def position_lr(op, iteration):
+    """general_utils.py:41-56 `get_expon_lr_func` as gaussian_model.py:395-431 sets it up: log-linear from position_lr_init to
+    position_lr_final over position_lr_max_steps + 1000 steps (no delay), clamped at the end"""
+    t = min(max(iteration / (op.get("position_lr_max_steps", 20000) + 1000), 0.0), 1.0)
+    return math.exp(math.log(op["position_lr_init"]) * (1 - t) + math.log(op["position_lr_final"]) * t)
+
+
 def SO3_matrix(q):
     """(r, x, y, z) unit quaternions [n,4] -> rotation matrices [n,3,3]"""
     r, x, y, z = q.unbind(-1)
@@ -205,6 +213,7 @@ def SO3_matrix(q):
 
 class Camera:
     """camera_utils.py Camera.init_from_tracking: image [3,H,W] in [0,1], depth [H,W], world->camera w2c [4,4], pinhole K"""
+    half_pixel_center = False
 
     def __init__(self, uid, image, depth, w2c, fx, fy, cx, cy, tstamp=None, device="cuda:0"):
         dev = torch.device(device)
@@ -222,12 +231,15 @@ class Camera:
         # per-view affine colour model (camera_utils.py exposure_a / exposure_b; used when Training.compensate_exposure)
         self.exposure_a = torch.eye(3, device=dev).requires_grad_(True)
         self.exposure_b = torch.zeros(3, device=dev, requires_grad=True)
-        # pinhole projection in the rasteriser's NDC (pixel u = ((ndc + 1) W - 1) / 2, forward.cu ndc2Pix): u = fx X/Z + cx exactly;
-        # stored transposed like the reference's cameras (graphics_utils.getProjectionMatrix2 + .transpose(0, 1))
+        # graphics_utils.getProjectionMatrix2 (:72-93: left = cx - W, right = cx in units of znear / fx, so P[0,2] = 2 cx / W - 1),
+        # stored transposed like the reference's cameras.  Through the rasteriser's ndc2Pix (auxiliary.h:57-60, pixel u = ((ndc + 1) W -
+        # 1) / 2) a point lands at u = fx X/Z + cx - 0.5: maps trained here and in the reference render alike.  Camera.half_pixel_center
+        # = True (a declared deviation, off by default) puts it at u = fx X/Z + cx exactly.
         znear, zfar, W, H = 0.01, 100.0, self.image_width, self.image_height
+        hp = 1.0 if Camera.half_pixel_center else 0.0
         P = torch.zeros(4, 4)
         P[0, 0], P[1, 1] = 2 * self.fx / W, 2 * self.fy / H
-        P[0, 2], P[1, 2] = (2 * self.cx + 1) / W - 1, (2 * self.cy + 1) / H - 1
+        P[0, 2], P[1, 2] = (2 * self.cx + hp) / W - 1, (2 * self.cy + hp) / H - 1
         P[3, 2], P[2, 2], P[2, 3] = 1.0, zfar / (zfar - znear), -(zfar * znear) / (zfar - znear)
         self.projection_matrix = P.T.contiguous().to(dev)
         self.projection_matrix_host = P.T.contiguous()                  # the rasteriser reads its matrices on the host: no copy back per render
@@ -609,9 +621,10 @@ class GSMapper:
                         self.gaussians.densify_and_prune(op["densify_grad_threshold"], self.gaussian_th, self.gaussian_extent, self.size_threshold)
                     if (self.iteration_count + 1) % reset_every == 0 and opacity_reset:
                         self.gaussians.reset_opacity()
-                    if "position_lr_final" in op:                           # gaussian_model.py:419-431, general_utils.py:41-56
-                        t = min(max(iteration / (op.get("position_lr_max_steps", 20000) + 1000), 0.0), 1.0)
-                        self.gaussians.lr[0, 0:3] = math.exp(math.log(op["position_lr_init"]) * (1 - t) + math.log(op["position_lr_final"]) * t)
+                if densify and "position_lr_final" in op:
+                    # gs_backend_per_frame.py:1043-1044 calls update_learning_rate(iteration) on EVERY iteration of a densifying run (only
+                    # the statistics / densify / reset above stop at 10000); gaussian_model.py:419-431, general_utils.py:41-56
+                    self.gaussians.lr[0, 0:3] = position_lr(op, iteration)
             opt.step()
             update_pose(v)
             last = loss.detach()

@@ -578,12 +578,16 @@ def remap_linear_u8(src_hwc, map_ix, map_iy, out=None):
     return out
 
 
-def resize_linear_u8(img_hwc, H1, W1, chw_out=True):
-    """cv2.resize(img, (W1, H1)) (INTER_LINEAR, u8) on the GPU.  img_hwc u8 [H0,W0,C] -> u8 [C,H1,W1] (or [H1,W1,C])."""
-    _cuda(img_hwc)
+def resize_linear_u8(img_hwc, H1, W1, chw_out=True, out=None):
+    """cv2.resize(img, (W1, H1)) (INTER_LINEAR, u8) on the GPU.  img_hwc u8 [H0,W0,C] -> u8 [C,H1,W1] (or [H1,W1,C]); `out`: write
+    there (e.g. straight into the keyframe store) instead of a new tensor."""
+    _cuda(img_hwc, out)
     _req(img_hwc.dtype == torch.uint8 and img_hwc.dim() == 3 and img_hwc.is_contiguous() and img_hwc.shape[2] <= 4, "u8 [H,W,C<=4] contiguous")
     H0, W0, Cc = img_hwc.shape
-    out = torch.empty((Cc, H1, W1) if chw_out else (H1, W1, Cc), dtype=torch.uint8, device=img_hwc.device)
+    shape = (Cc, int(H1), int(W1)) if chw_out else (int(H1), int(W1), Cc)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.uint8, device=img_hwc.device)
+    _req(out.dtype == torch.uint8 and tuple(out.shape) == shape and out.is_contiguous(), f"out u8 {shape} contiguous")
     lib = _lib.load()
     check(lib.cut3r_resize_linear_u8(_p(img_hwc), H0, W0, Cc, _p(out), int(H1), int(W1), int(bool(chw_out)), _stream()), "cut3r_resize_linear_u8")
     return out

@@ -52,10 +52,16 @@ class Cut3rSlam:
         # hi2.py:47-48: the Gaussian mapper (cut3r_slam_amd.gs_mapper.GSMapper); None = tracking only (BASELINE configs 1-4)
         self.mapper = None
         self.gs_iter_num = self.config.get("Mapping", {}).get("itr_num", 100)
+        # hi2.py:84 reads `self.keyframes.depth[updated_idx][mask] = depth[mask]` with a LIST index: an advanced-index copy, so the
+        # reference never changes keyframes.depth and later windows chain on the tracker's own depths.  Default = that effective
+        # behaviour; True writes the mapper's scale-corrected depths back (what the line looks like it wants) -- a declared deviation
+        self.gs_depth_writeback = False
 
     def call_gs(self, viz_idx, submap_idx, iterations, intrinsics):
-        """hi2.py:56-91: hand the window's keyframes to the mapper and take back its refined poses, scale-corrected depths and
-        pointmaps (the chain of later windows then starts from them).  Images are the stored tracking-resolution keyframes."""
+        """hi2.py:56-91: hand the window's keyframes to the mapper and take back its refined poses and pointmaps (the chain of later
+        windows then starts from them; depths only with `gs_depth_writeback`, see __init__).  Declared deviation: the images are the
+        stored tracking-resolution keyframes with the tracking intrinsics (the reference hands over its full-resolution
+        `self.images[t]` with the full-resolution calibration, hi2.py:60-63)."""
         kf = self.keyframes
         viz = list(viz_idx)
         n = len(viz)
@@ -68,8 +74,9 @@ class Cut3rSlam:
         depth = updated["depths"]
         ds = self.downsample_ratio
         for j, k in enumerate(idx):
-            ok = depth[j] > 0
-            kf.depth[k][ok] = depth[j][ok]
+            if self.gs_depth_writeback:
+                ok = depth[j] > 0
+                kf.depth[k][ok] = depth[j][ok]
             kf.submap_ds[k // 5, k % 5] = updated["pointmaps"][j, ::ds, ::ds]
         kf.submap_ds[:submap_idx + 1, -1] = kf.submap_ds[1:submap_idx + 2, 0]
         return idx

@@ -26,11 +26,20 @@ def medium_config(head_type: str = "dpt") -> Cut3rConfig:
 
 
 def tracking_state_dict(cfg: Cut3rConfig, seed: int = 0, enc_residual_gain: float | None = None, depth_logit: float = 1.5,
-                        head_gain: float = 0.3):
+                        head_gain: float = 0.3, depth_relief: float = 1.0):
+    """depth_relief < 1 damps the z logit's dependence on the features (its bias stays): a random-weight network predicts the SAME
+    image's depth a constant factor apart as view 0 and as view 5 of a window (the recurrent state differs), which a trained network
+    does not; chained over hundreds of windows of an uncut stream that factor compounds (log s grows linearly, see
+    track_frontend._check_scale).  With a small relief the per-window ratio averages ~1 and an endless synthetic stream stays in
+    the fp32 range.  The arithmetic cost does not depend on it."""
     sd = synth_state_dict(cfg, seed)
     if cfg.head_type == "dpt":
         k = "downstream_head.dpt_self.head.4."
-        sd[k + "weight"] = sd[k + "weight"] * head_gain
+        w = sd[k + "weight"] * head_gain
+        if depth_relief != 1.0:
+            w = w.clone()
+            w[2] = w[2] * depth_relief
+        sd[k + "weight"] = w
         b = sd[k + "bias"].clone()
         b[2] = depth_logit
         sd[k + "bias"] = b
@@ -39,6 +48,48 @@ def tracking_state_dict(cfg: Cut3rConfig, seed: int = 0, enc_residual_gain: floa
             if key.startswith("enc_blocks.") and key.rsplit(".", 1)[0].endswith(("attn.proj", "mlp.fc2")):
                 sd[key] = sd[key] * enc_residual_gain
     return sd
+
+
+def outlier_state_dict(cfg: Cut3rConfig, seed: int = 0, fc1_gain: float = 3.0e3, fc2_weight: float = 0.1, norm_gain: float = 8.0, **kw):
+    """Random weights with injected MASSIVE ACTIVATIONS, the feature of trained ViT checkpoints that random initialisation lacks (no
+    checkpoint exists in the reference tree and none may be fetched): in a few blocks one hidden unit h of the MLP gets its `fc1` row
+    multiplied by `fc1_gain` (hidden activations ~1e4 at the tokens that excite it) and feeds one residual channel c through
+    `fc2.weight[c, h] = fc2_weight` (the fp32 residual stream reaches ~1e3 in that channel, token dependent, and keeps it through
+    every later block); one LayerNorm channel per affected stack gets its gain multiplied by `norm_gain`.  Like a trained head, the
+    self-view DPT adapter does not read the massive decoder channels (its 1x1 input convolutions' columns for them are zero) --
+    otherwise the exp() of the output activation turns the outlier into astronomically large coordinates, in any arithmetic.
+    Returns (state_dict, plan) with plan = [(block prefix, hidden unit, residual channel)]."""
+    sd = tracking_state_dict(cfg, seed, **kw)
+    plan = []
+
+    def inject(prefix, h, c):
+        w1 = sd[prefix + ".mlp.fc1.weight"].clone()
+        w1[h] = w1[h] * fc1_gain
+        sd[prefix + ".mlp.fc1.weight"] = w1
+        w2 = sd[prefix + ".mlp.fc2.weight"].clone()
+        w2[:, h] = 0                                      # the massive unit feeds ONE channel (its fan-out is concentrated, as trained)
+        w2[c, h] = fc2_weight
+        sd[prefix + ".mlp.fc2.weight"] = w2
+        plan.append((prefix, h, c))
+
+    E, D = cfg.enc_embed_dim, cfg.dec_embed_dim
+    inject(f"enc_blocks.{max(1, cfg.enc_depth // 6)}", 7 % (4 * E), 5 % E)
+    inject(f"enc_blocks.{max(1, (2 * cfg.enc_depth) // 3)}", 100 % (4 * E), 321 % E)
+    c_img, c_state = 11 % D, 200 % D
+    inject(f"dec_blocks.{min(1, cfg.dec_depth - 1)}", 9 % (4 * D), c_img)
+    inject(f"dec_blocks_state.{min(2, cfg.dec_depth - 1)}", 33 % (4 * D), c_state)
+    for key, c in ((f"enc_blocks.{cfg.enc_depth - 1}.norm1.weight", 5 % E), (f"dec_blocks.{cfg.dec_depth - 1}.norm1.weight", c_img),
+                   (f"dec_blocks_state.{cfg.dec_depth - 1}.norm1.weight", c_state)):
+        g = sd[key].clone()
+        g[c] = g[c] * norm_gain
+        sd[key] = g
+    if cfg.head_type == "dpt":
+        for i in (1, 2):                                # hooks dec6 / dec9: raw residual streams of the image-side decoder
+            k = f"downstream_head.dpt_self.act_postprocess.{i}.0.weight"
+            w = sd[k].clone()
+            w[:, c_img] = 0
+            sd[k] = w
+    return sd, plan
 
 
 def pan_stream(n: int, H: int, W: int, pool: int = 5, num: int = 2, den: int = 1, seed: int = 0, device="cpu") -> torch.Tensor:

@@ -19,12 +19,36 @@ from . import ops
 from .factor_graph import AlignedPoints, SubmapStore
 
 
-def _check_scale(t0, s):
-    """The reference takes torch.log of the predicted depths as they come (track_frontend.py:203-206): one depth <= 0 in the shared
-    keyframe makes the window scale NaN and every later pose with it, silently.  Same arithmetic here, plus a warning."""
-    if not math.isfinite(float(s)):
-        warnings.warn(f"window at keyframe {t0}: log-depth scale is {float(s)} (a predicted depth <= 0 in the shared keyframe); "
-                      "poses from this window on are not finite", RuntimeWarning, stacklevel=3)
+def _check_scale(t0, s, stats=None):
+    """The reference chains windows by align_s = exp(mean(log depth_stored[t0] - log depth_window[view 0])) (track_frontend.py:203-222)
+    and multiplies the window's points and translations by it, silently.  The same arithmetic here, plus book-keeping and a warning
+    when the scale leaves the finite fp32 range.  Two things can do that: a predicted depth <= 0 in the shared keyframe (log of it
+    is NaN / -inf), or -- what an uncut stream through a network whose view-0 and view-5 depths of the same image differ by a
+    constant factor produces -- geometric growth of the chained scale, log s_k = log s_{k-1} + delta, until exp() overflows (the
+    camera centres overflow the squared-distance gate of the covisibility test, factor_graph.py:148-160, well before that).
+    `stats` (TrackFrontend.scale_stats) records the drift so that a caller can tell the two apart."""
+    s = float(s)
+    if stats is not None:
+        stats["windows"] += 1
+        if math.isfinite(s) and s > 0:
+            ls = math.log(s)
+            stats["log_scale_last"] = ls
+            stats["log_scale_absmax"] = max(stats["log_scale_absmax"], abs(ls))
+    if not (math.isfinite(s) and s > 0):
+        if stats is not None:
+            stats["nonfinite_windows"] += 1
+            if stats["first_nonfinite_keyframe"] is None:
+                stats["first_nonfinite_keyframe"] = t0
+        grew = stats is not None and stats["log_scale_absmax"] > 40.0
+        warnings.warn(f"window at keyframe {t0}: chained log-depth scale is {s} ("
+                      + ("the chained scale grew geometrically along the stream: |log s| reached "
+                         f"{stats['log_scale_absmax']:.1f} before leaving the fp32 range" if grew else
+                         "a non-positive or non-finite predicted depth in the shared keyframe, or an overflowing chained scale")
+                      + "); poses from this window on are not finite", RuntimeWarning, stacklevel=3)
+
+
+def new_scale_stats():
+    return {"windows": 0, "nonfinite_windows": 0, "first_nonfinite_keyframe": None, "log_scale_last": 0.0, "log_scale_absmax": 0.0}
 
 
 def make_views(model, images_u8):
@@ -78,6 +102,7 @@ class TrackFrontend:
         self._counts_host = None
         self._pose_host = torch.zeros(8, 7, dtype=torch.float32).pin_memory()
         self._ev = None
+        self.scale_stats = new_scale_stats()     # chained-scale book-keeping of every steady-state window (see _check_scale)
 
     def prepare_input(self, images):
         return make_views(self.model, images)
@@ -238,7 +263,7 @@ class TrackFrontend:
             align = None
             if not init_k:
                 align_s = np.float32(math.exp(np.float32(lsum / (H * W))))
-                _check_scale(t0, align_s)
+                _check_scale(t0, align_s, self.scale_stats)
                 prev_c2w = gh.pose_vec_to_matrix(kf.pose[t0].numpy()[None])[0]
                 align = (prev_c2w[:3, :3], prev_c2w[:3, 3], align_s)
             # host: chained pose of every view, one vectorised matrix->quaternion conversion (the reference converts and
@@ -385,9 +410,9 @@ class TrackFrontend:
 
         encs = scal[:, 2:2 + 7 * V].reshape(n, V, 7).astype(np.float32)
         chained_all, s_all, vecs, rows_all = gh.chain_windows(encs, scale_of, kf.pose[ranges[0][0]].numpy(), reset=cut)
-        if not np.isfinite(s_all).all():
-            k_bad = int(np.flatnonzero(~np.isfinite(s_all))[0])
-            _check_scale(ranges[k_bad][0], s_all[k_bad])
+        for k in range(n):
+            if not cut[k]:
+                _check_scale(ranges[k][0], s_all[k], self.scale_stats)
         cent = []
         for k, (t0, t1) in enumerate(ranges):                 # later windows overwrite the shared keyframe, as track() does
             kf.pose[t0:t1] = torch.from_numpy(vecs[k])

@@ -137,3 +137,16 @@ def test_sharded_tracker_world2_window_batch2():
     # keyframes 7..16 belong to rank 0's two windows of step 1 (the shared keyframe 5/6 were initialised earlier)
     assert [m for k, _, m in app0 if k <= 15] == [True] * 9
     assert nb0 == 4
+
+
+def test_memory_plan_of_the_drivers_8_gpu_job_fits_one_mi355x():
+    """the replicated stores of the driver's SCALE run (N = 8, --steps 20 --warmup 5, 28 windows per rank and step) per rank, with the
+    network's measured workspace (bench.py reports `hbm_peak_gb` at N = 1: weights + graphs' static buffers + activations of a 28-window
+    pass), must fit the 288 GB of one MI355X with a margin; the plan grows linearly with the steps, so its slope is checked too"""
+    from cut3r_slam_amd.dist import memory_plan
+    plan = memory_plan(world=8, steps=25, wb=28, workspace_bytes=60 * 10**9)
+    assert plan["keyframes"] == 7 + 5 * 28 * 8 * 25 + 2 + 8
+    assert plan["fits"] and plan["total"] < 0.6 * plan["hbm"], plan
+    per_kf = (memory_plan(8, 26, 28)["total"] - memory_plan(8, 25, 28)["total"]) / (5 * 28 * 8)
+    assert 2.2e6 < per_kf < 2.5e6, per_kf                      # image 0.59 + depth 0.79 + 6/5 x (stride-2 pointmap 0.59 + confidence 0.20) MB
+    assert not memory_plan(world=8, steps=120, wb=28, workspace_bytes=60 * 10**9)["fits"]      # (the bound is real: ~95 steps at N = 8)

@@ -65,3 +65,30 @@ def test_edge_sharded_ba_two_ranks_gloo():
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", str(_free_port()), "tools/ba_shard_check.py"], {"CUT3R_DIST_BACKEND": "gloo"})
     assert out.count("OK") == 2
+
+
+def test_one_rank_rccl_rehearsal_runs_the_real_collectives(tmp_path):
+    """RCCL readiness: ONE rank over the nccl (= RCCL) backend with CUT3R_FORCE_DIST=1 -- process-group
+    initialisation on the device, `all_gather_into_tensor` of the [wb, 44] fp64 window scalars, the two in-place store all-gathers,
+    the int32 count `all_reduce` and the max-over-ranks timing reduction all run on device buffers, exactly the calls an N-GPU job
+    makes.  Its result must be bit-identical to the scan-form replay without a process group (CUT3R_SCAN=1).  No scaling is measured
+    or claimed by this test."""
+    common = ["--small", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--window-batch", "4", "--sequence-windows", "6"]
+    a, b = str(tmp_path / "rccl1"), str(tmp_path / "scan1")
+    out = _run([sys.executable, "bench.py"] + common, {"CUT3R_FORCE_DIST": "1", "CUT3R_DUMP_STATE": a, "CUT3R_REPLICATE_DEPTH": "1",
+                                                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+                                                       "HSA_ENABLE_IPC_MODE_LEGACY": "0", "CUT3R_DIST_BACKEND": "nccl"})
+    assert '"n_gpus": 1' in out and '"nonfinite_windows": 0' in out
+    _run([sys.executable, "bench.py"] + common, {"CUT3R_SCAN": "1", "CUT3R_DUMP_STATE": b})
+    r, s = np.load(a + ".rank0.npz"), np.load(b + ".rank0.npz")
+    assert int(r["k"]) == int(s["k"]) == 6 + 5 * 4 * 3
+    for key in ("pose", "w2c", "depth_sum", "submap_sum", "ii", "jj"):
+        np.testing.assert_array_equal(r[key], s[key], err_msg=key)
+    assert len(r["ii"]) > 100
+
+
+def test_edge_sharded_ba_one_rank_rccl():
+    """the dense-BA split's `S, vS, diag H` all-reduce and the disparity-increment all-reduce on device buffers over RCCL (one rank)"""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "tools/ba_shard_check.py"], {"CUT3R_DIST_BACKEND": "nccl", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert out.count("OK") == 1

@@ -27,6 +27,9 @@ from oracle import cut3r_oracle as O  # noqa: E402
 
 DEV = "cuda:0"
 KEYS = ("camera_pose", "pts3d_in_self_view", "conf_self")
+# production shape (ViT-L / 768-d decoder / DPT at 368x512 and 384x512): 3 x the errors measured on MI355X in round 3
+# (profiles/r03/achieved_errors.txt), next to the relative rule e_hip <= 2 e_tf32 + 2e-4 of _budget
+TOL_PROD = {"camera_pose": 3e-3, "pts3d_in_self_view": 1.5e-2, "conf_self": 1.5e-2}
 
 
 def _rel(got, ref):
@@ -116,53 +119,98 @@ def test_scannet_crop_368x512_window(prod):
     imgs = _images(2, 368, 512, 7)
     torch.set_num_threads(min(16, torch.get_num_threads()))
     ref32 = O.forward_views(cfg, sd, O.normalize(imgs), minimal=True)
+    with O.matmul_precision("tf32"):
+        reftf = O.forward_views(cfg, sd, O.normalize(imgs), minimal=True)
     preds, _ = model.forward_window(imgs.to(DEV))
     torch.cuda.synchronize()
     assert preds[0]["pts3d_in_self_view"].shape == (1, 368, 512, 3)
-    _budget("production 368x512 2 views", preds, ref32, None, {"camera_pose": 3e-3, "pts3d_in_self_view": 1.5e-2, "conf_self": 1.5e-2})
+    _budget("production 368x512 2 views", preds, ref32, reftf, TOL_PROD)
 
 
-def test_six_view_full_size_window_and_fp16_headroom(prod):
-    """the steady-state tracking window (6 views, 384x512) against the fp32 oracle, and the largest magnitude every fp16
-    activation buffer reached (range risk of fp16 operands vs the reference's TF32: VERDICT r1 weak #6; random weights only --
-    no checkpoint exists)"""
-    cfg, sd, model = prod
-    imgs = _images(6, 384, 512, 0)
-    torch.set_num_threads(min(16, torch.get_num_threads()))
-    ref32 = O.forward_views(cfg, sd, O.normalize(imgs), minimal=True)
+PROBED = ("linear", "linear_batched", "layernorm", "layernorm_dual", "attention", "conv3x3_nhwc", "conv_transpose_nhwc", "upsample2x", "cast_f16",
+          "rope_2d", "rope_2d_qk", "im2col_patch")
+
+
+def _run_probed(model, imgs):
+    """one eager window with every ops.* entry point wrapped: the largest |value| of every fp16 operand / result per op, and of every
+    fp32 one (the residual streams enter LayerNorm and the residual-adding GEMM epilogues in fp32)"""
     from cut3r_slam_amd import ops
     was = model.use_graphs
     model.use_graphs = False
-    peaks = {}
-    names = ("linear", "linear_batched", "layernorm", "layernorm_dual", "attention", "conv3x3_nhwc", "conv_transpose_nhwc", "upsample2x", "cast_f16",
-             "rope_2d", "rope_2d_qk", "im2col_patch")
-    real = {n: getattr(ops, n) for n in names}
+    peaks16, peaks32 = {}, {}
+    real = {n: getattr(ops, n) for n in PROBED}
 
     def probe(n):
         def fn(*a, **k):
             r = real[n](*a, **k)
             for t in list(a) + list(k.values()):
-                if isinstance(t, torch.Tensor) and t.dtype == torch.float16 and t.is_cuda and t.numel():
+                if isinstance(t, torch.Tensor) and t.is_cuda and t.numel() and t.dtype in (torch.float16, torch.float32):
+                    d = peaks16 if t.dtype == torch.float16 else peaks32
                     m = t.detach().abs().max().float()
-                    peaks[n] = torch.maximum(peaks[n], m) if n in peaks else m
+                    d[n] = torch.maximum(d[n], m) if n in d else m
             return r
         return fn
 
-    for n in names:
+    for n in PROBED:
         setattr(ops, n, probe(n))
     try:
         preds, _ = model.forward_window(imgs.to(DEV))
         torch.cuda.synchronize()
     finally:
-        for n in names:
+        for n in PROBED:
             setattr(ops, n, real[n])
         model.use_graphs = was
-    _budget("production 384x512 6 views", preds, ref32, None, {"camera_pose": 3e-3, "pts3d_in_self_view": 1.5e-2, "conf_self": 1.5e-2})
-    pk = sorted(((float(v), n) for n, v in peaks.items()), reverse=True)
+    pk16 = sorted(((float(v), n) for n, v in peaks16.items()), reverse=True)
+    pk32 = sorted(((float(v), n) for n, v in peaks32.items()), reverse=True)
+    return preds, pk16, pk32
+
+
+def test_six_view_full_size_window_and_fp16_headroom(prod):
+    """the steady-state tracking window (6 views, 384x512) against the fp32 oracle with the TF32 budget beside it, and the largest
+    magnitude every fp16 activation buffer reached (seeded random weights; the outlier test below injects massive activations)"""
+    cfg, sd, model = prod
+    imgs = _images(6, 384, 512, 0)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref32 = O.forward_views(cfg, sd, O.normalize(imgs), minimal=True)
+    with O.matmul_precision("tf32"):
+        reftf = O.forward_views(cfg, sd, O.normalize(imgs), minimal=True)
+    preds, pk, _ = _run_probed(model, imgs)
+    _budget("production 384x512 6 views", preds, ref32, reftf, TOL_PROD)
     assert pk and all(np.isfinite(p) for p, _ in pk)
     print("[fp16 headroom] largest |value| seen in any fp16 operand/result of each op over a 6-view window: " +
           ", ".join(f"{n} {p:.1f}" for p, n in pk) + f" | headroom to 65504: x{65504.0 / max(pk[0][0], 1e-9):.0f}")
     assert pk[0][0] < 65504.0 / 16, pk[:3]
+
+
+def test_six_view_window_with_massive_activations_stays_inside_the_tf32_budget():
+    """fp16 range under OUTLIERS: trained ViT-L checkpoints carry massive-activation channels that seeded
+    N(0, 1/fan_in) weights lack, and the MI355X path stores LayerNorm outputs, fc1+GELU hiddens and the DPT activations in fp16
+    (5-bit exponent) where the reference's TF32 keeps fp32's 8 bits.  No checkpoint exists and none may be fetched, so
+    cut3r_slam_amd.synth.outlier_state_dict injects them: MLP hiddens ~1e4 and fp32 residual channels ~1e3 in two encoder blocks and
+    in one block of each decoder stack.  The 6-view 384x512 window must stay finite and inside the same TF32 budget as with plain
+    weights; the achieved magnitudes and the remaining fp16 headroom are printed."""
+    cfg = production_config()
+    sd, plan = synth.outlier_state_dict(cfg, 0)
+    imgs = _images(6, 384, 512, 0)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref32 = O.forward_views(cfg, sd, O.normalize(imgs), minimal=True)
+    with O.matmul_precision("tf32"):
+        reftf = O.forward_views(cfg, sd, O.normalize(imgs), minimal=True)
+    model = Cut3rModel(cfg, sd, DEV, minimal=True)
+    preds, pk16, pk32 = _run_probed(model, imgs)
+    for p in preds:
+        for k in KEYS:
+            assert torch.isfinite(p[k]).all(), k
+    print(f"[fp16 outliers] injected {plan} | largest fp16 |value| per op: " + ", ".join(f"{n} {p:.1f}" for p, n in pk16[:6]) +
+          " | largest fp32 |value| per op: " + ", ".join(f"{n} {p:.1f}" for p, n in pk32[:4]) +
+          f" | headroom of the fp16 operands to 65504: x{65504.0 / max(pk16[0][0], 1e-9):.1f}")
+    assert pk16[0][0] >= 3e3, "the injection did not produce massive hidden activations"
+    assert pk32[0][0] >= 3e2, "the injection did not produce a massive residual channel"
+    assert pk16[0][0] < 65504.0 / 2
+    _budget("production 384x512 6 views, massive activations", preds, ref32, reftf,
+            {"camera_pose": 1e-2, "pts3d_in_self_view": 2e-2, "conf_self": 2e-2})
+    del model
+    torch.cuda.empty_cache()
 
 
 def test_from_pretrained_round_trip(tmp_path):
