@@ -295,27 +295,38 @@ def overlap_mode_leg(model, slam_cls, dev, n_frames=800, lookahead=16, plain_fra
     return out
 
 
-def trajectory_parity_leg(dev):
-    """GPU path vs CPU restatement of the reference loop on the same seeded stream + weights (medium config, both keyframe
-    modes): ATE-RMSE with Sim(3) alignment, keyframe agreement, edge lists.  tests/test_e2e_gpu.py asserts the same."""
+def trajectory_parity_leg(dev, production_model=None, production_sd=None):
+    """GPU path vs CPU restatement of the reference loop on the same seeded stream + weights: ATE-RMSE with Sim(3) alignment, keyframe
+    agreement, edge lists.  Medium config at 64x96 in both keyframe modes (tests/test_e2e_gpu.py asserts the same) and -- a third entry
+    -- the PRODUCTION network at 384x512 over two tracking windows + the closing window (tests/test_e2e_production_gpu.py asserts it over
+    three; bounded here to about a minute of CPU oracle per precision)."""
     from cut3r_slam_amd import synth
     from cut3r_slam_amd.eval_ate import ate_rmse
     from cut3r_slam_amd.model import Cut3rModel
     from cut3r_slam_amd.slam import Cut3rSlam
     from oracle import slam_run as SR
     Hm, Wm = 64, 96
-    intr = np.array([80.0, 80.0, 47.5, 31.5], np.float32)
+    intr_m = np.array([80.0, 80.0, 47.5, 31.5], np.float32)
     cfg = synth.medium_config()
     sd = synth.tracking_state_dict(cfg, 11)
     model = Cut3rModel(cfg, sd, dev, minimal=True)
-    res = {"config": "medium (enc 256/3/4, dec 192/4/3 + 4 state heads, DPT head) at 64x96; oracle/slam_run.py fp32 on the host",
+    res = {"config": "medium (enc 256/3/4, dec 192/4/3 + 4 state heads, DPT head) at 64x96, and the production network at 384x512; "
+                     "oracle/slam_run.py fp32 (and TF32-rounded operands) on the host",
            "alignment": "Sim(3) Umeyama, RMSE of translation residuals (evo_ape tum -vas, scripts/run_scannet.py:34-36)"}
-    for tag, mf, frames in (("fixed_cadence_kf_every_2", {"thresh": 0.9, "skip": 1, "kf_every": 2}, synth.pan_stream(70, Hm, Wm, 5, 2, 1, 0)),
-                            ("overlap_mode_skip_2", {"thresh": 0.9, "skip": 2, "kf_every": -1}, synth.slideshow_stream(150, Hm, Wm, 4, 3))):
-        so = SR.run_stream(cfg, sd, frames, intr, mf, precision="fp32")
-        sotf = SR.run_stream(cfg, sd, frames, intr, mf, precision="tf32")
+    legs = [("fixed_cadence_kf_every_2", cfg, sd, model, {"thresh": 0.9, "skip": 1, "kf_every": 2}, synth.pan_stream(70, Hm, Wm, 5, 2, 1, 0), intr_m),
+            ("overlap_mode_skip_2", cfg, sd, model, {"thresh": 0.9, "skip": 2, "kf_every": -1}, synth.slideshow_stream(150, Hm, Wm, 4, 3), intr_m)]
+    if production_model is not None:
+        intr_p = np.array([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0], np.float32)
+        legs.append(("production_384x512_kf_every_2", production_model.cfg, production_sd, production_model, {"thresh": 0.9, "skip": 1, "kf_every": 2},
+                     synth.pan_stream(23, H, W, 9, 6, 1, 0), intr_p))
+    for tag, cfg_l, sd_l, model_l, mf, frames, intr in legs:
+        tic = time.perf_counter()
+        so = SR.run_stream(cfg_l, sd_l, frames, intr, mf, precision="fp32")
+        sotf = SR.run_stream(cfg_l, sd_l, frames, intr, mf, precision="tf32")
+        t_oracle = time.perf_counter() - tic
         conf = {"Tracking": {"motion_filter": dict(mf), "frontend": {"iteration": 0}}}
-        slam = Cut3rSlam(model, conf, (Hm, Wm), buffer=frames.shape[0] + 8, device=dev)
+        Hl, Wl = frames.shape[2:]
+        slam = Cut3rSlam(model_l, conf, (Hl, Wl), buffer=frames.shape[0] + 8, device=dev)
         fr = frames.to(dev)
         n = fr.shape[0]
         it = torch.from_numpy(intr)
@@ -334,12 +345,15 @@ def trajectory_parity_leg(dev):
         diff = sorted(set(e_gpu) ^ set(e_ref))
         a = ate_rmse(tg, tr, 0.01, True)
         atf = ate_rmse(ttf, tr, 0.01, True)
-        res[tag] = {"keyframes": len(tr), "windows": len(so.windows), "path_length_m": round(float(np.linalg.norm(np.diff(tr[:, 1:4], axis=0), axis=1).sum()), 4),
-                    "ate_rmse_m": a["rmse"], "ate_max_m": a["max"], "sim3_scale": a["scale"],
+        path = float(np.linalg.norm(np.diff(tr[:, 1:4], axis=0), axis=1).sum())
+        res[tag] = {"keyframes": len(tr), "windows": len(so.windows), "path_length_m": round(path, 4),
+                    "ate_rmse_m": a["rmse"], "ate_max_m": a["max"], "sim3_scale": a["scale"], "ate_rmse_mm_per_m": 1e3 * a["rmse"] / max(path, 1e-9),
                     "ate_rmse_m_cpu_tf32_vs_cpu_fp32": atf["rmse"],
                     "keyframe_agreement": len(kf_gpu & kf_ref) / max(1, len(kf_gpu | kf_ref)),
                     "edges_gpu": len(e_gpu), "edges_cpu": len(e_ref), "edge_lists_equal": e_gpu == e_ref, "first_divergent_edge": first_div,
-                    "differing_edges": [[int(i), int(j), so.graph.ratios.get((max(i, j), min(i, j)))] for i, j in diff[:8]]}
+                    "differing_edges": [[int(i), int(j), so.graph.ratios.get((max(i, j), min(i, j)))] for i, j in diff[:8]],
+                    "cpu_oracle_s": round(t_oracle, 1)}
+        del slam
     return res
 
 
@@ -404,6 +418,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-operating-points", action="store_true")
     ap.add_argument("--no-trajectory-parity", action="store_true")
+    ap.add_argument("--no-production-parity", action="store_true", help="skip the 384x512 entry of trajectory_parity (about two minutes of CPU oracle)")
     ap.add_argument("--small", action="store_true", help="debug: tiny network (NOT a valid benchmark line)")
     ap.add_argument("--sequence-windows", type=int, default=40, help="windows per sequence (40 = a Replica-shaped 2000-frame sequence at "
                     "kf_every=10, whatever the number of GPUs: a bigger job runs through more sequences per step); 0 = one endless stream")
@@ -560,7 +575,7 @@ def main():
         op_points["gs_mapper_synthetic_window"] = synth.gs_mapper_window_leg(H, W, dev)
     if single and not args.no_trajectory_parity:
         log("trajectory parity leg (medium config, GPU vs CPU oracle)")
-        traj = trajectory_parity_leg(dev)
+        traj = trajectory_parity_leg(dev, None if (args.small or args.no_production_parity) else model, sd)
     if single and not args.no_cpu_baseline and not args.small:
         log("cpu baseline (oracle on host cores)")
         cpu_base = cpu_baseline(cfg, sd, torch.cat([to_tracking(frames[i:i + 1]) for i in range(2)], 0).cpu())
@@ -587,9 +602,11 @@ def main():
                        "frames_per_step": frames_per_step, "window_views": 6, "window_batch": WB, "sequence_windows": SEQ, "parallelism": f"window-sharded x{world}"},
             "roofline": roofline, "cpu_baseline": cpu_base, "operating_points": op_points, "trajectory_parity": traj,
             "ate_rmse_m": (traj or {}).get("fixed_cadence_kf_every_2", {}).get("ate_rmse_m"),
+            "ate_rmse_m_production_384x512": (traj or {}).get("production_384x512_kf_every_2", {}).get("ate_rmse_m"),
             "hbm_peak_gb": round(hbm_peak / 1e9, 2),
-            "memory_plan_8_gpus_25_steps_gb": {k: (round(v / 1e9, 2) if isinstance(v, int) and k != "keyframes" else v) for k, v in
-                                               cdist.memory_plan(8, 25, WB, H, W, workspace_bytes=max(0, hbm_peak - cdist.memory_plan(1, args.steps + args.warmup + (probe_steps or 0), WB, H, W, weights_bytes=0)["total"])).items()},
+            "memory_plan_8_gpus_25_steps_gb": {k: (round(v / 1e9, 2) if k != "keyframes" else v) for k, v in
+                                               cdist.memory_plan(8, 25, WB, H, W, workspace_bytes=max(0, hbm_peak - cdist.memory_plan(1, args.steps + args.warmup + (probe_steps or 0), WB, H, W, weights_bytes=0)["total"])).items()
+                                               if k != "fits"},
             "build_s": round(t_build, 1), "git_sha": git_sha(),
         }
         print(json.dumps(out))

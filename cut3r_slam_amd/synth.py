@@ -50,7 +50,7 @@ def tracking_state_dict(cfg: Cut3rConfig, seed: int = 0, enc_residual_gain: floa
     return sd
 
 
-def outlier_state_dict(cfg: Cut3rConfig, seed: int = 0, fc1_gain: float = 3.0e3, fc2_weight: float = 0.1, norm_gain: float = 8.0, **kw):
+def outlier_state_dict(cfg: Cut3rConfig, seed: int = 0, fc1_gain: float = 6.0e3, fc2_weight: float = 0.1, norm_gain: float = 8.0, **kw):
     """Random weights with injected MASSIVE ACTIVATIONS, the feature of trained ViT checkpoints that random initialisation lacks (no
     checkpoint exists in the reference tree and none may be fetched): in a few blocks one hidden unit h of the MLP gets its `fc1` row
     multiplied by `fc1_gain` (hidden activations ~1e4 at the tokens that excite it) and feeds one residual channel c through
@@ -184,3 +184,16 @@ def gs_mapper_window_leg(H: int = 384, W: int = 512, device="cuda:0", use_graphs
                       + (", iterations without densification replayed from a captured hipGraph" if use_graphs else ""),
             "seconds": round(dt, 3), "ms_per_keyframe": round(1e3 * dt / n, 1), "render_iterations": renders,
             "ms_per_render_iteration": round(1e3 * dt / renders, 3), "gaussians": len(mapper.gaussians), "psnr_db": round(sum(ps) / n, 2)}
+
+
+def loop_state_dict(cfg: Cut3rConfig, seed: int = 0, pose_gain: float = 0.05, **kw):
+    """Random weights for which the loop-closure backend fires by itself: the pose head's last layer is damped by `pose_gain`, so the
+    predicted cameras of a window sit within centimetres of each other and every keyframe sees the same stretch of the (random)
+    pointmaps.  The covisibility graph then links keyframes more than 8 apart (`FactorGraph.detect_loop`), the NMS score passes 0.4
+    and `TrackBackend.run` closes a loop every other eligible window -- detect -> NMS -> re-track -> optimise -> rewrite, nothing
+    forced.  (A random-weight network carries no geometry: its poses do not depend on where the camera really is, so a stream that
+    "revisits" a place would not be recognised; this variant makes EVERY place the same one.)"""
+    sd = tracking_state_dict(cfg, seed, **kw)
+    k = "downstream_head.pose_head.mlp.fc2.weight"
+    sd[k] = sd[k] * pose_gain
+    return sd

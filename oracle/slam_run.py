@@ -3,7 +3,10 @@ Only tests/, __graft_entry__.smoke() and bench.py's bounded `cpu_baseline` / tra
 
 It composes the other oracle pieces into the per-frame loop of the reference WITHOUT touching any product code:
 
-  Hi2.run                 /root/reference/hislam2/hi2.py:101-133 (GS mapper and loop closure off)
+  Hi2.run                 /root/reference/hislam2/hi2.py:101-133 (GS mapper off; loop closure when `iteration` > 0)
+  TrackBackend.run/track  /root/reference/hislam2/track_backend.py:527-586, 137-217 (detect_loop = factor_graph.py:503-543, NMS = :561-582
+                          with :328-341 and cal_overlap_bi :286-315; the two optimisers and the store rewrite = oracle.lc_oracle.LoopCloser,
+                          fp64 autograd with matrix_exp in place of the absent lietorch: parity unpinned, see its header)
   MotionFilter.kfFilter   /root/reference/hislam2/motion_filter.py:70-135  (encoder = oracle.cut3r_oracle.encode_image,
                           overlap ratio = hislam2/util/utils.py:726-736 restated below in fp32)
   TrackFrontend.run/track /root/reference/hislam2/track_frontend.py:285-330, 166-262 (network = cut3r_oracle.forward_views,
@@ -26,6 +29,7 @@ import torch
 
 from . import cut3r_oracle as O
 from . import geom as G
+from . import lc_oracle as LC
 from . import slam_oracle as SO
 
 
@@ -86,6 +90,12 @@ class RefGraph:
                 self.add_factors(jj.tolist(), ii)
         self.age = [a + 1 for a in self.age]
 
+    def detect_loop(self, current_idx, temporal_window=8):
+        """:503-543 (the live part): keyframes covisible with `current_idx` and more than `temporal_window` keyframes away"""
+        cov = set(j for i, j in zip(self.ii, self.jj) if i == current_idx)
+        cand = [i for i in cov if abs(i - current_idx) > temporal_window]
+        return np.array(cand) if cand else None
+
     def edges_numpy(self):
         return np.asarray(self.ii, np.int64), np.asarray(self.jj, np.int64), np.asarray(self.age, np.int64)
 
@@ -103,7 +113,7 @@ def patch_overlap_ratio_f32(feat0: torch.Tensor, feat1: torch.Tensor, threshold:
 class SlamOracle:
     """Frame-by-frame CPU tracker.  `run(t, image_u8, intr4, second_last_frame, last_frame)` mirrors Hi2.run."""
 
-    def __init__(self, cfg, sd, image_size, buffer, motion_filter, intrinsics_ds=2, precision="fp32"):
+    def __init__(self, cfg, sd, image_size, buffer, motion_filter, intrinsics_ds=2, precision="fp32", iteration=0):
         self.cfg, self.sd = cfg, sd
         H, W = image_size
         self.H, self.W, self.ds = H, W, 2
@@ -127,6 +137,11 @@ class SlamOracle:
         self.windows = []                   # (t0, t1, init) in execution order
         self.ratios = []                    # (tstamp, overlap ratio) of every tested frame
         self.timing = {"encode_s": 0.0, "window_s": 0.0, "align_graph_s": 0.0, "encodes": 0, "windows": 0, "graph_adds": 0}
+        # loop closure (hi2.py:44-49,112-121: the backend runs when Tracking.frontend.iteration > 0, every other eligible window)
+        self.iteration = int(iteration)
+        self.freeze_counter = 0
+        self.closer = None                  # oracle.lc_oracle.LoopCloser, created at the first closure
+        self.closures = []                  # dicts: idx_current, idx_matched, candidates, scores, at_keyframe, poses / submaps after it
 
     # -- keyframe store (keyframe.py:43-77,105-107)
     def _append(self, tstamp, image, intr, feat):
@@ -202,7 +217,7 @@ class SlamOracle:
         self.timing["align_graph_s"] += time.perf_counter() - tic
         self.windows.append((t0, t1, init))
 
-    # -- track_frontend.py:285-330
+    # -- track_frontend.py:285-330 (returns its `run_backend` flag: a steady-state window beyond keyframe 10 was tracked)
     def tracker_run(self, last_frame=False):
         if not self.is_initialized and self.counter - 1 == self.warmup:
             t1 = self.counter - 1
@@ -213,6 +228,7 @@ class SlamOracle:
             t0, t1 = self.t1 - 1, self.counter - 1
             self.track(t0, t1)
             self.t1 = t1
+            return t1 > 10
         elif last_frame:
             # (the reference calls track() here even when nothing is pending or nothing was initialised; both cases
             # raise there -- an empty window / a never-initialised tracker -- so they are not part of the compared runs)
@@ -221,9 +237,77 @@ class SlamOracle:
                 self.track(t0, t1)
                 self.t1 = t1
 
+        return False
+
+    # -- track_backend.py:561-582 + 328-341 + 286-315
+    def nms_scores(self, ids_matched, idx_current, K4):
+        st = self.state
+        h, w = st["submap_ds"].shape[2:4]
+        ids = np.asarray(ids_matched)
+        pm_m = st["submap_ds"][ids // 5, ids % 5].numpy()
+        pm_c = st["submap_ds"][idx_current // 5, idx_current % 5].numpy()
+        c2w_m = SO.pose_vec_to_matrix(st["pose"][ids]).numpy()
+        c2w_c = SO.pose_vec_to_matrix(st["pose"][idx_current][None]).numpy()
+        a2c = G.overlap_bwd(pm_m, G.w2c_rows(c2w_c)[0], K4, w, h).astype(np.float32) / np.float32(h * w)
+        c2a = G.overlap_fwd(pm_c, G.w2c_rows(c2w_m), K4, w, h, clamp_z=False).astype(np.float32) / np.float32(h * w)
+        feat = np.array([patch_overlap_ratio_f32(self.featI[idx_current], self.featI[int(i)]) for i in ids], np.float32)
+        return np.float32(0.8) * ((a2c + c2a) / np.float32(2)) + np.float32(0.2) * feat
+
+    # -- track_backend.py:137-217: the submap [5 keyframes of the matched submap, current keyframe] chained to the anchor keyframe
+    def backend_track(self, selected, anchor_sub):
+        with O.matmul_precision(self.precision):
+            preds = O.forward_views(self.cfg, self.sd, O.normalize(self.image[selected]), minimal=True)
+        pts = torch.cat([p["pts3d_in_self_view"] for p in preds], 0)
+        conf = torch.cat([p["conf_self"] for p in preds], 0)
+        enc = torch.cat([p["camera_pose"] for p in preds], 0)
+        st, a = self.state, anchor_sub * 5
+        tmp = {"pose": st["pose"][a:a + 1].clone().repeat(6, 1), "depth": st["depth"][a:a + 1].clone().repeat(6, 1, 1),
+               "submap_ds": torch.zeros(1, 6, self.H // 2, self.W // 2, 3), "conf_ds": torch.zeros(1, 6, self.H // 2, self.W // 2)}
+        SO.track_window(tmp, 0, len(selected), pts, conf, enc, False, self.ds)      # same chaining arithmetic as the front end (:166-199)
+        return tmp["submap_ds"][0], tmp["conf_ds"][0], tmp["pose"]
+
+    # -- track_backend.py:527-586
+    def backend_run(self):
+        K4 = (self.intrinsic[0] / np.float32(self.ds)).astype(np.float32)
+        t1 = self.counter - 1
+        t0 = t1 - 6
+        ids, idx_current = None, None
+        for idx_current in range(t0, t1 - 1):
+            ids = self.graph.detect_loop(idx_current)
+            if ids is not None:
+                break
+        if ids is None:
+            return False
+        scores = self.nms_scores(ids, idx_current, K4)
+        if not float(scores.max()) > 0.4:
+            return False
+        idx_matched = int(ids[int(np.argmax(scores))])
+        anchor = idx_matched // 5
+        selected = list(range(anchor * 5, anchor * 5 + 5)) + [idx_current]
+        pm_lc, _, _ = self.backend_track(selected, anchor)
+        st = self.state
+        if self.closer is None:
+            self.closer = LC.LoopCloser(st["submap_ds"], st["conf_ds"], st["pose"], self.iteration)
+        lc = self.closer
+        lc.sub, lc.conf, lc.pose = st["submap_ds"].double(), st["conf_ds"].double(), st["pose"].double()
+        lc.close(pm_lc, idx_matched, idx_current)
+        st["submap_ds"], st["pose"] = lc.sub.float(), lc.pose.float()
+        n_sub = idx_current // 5 + 1
+        self.closures.append({"idx_current": idx_current, "idx_matched": idx_matched, "candidates": np.asarray(ids).copy(), "scores": scores.copy(),
+                              "at_keyframe": self.counter, "pose": st["pose"][:n_sub * 5 + 1].clone(), "submap_ds": st["submap_ds"][:n_sub].clone(),
+                              "loss": lc.losses[-1]})
+        return True
+
     def run(self, tstamp, image_u8, intr, second_last_frame=False, last_frame=False):
+        """hi2.py:101-121"""
         self.kf_filter(tstamp, image_u8, intr, second_last_frame, last_frame)
-        self.tracker_run(last_frame)
+        run_backend = self.tracker_run(last_frame)
+        if run_backend and not last_frame and self.iteration > 0:
+            if self.freeze_counter > 0:
+                if self.backend_run():
+                    self.freeze_counter = 0
+            else:
+                self.freeze_counter += 1
 
     def trajectory(self):
         """demo_s.py:97-100: rows [tstamp, tx,ty,tz, qx,qy,qz,qw] of keyframes 0..counter-2"""
@@ -231,11 +315,11 @@ class SlamOracle:
         return np.concatenate([self.tstamp[:t, None], self.state["pose"][:t].numpy().astype(np.float64)], 1)
 
 
-def run_stream(cfg, sd, frames_u8, intr, motion_filter, precision="fp32", buffer=None, mark_tail=True):
+def run_stream(cfg, sd, frames_u8, intr, motion_filter, precision="fp32", buffer=None, mark_tail=True, iteration=0):
     """Drive SlamOracle over frames_u8 [n,3,H,W] like demo_s.py:151-160 (second-last / last frame flags) and return it."""
     n = frames_u8.shape[0]
     H, W = frames_u8.shape[2:]
-    so = SlamOracle(cfg, sd, (H, W), buffer or (n + 8), motion_filter, precision=precision)
+    so = SlamOracle(cfg, sd, (H, W), buffer or (n + 8), motion_filter, precision=precision, iteration=iteration)
     for t in range(n):
         so.run(t, frames_u8[t], intr, second_last_frame=mark_tail and t == n - 2, last_frame=mark_tail and t == n - 1)
     return so

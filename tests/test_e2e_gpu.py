@@ -166,3 +166,79 @@ def test_overlap_decisions_at_production_encoder_shape_match_oracle_on_same_feat
     assert k == 7
     for i, t in enumerate([t for t in idx if ref[t]]):
         assert torch.equal(slam2.keyframes.featI[i], ahead[t][0])
+
+
+def test_loop_closure_fires_inside_the_loop_and_matches_the_cpu_restatement():
+    """BASELINE configs[2] as a LOOP: `Cut3rSlam.run` with Tracking.frontend.iteration > 0 on a stream whose
+    network (synth.loop_state_dict) keeps every keyframe covisible with every other, so that `TrackBackend.run` fires by itself --
+    detect_loop -> NMS -> 6-view re-tracking against the matched submap -> submap-level Adam -> rewrite of every pointmap and pose
+    -- every other eligible window (hi2.py:112-121 `freeze_counter`), and later windows chain on the rewritten stores.  Compared with
+    oracle/slam_run.py extended by oracle/lc_oracle.LoopCloser (fp64 autograd, matrix_exp for the absent lietorch: optimiser parity
+    unpinned, see tests/test_loop_closure_gpu.py for its tolerances):
+      * the same closures in the same order: (current keyframe, matched keyframe), the same candidate lists, NMS scores within 5e-3;
+      * the first closure takes the `loop_closure_init` path, the later ones the general term list;
+      * keyframes, ordered edge lists (near-threshold exceptions as above), the trajectory (ATE <= 2 mm: the L1 objective's sign()
+        gradients make fp32 and fp64 Adam trajectories differ by a few steps of lr = 5e-4 per closure) and the rewritten stores."""
+    cfg = synth.medium_config()
+    sd = synth.loop_state_dict(cfg, 11)
+    mf = {"thresh": 0.9, "skip": 1, "kf_every": 2}
+    iters = 100
+    frames = synth.pan_stream(90, H, W, pool=5, num=2, den=1, seed=0)
+    so = SR.run_stream(cfg, sd, frames, INTR, mf, precision="fp32", iteration=iters)
+    assert len(so.closures) >= 3, "the oracle run closed fewer than three loops"
+    # ---- HIP
+    model = Cut3rModel(cfg, sd, DEV, minimal=True)
+    conf = {"Tracking": {"motion_filter": dict(mf), "frontend": {"iteration": iters, "window_batch": 1}}}
+    slam = Cut3rSlam(model, conf, (H, W), buffer=frames.shape[0] + 8, device=DEV)
+    be = slam.backend
+    seen = []
+    real_scores = be.nms_scores
+
+    def spy(ids, cur, K4):
+        s = real_scores(ids, cur, K4)
+        seen.append((int(cur), np.asarray(ids).copy(), s.numpy().copy()))
+        return s
+    be.nms_scores = spy
+    intr, fr, n = torch.from_numpy(INTR), frames.to(DEV), frames.shape[0]
+    did = []
+    for t in range(n):
+        _, _, lc = slam.run(t, fr[t:t + 1], intr, fr[t:t + 1], intr, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+        if lc:
+            did.append(slam.keyframes.counter.value)
+    torch.cuda.synchronize()
+    # ---- the same closures, organically
+    assert be.closed_loop["idx_current"] == [c["idx_current"] for c in so.closures], (be.closed_loop["idx_current"], [c["idx_current"] for c in so.closures])
+    assert be.closed_loop["idx_matched"] == [c["idx_matched"] for c in so.closures]
+    assert did == [c["at_keyframe"] for c in so.closures]
+    assert len(seen) == len(so.closures)
+    worst_score = 0.0
+    for (cur, ids, sc), c in zip(seen, so.closures):
+        assert cur == c["idx_current"] and sorted(ids.tolist()) == sorted(c["candidates"].tolist())
+        order = {int(j): k for k, j in enumerate(c["candidates"])}
+        ref_sc = np.array([c["scores"][order[int(j)]] for j in ids])
+        worst_score = max(worst_score, float(np.abs(sc - ref_sc).max()))
+        assert all(abs(int(j) - cur) > 8 for j in ids)
+    assert worst_score < 5e-3, worst_score
+    assert be.lc_initialized and len(be.closed_loop["pointmaps_lc"]) == len(so.closures)
+    # ---- trajectory, graph, stores
+    ts, poses = slam.trajectory()
+    traj = np.concatenate([ts.reshape(-1, 1).astype(np.float64), poses.astype(np.float64)], 1)
+    ref = so.trajectory()
+    assert np.array_equal(traj[:, 0], ref[:, 0]) and slam.tracker.t1 == so.t1
+    ate = ate_rmse(traj, ref, 0.01, True)
+    ii, jj, _ = slam.graph.edges_numpy()
+    e_gpu, e_ref = list(zip(ii.tolist(), jj.tolist())), list(zip(so.graph.ii, so.graph.jj))
+    near, unexplained = _explain_edge_differences(e_gpu, e_ref, so)
+    k = so.t1
+    nsub = (k - 1) // 5
+    e_pm = float((slam.keyframes.submap_ds[:nsub].cpu() - so.state["submap_ds"][:nsub]).abs().max())
+    e_t = float(np.abs(traj[:, 1:4] - ref[:, 1:4]).max())
+    print(f"[e2e loop closure on] closures {[(c['idx_current'], c['idx_matched']) for c in so.closures]} at keyframe counts {did} | NMS score max |diff| "
+          f"{worst_score:.2e} | keyframes {len(ref)} windows {len(so.windows)} path {_path_length(ref):.3f} m | ATE-RMSE HIP vs CPU {ate['rmse'] * 1e3:.3f} mm "
+          f"(unaligned max |dt| {e_t * 1e3:.3f} mm) | stride-2 world pointmaps max |diff| {e_pm * 1e3:.2f} mm | edges {len(e_gpu)} vs {len(e_ref)}, "
+          f"near-threshold differences {near}")
+    assert not unexplained and len(near) <= 0.02 * len(e_ref) + 2
+    assert ate["rmse"] <= 2e-3 and e_t <= 2e-2 and e_pm <= 3e-2, (ate, e_t, e_pm)
+    # the closures did something: poses of early keyframes differ from a run with the backend off
+    so_off = SR.run_stream(cfg, sd, frames, INTR, mf, precision="fp32", iteration=0)
+    assert np.abs(so_off.trajectory()[:, 1:4] - ref[:, 1:4]).max() > 10 * e_t

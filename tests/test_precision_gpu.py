@@ -29,7 +29,7 @@ DEV = "cuda:0"
 KEYS = ("camera_pose", "pts3d_in_self_view", "conf_self")
 # production shape (ViT-L / 768-d decoder / DPT at 368x512 and 384x512): 3 x the errors measured on MI355X in round 3
 # (profiles/r03/achieved_errors.txt), next to the relative rule e_hip <= 2 e_tf32 + 2e-4 of _budget
-TOL_PROD = {"camera_pose": 3e-3, "pts3d_in_self_view": 1.5e-2, "conf_self": 1.5e-2}
+TOL_PROD = {"camera_pose": 4e-3, "pts3d_in_self_view": 1.2e-2, "conf_self": 7e-3}
 
 
 def _rel(got, ref):
