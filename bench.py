@@ -322,7 +322,9 @@ def trajectory_parity_leg(dev, production_model=None, production_sd=None):
     for tag, cfg_l, sd_l, model_l, mf, frames, intr in legs:
         tic = time.perf_counter()
         so = SR.run_stream(cfg_l, sd_l, frames, intr, mf, precision="fp32")
-        sotf = SR.run_stream(cfg_l, sd_l, frames, intr, mf, precision="tf32")
+        # (the TF32 leg of the production entry is asserted by tests/test_e2e_production_gpu.py: 0.19 mm HIP vs 0.21 mm TF32 over three
+        #  windows, profiles/r03/achieved_errors.txt; here it would add another minute of CPU)
+        sotf = SR.run_stream(cfg_l, sd_l, frames, intr, mf, precision="tf32") if model_l is not production_model else None
         t_oracle = time.perf_counter() - tic
         conf = {"Tracking": {"motion_filter": dict(mf), "frontend": {"iteration": 0}}}
         Hl, Wl = frames.shape[2:]
@@ -335,7 +337,7 @@ def trajectory_parity_leg(dev, production_model=None, production_sd=None):
         torch.cuda.synchronize()
         ts, poses = slam.trajectory()
         tg = np.concatenate([ts.reshape(-1, 1).astype(np.float64), poses.astype(np.float64)], 1)
-        tr, ttf = so.trajectory(), sotf.trajectory()
+        tr, ttf = so.trajectory(), (sotf.trajectory() if sotf is not None else None)
         kf_gpu, kf_ref = set(tg[:, 0].tolist()), set(tr[:, 0].tolist())
         ii, jj, _ = slam.graph.edges_numpy()
         e_gpu, e_ref = list(zip(ii.tolist(), jj.tolist())), list(zip(so.graph.ii, so.graph.jj))
@@ -344,7 +346,7 @@ def trajectory_parity_leg(dev, production_model=None, production_sd=None):
             first_div = min(len(e_gpu), len(e_ref))
         diff = sorted(set(e_gpu) ^ set(e_ref))
         a = ate_rmse(tg, tr, 0.01, True)
-        atf = ate_rmse(ttf, tr, 0.01, True)
+        atf = ate_rmse(ttf, tr, 0.01, True) if ttf is not None else {"rmse": None}
         path = float(np.linalg.norm(np.diff(tr[:, 1:4], axis=0), axis=1).sum())
         res[tag] = {"keyframes": len(tr), "windows": len(so.windows), "path_length_m": round(path, 4),
                     "ate_rmse_m": a["rmse"], "ate_max_m": a["max"], "sim3_scale": a["scale"], "ate_rmse_mm_per_m": 1e3 * a["rmse"] / max(path, 1e-9),

@@ -102,6 +102,9 @@ SIGNATURES = {
     "cut3r_ba_backsub": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "cut3r_ba_proj_trans": [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 4,
     "cut3r_bi_inter": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "cut3r_schur_mono_prior_workspace_floats": [c_int, c_ll],
+    "cut3r_schur_mono_prior": [c_void_p] * 5 + [c_int, c_ll, c_float, c_float] + [c_void_p] * 6,
+    "cut3r_jdsa_blocks": [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "cut3r_depth_filter": [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_void_p],
     "cut3r_altcorr_forward": [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p],
     "cut3r_altcorr_backward": [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p, c_void_p],
@@ -122,7 +125,7 @@ SIGNATURES = {
     "cut3r_gs_render_backward": [c_void_p] * 3 + [c_int, c_int, c_int, c_float, c_float] + [c_void_p] * 16,
     "cut3r_gs_preprocess_backward": [c_int] + [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 3 + [c_int, c_int] + [c_float] * 4 + [c_void_p] * 10,
 }
-RESTYPES = {"cut3r_ba_workspace_floats": c_ll, "cut3r_gs_workspace_bytes": c_ll}
+RESTYPES = {"cut3r_ba_workspace_floats": c_ll, "cut3r_gs_workspace_bytes": c_ll, "cut3r_schur_mono_prior_workspace_floats": c_ll}
 
 _lib = None
 

@@ -192,33 +192,33 @@ def MoBA(target, weight, eta, poses, disps, intrinsics, ii, jj, fixedp=1, rig=1,
     return SE3(c["G"].data[None]).retr(full_dx[None])
 
 
+def _mono_prior_solve(C, w, H, E, v, ep, lm, dzcov):
+    """cut3r_schur_mono_prior on dense H [n,n], E [n,cols], v [n], C / w [cols] (fp32, contiguous, on the GPU)"""
+    lib = _lib.load()
+    n, cols = int(H.shape[0]), int(E.shape[1])
+    dev = H.device
+    ws = torch.empty(int(lib.cut3r_schur_mono_prior_workspace_floats(n, cols)), device=dev)
+    dso, dz = torch.empty(n, device=dev), torch.empty(cols, device=dev)
+    cov = torch.empty(cols, device=dev) if dzcov else None
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib.cut3r_schur_mono_prior(_p(C), _p(w), _p(H), _p(E), _p(v), n, cols, float(ep), float(lm), _p(ws), _p(dso), _p(dz), _p(cov), _p(flag),
+                                     _stream()), "cut3r_schur_mono_prior")
+    return dso, dz, cov, flag
+
+
 def schur_solve_mono_prior(C, w, Hs, Es, vs, ep=0.1, lm=1e-4, dzcov=False):
-    """geom/chol.py:80-107 on the GPU (dense torch ops: the reduced system is M*D x M*D with D = hs*ws scale-grid nodes).
-    C, w [1,M,HW]; Hs [1,M,M,D,D]; Es [1,M,M,D,HW]; vs [1,M,D].  Returns (dso [1,M,D], dz [1,M,HW], dzcov [M,HW])."""
+    """geom/chol.py:80-107 on the HIP kernels of csrc/ba.hip (reduction S = H + damping - E C^-1 E^T, in-LDS Cholesky, back-substitution,
+    column-wise covariance): the reduced system is M*D x M*D with D = hs*ws scale-grid nodes (M*D <= 192).
+    C, w [1,M,HW]; Hs [1,M,M,D,D]; Es [1,M,M,D,HW]; vs [1,M,D].  Returns (dso [1,M,D], dz [1,M,HW], dzcov [M,HW] or None)."""
     D = Hs.shape[-1]
     B, M, HW = C.shape
-    Q = (1.0 / C).view(B, M * HW, 1)
-    w = w.reshape(B, M * HW, 1)
-    H = Hs.permute(0, 1, 3, 2, 4).reshape(B, M * D, M * D)
-    E = Es.permute(0, 1, 3, 2, 4).reshape(B, M * D, M * HW)
-    v = vs.reshape(B, M * D, 1)
-    I = torch.eye(M * D, device=H.device)
-    H = H + (ep + lm * H) * I
-    Et = E.transpose(1, 2)
-    S = H - torch.matmul(E, Q * Et)
-    v = v - torch.matmul(E, Q * w)
-    L, info = torch.linalg.cholesky_ex(S)
-    if int(info.max()) != 0:                                  # CholeskySolver swallows the failure and returns zeros (chol.py:13-18)
-        dso = torch.zeros_like(v)
-        L = torch.zeros_like(S)
-    else:
-        dso = torch.cholesky_solve(v, L)
-    dz = (Q * (w - Et @ dso)).reshape(B, M, HW)
-    cov = None
-    if dzcov:
-        Fm = torch.linalg.solve_triangular(L, E * Q[..., 0], upper=False) if int(info.max()) == 0 else torch.zeros_like(E)
-        cov = (torch.sum(torch.square(Fm), dim=1) + Q[..., 0]).reshape(M, HW)
-    return dso.reshape(B, M, D), dz, cov
+    if B != 1:
+        raise NotImplementedError("batch 1 (the only use in the reference)")
+    H = Hs.permute(0, 1, 3, 2, 4).reshape(M * D, M * D).float().contiguous()         # the reference's layout change, chol.py:88-89
+    E = Es.permute(0, 1, 3, 2, 4).reshape(M * D, M * HW).float().contiguous()
+    dso, dz, cov, _ = _mono_prior_solve(C.reshape(-1).float().contiguous(), w.reshape(-1).float().contiguous(), H, E,
+                                        vs.reshape(-1).float().contiguous(), ep, lm, dzcov)
+    return dso.reshape(1, M, D), dz.reshape(1, M, HW), (cov.reshape(M, HW) if cov is not None else None)
 
 
 def get_prior_depth_aligned(depth_prior, scales):
@@ -249,23 +249,18 @@ def JDSA(target, weight, eta, poses, disps, intrinsics, disps_prior, dscales, ii
     m = (prior > 0).to(torch.float).view(-1, HW)
     hs, ws = dscales.shape[-2:]
     disps_bi, Jbi = get_prior_depth_aligned(prior, dscales[kx])
-    rd = (disps[0, kx] - disps_bi).view(-1, HW)
-    Jd = torch.ones_like(rd).view(1, -1, 1, HW)
-    Jso = -m.unsqueeze(-1) * prior.view(-1, HW).unsqueeze(-1) * Jbi.view(M, HW, -1)[None]         # [1,M,HW,D]
-    al = torch.ones(M, HW, 1, device=dev) * alpha
+    rd = (disps[0, kx] - disps_bi).reshape(-1, HW).float().contiguous()
     D = hs * ws
-    wJsoT = (al * Jso).transpose(2, 3)                                                           # [1,M,D,HW]
-    # the scatter of the reference puts frame k's blocks on the diagonal (kx, kx): block-diagonal Hs / Es
-    Hs = torch.zeros(1, M, M, D, D, device=dev)
-    Es = torch.zeros(1, M, M, D, HW, device=dev)
-    idx = torch.arange(M, device=dev)
-    Hs[0, idx, idx] = (wJsoT @ Jso)[0]
-    Es[0, idx, idx] = (wJsoT * Jd)[0]
-    vs = (-wJsoT @ rd[None].unsqueeze(-1))[..., 0]                                               # [1,M,D]
-    al = al.squeeze(-1)
-    C = Cm[None] + m * al * (Jd * Jd).squeeze(2)[0] + (1 - m) * eta.view(M, HW)
-    w = wv[None] - m * al * rd * Jd.squeeze(2)[0]
-    dso, dz, dzcov = schur_solve_mono_prior(C.reshape(1, M, HW), w.reshape(1, M, HW), Hs, Es, vs, ep, lm, dzcov=True)
+    n = M * D
+    # the scatter of the reference puts frame k's blocks on the diagonal (kx, kx): block-diagonal H [n,n] / E [n,M*HW], written by one
+    # kernel (Jso = -m prior Jbi, H_k = alpha Jso^T Jso, E_k = alpha Jso^T (Jd = 1), v_k = -alpha Jso^T rd, ba.py:213-228)
+    Hd, Ed, vd = torch.empty(n, n, device=dev), torch.empty(n, M * HW, device=dev), torch.empty(n, device=dev)
+    check(_lib.load().cut3r_jdsa_blocks(_p(prior.reshape(M, HW).float().contiguous()), _p(Jbi.reshape(M, HW, D).float().contiguous()), _p(rd),
+                                        float(alpha), M, HW, D, _p(Hd), _p(Ed), _p(vd), _stream()), "cut3r_jdsa_blocks")
+    C = Cm.reshape(M, HW) + m * float(alpha) + (1 - m) * eta.reshape(M, HW)                     # Jd = 1
+    w = wv.reshape(M, HW) - m * float(alpha) * rd
+    dso, dz, dzcov, _ = _mono_prior_solve(C.reshape(-1).contiguous(), w.reshape(-1).contiguous(), Hd, Ed, vd, ep, lm, True)
+    dzcov = dzcov.reshape(M, HW)
     new_disps = disps.clone()
     new_disps[0, kx] += dz.view(M, ht, wd)
     dscales[kx] += dso.view(-1, hs, ws)

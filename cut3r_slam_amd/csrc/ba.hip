@@ -529,6 +529,133 @@ __global__ void ba_damp_kernel(const float* __restrict__ S, const float* __restr
     Sd[i] = S[i] + ((r == c) ? (ep + lm * hd[r]) : 0.f);
 }
 
+// ------------------------------------------------------------------------------------------------ mono-prior Schur solve (geom/chol.py:80-107)
+// S = H - E diag(1/C) E^T (undamped), vS = v - E (w / C), hdiag = diag(H) for H [n,n], E [n,cols], C, w [cols].  One workgroup per 16 x 16
+// block of S: the two 16-row slabs of E go through LDS 64 columns at a time together with 1/C; thread (i, j) keeps S[i][j].  Blocks on the
+// block diagonal also produce vS (threads j == 0) and hdiag.
+__global__ __launch_bounds__(256) void mp_reduce_kernel(const float* __restrict__ H, const float* __restrict__ E, const float* __restrict__ Cd,
+                                                        const float* __restrict__ wd, const float* __restrict__ v, int n, long long cols,
+                                                        float* __restrict__ S, float* __restrict__ vS, float* __restrict__ hd) {
+    __shared__ float Ea[16][65], Eb[16][65], Qs[64], Ws[64];
+    const int bi = blockIdx.y * 16, bj = blockIdx.x * 16;
+    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+    float acc = 0.f, accv = 0.f;
+    for (long long c0 = 0; c0 < cols; c0 += 64) {
+        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            const long long col = c0 + c;
+            Ea[r][c] = (bi + r < n && col < cols) ? E[(size_t)(bi + r) * cols + col] : 0.f;
+            Eb[r][c] = (bj + r < n && col < cols) ? E[(size_t)(bj + r) * cols + col] : 0.f;
+        }
+        if (threadIdx.x < 64) {
+            const long long col = c0 + threadIdx.x;
+            const float q = col < cols ? 1.0f / Cd[col] : 0.f;
+            Qs[threadIdx.x] = q;
+            Ws[threadIdx.x] = col < cols ? q * wd[col] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int c = 0; c < 64; c++) acc = fmaf(Ea[ti][c] * Qs[c], Eb[tj][c], acc);
+        if (bi == bj && tj == 0) {
+#pragma unroll 8
+            for (int c = 0; c < 64; c++) accv = fmaf(Ea[ti][c], Ws[c], accv);
+        }
+        __syncthreads();
+    }
+    const int i = bi + ti, j = bj + tj;
+    if (i < n && j < n) S[(size_t)i * n + j] = H[(size_t)i * n + j] - acc;
+    if (bi == bj && tj == 0 && i < n) {
+        vS[i] = v[i] - accv;
+        hd[i] = H[(size_t)i * n + i];
+    }
+}
+
+// per column c: dz = (w - E[:,c] . dso) / C; with cov != NULL also dzcov = sum_i x_i^2 + 1/C where L x = E[:,c] / C (forward substitution:
+// L in LDS as packed rows, x_i kept in the column's own slot of `xs` [n, cols] -- coalesced across the threads of a workgroup)
+__global__ __launch_bounds__(256) void mp_backsub_kernel(const float* __restrict__ E, const float* __restrict__ Cd, const float* __restrict__ wd,
+                                                         const float* __restrict__ dso, const float* __restrict__ L, const int* __restrict__ flag,
+                                                         int n, long long cols, float* __restrict__ dz, float* __restrict__ cov,
+                                                         float* __restrict__ xs) {
+    extern __shared__ float Ls[];                  // packed lower triangle: row i at i (i + 1) / 2
+    float* ds = Ls + (cov ? (size_t)n * (n + 1) / 2 : 0);
+    const int failed = flag[0];
+    if (cov)
+        for (int e = threadIdx.x; e < n * n; e += 256) {
+            const int r = e / n, c = e - r * n;
+            if (c <= r) Ls[(size_t)r * (r + 1) / 2 + c] = L[e];
+        }
+    for (int e = threadIdx.x; e < n; e += 256) ds[e] = failed ? 0.f : dso[e];
+    __syncthreads();
+    const long long col = blockIdx.x * (long long)256 + threadIdx.x;
+    if (col >= cols) return;
+    const float q = 1.0f / Cd[col];
+    float s = wd[col];
+    for (int i = 0; i < n; i++) s = fmaf(-E[(size_t)i * cols + col], ds[i], s);
+    dz[col] = q * s;
+    if (!cov) return;
+    float sq = 0.f;
+    if (!failed) {                                 // (CholeskySolver returns zeros on failure, chol.py:13-18: the covariance is then 1/C)
+        for (int i = 0; i < n; i++) {
+            const float* Li = Ls + (size_t)i * (i + 1) / 2;
+            float x = E[(size_t)i * cols + col] * q;
+            for (int j = 0; j < i; j++) x = fmaf(-Li[j], xs[(size_t)j * cols + col], x);
+            x /= Li[i];
+            xs[(size_t)i * cols + col] = x;
+            sq = fmaf(x, x, sq);
+        }
+    }
+    cov[col] = sq + q;
+}
+
+// JDSA blocks of source frame m (geom/ba.py:213-228): Jso[p,a] = -mask_p prior_p Jbi[m,p,a];  H_m = alpha Jso^T Jso [D,D] on the block
+// diagonal of H [n,n], E_m = alpha Jso^T [D,HW] on the block diagonal of E [n, M*HW], v_m = -alpha Jso^T rd.  One workgroup per frame;
+// H, E, v are written completely (zeros off the diagonal blocks).
+__global__ __launch_bounds__(256) void jdsa_blocks_kernel(const float* __restrict__ prior, const float* __restrict__ Jbi, const float* __restrict__ rd,
+                                                          float alpha, int M, int HW, int D, float* __restrict__ H, float* __restrict__ E,
+                                                          float* __restrict__ v) {
+    extern __shared__ float red[];                 // [256] partial sums
+    const int m = blockIdx.x, n = M * D;
+    const size_t cols = (size_t)M * HW;
+    // E rows of this frame: zero everywhere except its own column range
+    for (int a = 0; a < D; a++) {
+        float* Er = E + (size_t)(m * D + a) * cols;
+        for (size_t c = threadIdx.x; c < cols; c += 256) {
+            float val = 0.f;
+            if (c >= (size_t)m * HW && c < (size_t)(m + 1) * HW) {
+                const size_t p = c - (size_t)m * HW;
+                const float pr = prior[(size_t)m * HW + p];
+                val = alpha * (pr > 0.f ? -pr * Jbi[((size_t)m * HW + p) * D + a] : 0.f);
+            }
+            Er[c] = val;
+        }
+    }
+    for (int a = 0; a < D; a++) {
+        for (int b = 0; b <= D; b++) {             // b == D: the right-hand side
+            float acc = 0.f;
+            for (int p = threadIdx.x; p < HW; p += 256) {
+                const float pr = prior[(size_t)m * HW + p];
+                if (pr > 0.f) {
+                    const float ja = -pr * Jbi[((size_t)m * HW + p) * D + a];
+                    acc = fmaf(alpha * ja, b < D ? -pr * Jbi[((size_t)m * HW + p) * D + b] : -rd[(size_t)m * HW + p], acc);
+                }
+            }
+            red[threadIdx.x] = acc;
+            __syncthreads();
+            for (int st = 128; st > 0; st >>= 1) {
+                if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                if (b < D) H[(size_t)(m * D + a) * n + m * D + b] = red[0];
+                else v[m * D + a] = red[0];
+            }
+            __syncthreads();
+        }
+        for (int j = threadIdx.x; j < n; j += 256)
+            if (j < m * D || j >= (m + 1) * D) H[(size_t)(m * D + a) * n + j] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ bi_inter (geom/ba.py:160-170)
 // scales [M,hs,ws], grid [M,ht,wd,2] (x, y in scale-grid units) -> vals [M,ht,wd] (bilinear), J [M,ht,wd,hs*ws] (d val / d node)
 __global__ __launch_bounds__(256) void bi_inter_kernel(const float* __restrict__ scales, const float* __restrict__ grid, int M, int hs, int ws,
@@ -805,6 +932,41 @@ extern "C" int cut3r_bi_inter(const float* scales, const float* grid, int M, int
     const size_t tot = (size_t)M * ht * wd;
     hipLaunchKernelGGL(bi_inter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scales, grid, M, hs, ws, ht * wd,
                        vals, J);
+    return cut3r_check_launch();
+}
+
+extern "C" long long cut3r_schur_mono_prior_workspace_floats(int n, long long cols) {
+    return (long long)n * n * 3 + 3LL * n + (long long)n * cols;
+}
+
+extern "C" int cut3r_schur_mono_prior(const float* C, const float* w, const float* H, const float* E, const float* v, int n, long long cols,
+                                      float ep, float lm, float* workspace, float* dso, float* dz, float* dzcov, int* flag, void* stream) {
+    if (!C || !w || !H || !E || !v || !workspace || !dso || !dz || !flag || n <= 0 || n > CHOL_MAXN || cols <= 0) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    float* S = workspace;
+    float* Sd = S + (size_t)n * n;
+    float* L = Sd + (size_t)n * n;
+    float* vS = L + (size_t)n * n;
+    float* hd = vS + n;
+    float* xs = hd + 2 * n;
+    const int nb = (n + 15) / 16;
+    hipLaunchKernelGGL(mp_reduce_kernel, dim3(nb, nb), dim3(256), 0, s, H, E, C, w, v, n, cols, S, vS, hd);
+    hipLaunchKernelGGL(ba_damp_kernel, dim3((n * n + 255) / 256), dim3(256), 0, s, S, hd, n, ep, lm, Sd);
+    const size_t chol_lds = sizeof(float) * ((size_t)n * (n + 1) + 2 * (n + 8));
+    if (hipFuncSetAttribute((const void*)ba_chol_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds) != hipSuccess)
+        return CUT3R_ERR_LAUNCH;
+    hipLaunchKernelGGL(ba_chol_solve_kernel, dim3(1), dim3(256), chol_lds, s, Sd, vS, n, dso, L, flag);
+    const size_t bs_lds = sizeof(float) * ((dzcov ? (size_t)n * (n + 1) / 2 : 0) + n);
+    if (hipFuncSetAttribute((const void*)mp_backsub_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds) != hipSuccess)
+        return CUT3R_ERR_LAUNCH;
+    hipLaunchKernelGGL(mp_backsub_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), bs_lds, s, E, C, w, dso, L, flag, n, cols, dz, dzcov, xs);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_jdsa_blocks(const float* prior, const float* Jbi, const float* rd, float alpha, int M, int HW, int D, float* H, float* E,
+                                 float* v, void* stream) {
+    if (!prior || !Jbi || !rd || !H || !E || !v || M <= 0 || HW <= 0 || D <= 0 || M * D > CHOL_MAXN) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(jdsa_blocks_kernel, dim3(M), dim3(256), 256 * sizeof(float), (hipStream_t)stream, prior, Jbi, rd, alpha, M, HW, D, H, E, v);
     return cut3r_check_launch();
 }
 

@@ -284,6 +284,20 @@ int cut3r_ba_backsub(float* workspace, const float* dx, const unsigned char* pre
 int cut3r_ba_proj_trans(const float* Gij, const float* disps, const float* intr, const float* target, const float* weight, const int* ii,
                         const int* jj, const int* src_ptr, const int* src_edges, const int* kx, int P, int ht, int wd, int N, int M,
                         float* workspace, float* C_out, float* w_out, void* stream);
+/* geom.chol.schur_solve_mono_prior (/root/reference/hislam2/geom/chol.py:80-107; call site geom/ba.py:235): the scale-grid block of
+ * JDSA reduced over the per-pixel disparities.  H [n,n], E [n,cols], v [n] with n = M*D scale nodes (<= 192) and cols = M*ht*wd
+ * disparities, in the layout the reference builds with permute + reshape; C, w [cols].  S = H + (ep + lm diag H) I - E C^-1 E^T,
+ * in-LDS Cholesky, dso = S^-1 (v - E C^-1 w), dz = C^-1 (w - E^T dso), dzcov = |L^-1 E C^-1|^2 column-wise + C^-1 (NULL: skipped).
+ * A failed factorisation gives dso = 0 (CholeskySolver, chol.py:13-18) and sets flag[0].  workspace:
+ * cut3r_schur_mono_prior_workspace_floats(n, cols) floats. */
+long long cut3r_schur_mono_prior_workspace_floats(int n, long long cols);
+int cut3r_schur_mono_prior(const float* C, const float* w, const float* H, const float* E, const float* v, int n, long long cols, float ep,
+                           float lm, float* workspace, float* dso, float* dz, float* dzcov, int* flag, void* stream);
+/* the normal-equation blocks of geom.ba.JDSA's scale grids (/root/reference/hislam2/geom/ba.py:213-228): per source frame m,
+ * Jso = -[prior > 0] prior Jbi[m] ([HW,D], Jbi from cut3r_bi_inter), H_m = alpha Jso^T Jso, E_m = alpha Jso^T, v_m = -alpha Jso^T rd,
+ * written as the block-diagonal dense H [M*D, M*D], E [M*D, M*HW], v [M*D] that cut3r_schur_mono_prior takes. */
+int cut3r_jdsa_blocks(const float* prior, const float* Jbi, const float* rd, float alpha, int M, int HW, int D, float* H, float* E, float* v,
+                      void* stream);
 /* droid_backends.bi_inter (call site hislam2/geom/ba.py:167): bilinear interpolation of per-frame scale grids scales [M,hs,ws] at
  * grid [M,ht,wd,2] (x, y) -> vals [M,ht,wd] and the dense Jacobian J [M,ht,wd,hs*ws] w.r.t. the grid nodes. */
 int cut3r_bi_inter(const float* scales, const float* grid, int M, int hs, int ws, int ht, int wd, float* vals, float* J, void* stream);

@@ -86,7 +86,10 @@ class LoopCloser:
     submap rewrite, pose rewrite (c2w <- T_b c2w, keyframes 0..(sub+1)*5), bookkeeping of `closed_loop`.
     `submaps` [S,6,h,w,3], `conf_ds` [S,6,h,w], `pose` [K,7] (t, q_xyzw) are torch CPU tensors, updated in place."""
 
-    def __init__(self, submaps, conf_ds, pose, iters):
+    def __init__(self, submaps, conf_ds, pose, iters, dtype=torch.float64):
+        """dtype: arithmetic of the two optimisers (fp64 = the oracle; fp32 = what the reference's torch.optim.Adam on CUDA tensors
+        computes in, used to measure how far two correct implementations of these L1 objectives drift apart)"""
+        self.dtype = dtype
         self.sub, self.conf, self.pose, self.iters = submaps.double(), conf_ds.double(), pose.double(), iters
         self.initialized = False
         self.closed = {"idx_current": [], "idx_matched": [], "pointmaps_lc": []}
@@ -118,7 +121,8 @@ class LoopCloser:
             B = sub1 + 1
             mask = (self.conf[:sub1, 5] > 0).reshape(B - 1, -1)
             cur = self.sub[sub1, idx_current % 5].reshape(-1, 3)
-            xi, T, losses = loop_closure_init(self.sub[:B], mask, cur, pm_lc[-1].reshape(-1, 3), self.iters)
+            xi, T, losses = loop_closure_init(self.sub[:B], mask, cur, pm_lc[-1].reshape(-1, 3), self.iters, dtype=self.dtype)
+            T = T.double()
             self._rewrite(sub1, T)
             self.initialized = True
             stored = pm_lc
@@ -128,7 +132,8 @@ class LoopCloser:
             pm_cur = torch.stack([self.sub[c // 5, c % 5] for c in prev_cur] + [self.sub[sub1, idx_current % 5]], 0)
             sc = [c // 5 for c in prev_cur] + [sub1]
             sm = [m // 5 for m in self.closed["idx_matched"]] + [idx_matched // 5]
-            xi, T, xi_m, Tm, losses = loop_closure(self.sub[:sub1 + 1], lc_all, pm_cur, sc, sm, self.iters)
+            xi, T, xi_m, Tm, losses = loop_closure(self.sub[:sub1 + 1], lc_all, pm_cur, sc, sm, self.iters, dtype=self.dtype)
+            T, Tm = T.double(), Tm.double()
             self._rewrite(sub1, T)
             lc_al = torch.einsum("kij,kshwj->kshwi", Tm[:, :3, :3], lc_all) + Tm[:, :3, 3].reshape(-1, 1, 1, 1, 3)
             for i in range(len(prev_cur)):

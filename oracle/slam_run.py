@@ -113,7 +113,7 @@ def patch_overlap_ratio_f32(feat0: torch.Tensor, feat1: torch.Tensor, threshold:
 class SlamOracle:
     """Frame-by-frame CPU tracker.  `run(t, image_u8, intr4, second_last_frame, last_frame)` mirrors Hi2.run."""
 
-    def __init__(self, cfg, sd, image_size, buffer, motion_filter, intrinsics_ds=2, precision="fp32", iteration=0):
+    def __init__(self, cfg, sd, image_size, buffer, motion_filter, intrinsics_ds=2, precision="fp32", iteration=0, lc_dtype=torch.float64):
         self.cfg, self.sd = cfg, sd
         H, W = image_size
         self.H, self.W, self.ds = H, W, 2
@@ -139,6 +139,7 @@ class SlamOracle:
         self.timing = {"encode_s": 0.0, "window_s": 0.0, "align_graph_s": 0.0, "encodes": 0, "windows": 0, "graph_adds": 0}
         # loop closure (hi2.py:44-49,112-121: the backend runs when Tracking.frontend.iteration > 0, every other eligible window)
         self.iteration = int(iteration)
+        self.lc_dtype = lc_dtype
         self.freeze_counter = 0
         self.closer = None                  # oracle.lc_oracle.LoopCloser, created at the first closure
         self.closures = []                  # dicts: idx_current, idx_matched, candidates, scores, at_keyframe, poses / submaps after it
@@ -287,7 +288,7 @@ class SlamOracle:
         pm_lc, _, _ = self.backend_track(selected, anchor)
         st = self.state
         if self.closer is None:
-            self.closer = LC.LoopCloser(st["submap_ds"], st["conf_ds"], st["pose"], self.iteration)
+            self.closer = LC.LoopCloser(st["submap_ds"], st["conf_ds"], st["pose"], self.iteration, dtype=self.lc_dtype)
         lc = self.closer
         lc.sub, lc.conf, lc.pose = st["submap_ds"].double(), st["conf_ds"].double(), st["pose"].double()
         lc.close(pm_lc, idx_matched, idx_current)
@@ -315,11 +316,11 @@ class SlamOracle:
         return np.concatenate([self.tstamp[:t, None], self.state["pose"][:t].numpy().astype(np.float64)], 1)
 
 
-def run_stream(cfg, sd, frames_u8, intr, motion_filter, precision="fp32", buffer=None, mark_tail=True, iteration=0):
+def run_stream(cfg, sd, frames_u8, intr, motion_filter, precision="fp32", buffer=None, mark_tail=True, iteration=0, lc_dtype=torch.float64):
     """Drive SlamOracle over frames_u8 [n,3,H,W] like demo_s.py:151-160 (second-last / last frame flags) and return it."""
     n = frames_u8.shape[0]
     H, W = frames_u8.shape[2:]
-    so = SlamOracle(cfg, sd, (H, W), buffer or (n + 8), motion_filter, precision=precision, iteration=iteration)
+    so = SlamOracle(cfg, sd, (H, W), buffer or (n + 8), motion_filter, precision=precision, iteration=iteration, lc_dtype=lc_dtype)
     for t in range(n):
         so.run(t, frames_u8[t], intr, second_last_frame=mark_tail and t == n - 2, last_frame=mark_tail and t == n - 1)
     return so

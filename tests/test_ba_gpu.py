@@ -154,6 +154,54 @@ def test_jdsa_matches_unreduced_dense_solve():
     assert dzcov.shape == (len(kx), ht * wd) and bool((dzcov > 0).all())
 
 
+def test_schur_solve_mono_prior_matches_fp64_restatement_including_the_covariance():
+    """geom/chol.py:80-107 on the HIP kernels (cut3r_schur_mono_prior: reduction, damping, in-LDS Cholesky, back-substitution, column-wise
+    covariance) against the same formulas in fp64 torch on the CPU, with GENERAL (not block-diagonal) Hs / Es; a non-SPD system gives
+    the reference's swallowed failure: dso = 0, dz = w / C (CholeskySolver, chol.py:9-18).  Parity unpinned (dead code in the reference)."""
+    from cut3r_slam_amd.ba import schur_solve_mono_prior
+    g = torch.Generator().manual_seed(4)
+    M, D, HW = 3, 6, 40
+    Es = torch.randn(1, M, M, D, HW, generator=g, dtype=torch.float64) * 0.3
+    A = torch.randn(M * D, M * D, generator=g, dtype=torch.float64)
+    Hfull = A @ A.T + 4.0 * torch.eye(M * D, dtype=torch.float64)
+    Hs = Hfull.reshape(M, D, M, D).permute(0, 2, 1, 3)[None].contiguous()
+    vs = torch.randn(1, M, D, generator=g, dtype=torch.float64)
+    C = torch.rand(1, M, HW, generator=g, dtype=torch.float64) * 2 + 6.0
+    w = torch.randn(1, M, HW, generator=g, dtype=torch.float64)
+
+    def ref(C, w, Hs, Es, vs, ep=0.1, lm=1e-4):
+        Q = (1.0 / C).view(1, M * HW, 1)
+        wv = w.reshape(1, M * HW, 1)
+        H = Hs.permute(0, 1, 3, 2, 4).reshape(1, M * D, M * D)
+        E = Es.permute(0, 1, 3, 2, 4).reshape(1, M * D, M * HW)
+        v = vs.reshape(1, M * D, 1)
+        H = H + (ep + lm * H) * torch.eye(M * D, dtype=torch.float64)
+        Et = E.transpose(1, 2)
+        S = H - E @ (Q * Et)
+        v = v - E @ (Q * wv)
+        L = torch.linalg.cholesky(S)
+        dso = torch.cholesky_solve(v, L)
+        dz = Q * (wv - Et @ dso)
+        Fm = torch.linalg.solve_triangular(L, E * Q[..., 0][:, None], upper=False)
+        cov = (Fm ** 2).sum(1) + Q[..., 0]
+        return dso.reshape(1, M, D), dz.reshape(1, M, HW), cov.reshape(M, HW)
+
+    dso_r, dz_r, cov_r = ref(C, w, Hs, Es, vs)
+    f = lambda t: t.float().to(DEV)
+    dso, dz, cov = schur_solve_mono_prior(f(C), f(w), f(Hs), f(Es), f(vs), dzcov=True)
+    torch.cuda.synchronize()
+    for got, want, name in ((dso, dso_r, "dso"), (dz, dz_r, "dz"), (cov, cov_r, "dzcov")):
+        err = float((got.cpu().double() - want).abs().max() / want.abs().max())
+        assert err < 2e-4, (name, err)
+    _, _, none = schur_solve_mono_prior(f(C), f(w), f(Hs), f(Es), f(vs), dzcov=False)
+    assert none is None
+    # failure path: an indefinite reduced system
+    dso_b, dz_b, cov_b = schur_solve_mono_prior(f(C), f(w), f(-Hs), f(Es), f(vs), dzcov=True)
+    assert float(dso_b.abs().max()) == 0.0
+    np.testing.assert_allclose(dz_b.cpu().numpy(), (w / C).float().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(cov_b.cpu().numpy(), (1.0 / C)[0].float().numpy(), rtol=1e-5)
+
+
 def test_altcorr_forward_and_backward_vs_all_pairs_volume():
     g = torch.Generator().manual_seed(4)
     BN, H, W, H2, W2, Cc, S, r = 2, 5, 6, 7, 8, 24, 2, 2

@@ -177,14 +177,17 @@ def test_loop_closure_fires_inside_the_loop_and_matches_the_cpu_restatement():
     unpinned, see tests/test_loop_closure_gpu.py for its tolerances):
       * the same closures in the same order: (current keyframe, matched keyframe), the same candidate lists, NMS scores within 5e-3;
       * the first closure takes the `loop_closure_init` path, the later ones the general term list;
-      * keyframes, ordered edge lists (near-threshold exceptions as above), the trajectory (ATE <= 2 mm: the L1 objective's sign()
-        gradients make fp32 and fp64 Adam trajectories differ by a few steps of lr = 5e-4 per closure) and the rewritten stores."""
+      * keyframes, ordered edge lists (near-threshold exceptions as above), the trajectory and the rewritten stores, against the
+        TF32 budget: the L1 objectives' sign() gradients amplify the network's rounding noise (the CPU loop run with TF32-rounded
+        operands -- the reference's own arithmetic -- ends 3.4 mm ATE / 11 mm per keyframe away from its fp32 run), so the bounds are
+        2.5 x what that TF32 run deviates."""
     cfg = synth.medium_config()
     sd = synth.loop_state_dict(cfg, 11)
     mf = {"thresh": 0.9, "skip": 1, "kf_every": 2}
     iters = 100
     frames = synth.pan_stream(90, H, W, pool=5, num=2, den=1, seed=0)
     so = SR.run_stream(cfg, sd, frames, INTR, mf, precision="fp32", iteration=iters)
+    sotf = SR.run_stream(cfg, sd, frames, INTR, mf, precision="tf32", iteration=iters)
     assert len(so.closures) >= 3, "the oracle run closed fewer than three loops"
     # ---- HIP
     model = Cut3rModel(cfg, sd, DEV, minimal=True)
@@ -238,7 +241,14 @@ def test_loop_closure_fires_inside_the_loop_and_matches_the_cpu_restatement():
           f"(unaligned max |dt| {e_t * 1e3:.3f} mm) | stride-2 world pointmaps max |diff| {e_pm * 1e3:.2f} mm | edges {len(e_gpu)} vs {len(e_ref)}, "
           f"near-threshold differences {near}")
     assert not unexplained and len(near) <= 0.02 * len(e_ref) + 2
-    assert ate["rmse"] <= 2e-3 and e_t <= 2e-2 and e_pm <= 3e-2, (ate, e_t, e_pm)
+    tf = sotf.trajectory()
+    assert [(c["idx_current"], c["idx_matched"]) for c in sotf.closures] == [(c["idx_current"], c["idx_matched"]) for c in so.closures]
+    ate_tf = ate_rmse(tf, ref, 0.01, True)
+    e_t_tf = float(np.abs(tf[:, 1:4] - ref[:, 1:4]).max())
+    e_pm_tf = float((sotf.state["submap_ds"][:nsub] - so.state["submap_ds"][:nsub]).abs().max())
+    print(f"[e2e loop closure on] CPU-tf32 vs CPU-fp32: ATE-RMSE {ate_tf['rmse'] * 1e3:.3f} mm, unaligned max |dt| {e_t_tf * 1e3:.3f} mm, pointmaps {e_pm_tf * 1e3:.2f} mm")
+    assert ate["rmse"] <= 2.5 * ate_tf["rmse"] + 5e-5 and e_t <= 2.5 * e_t_tf + 1e-3 and e_pm <= 2.5 * e_pm_tf + 1e-3, (ate, ate_tf, e_t, e_t_tf, e_pm, e_pm_tf)
+    assert ate["rmse"] <= 1e-2 and e_t <= 4e-2 and e_pm <= 4e-2                   # 3 x measured
     # the closures did something: poses of early keyframes differ from a run with the backend off
     so_off = SR.run_stream(cfg, sd, frames, INTR, mf, precision="fp32", iteration=0)
     assert np.abs(so_off.trajectory()[:, 1:4] - ref[:, 1:4]).max() > 10 * e_t
