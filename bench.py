@@ -295,6 +295,57 @@ def overlap_mode_leg(model, slam_cls, dev, n_frames=800, lookahead=16, plain_fra
     return out
 
 
+def loop_closure_leg(cfg, slam_cls, dev, iters=2000, n_frames=1000, warm=160):
+    """BASELINE configs[2]: the tracking loop WITH the loop-closure backend (hislam2/hi2.py:112-121, track_backend.py:527-586), one window
+    at a time, Tracking.frontend.iteration = 2000 (config/scannet_config.yaml:33).  A random-weight network recognises no place, so the
+    weights are synth.loop_state_dict (pose head damped: every keyframe stays covisible with the early ones) -- the backend then fires by
+    itself every other eligible window: detect_loop -> NMS -> 6-view re-tracking -> fused Adam over the submap corrections -> rewrite."""
+    from cut3r_slam_amd import synth
+    from cut3r_slam_amd.model import Cut3rModel
+    sd = synth.loop_state_dict(cfg, seed=0, enc_residual_gain=0.1, depth_relief=0.02)
+    model = Cut3rModel(cfg, sd, dev, minimal=True)
+    config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": KF_EVERY},
+                           "frontend": {"iteration": int(iters), "window_batch": 1}}}
+    intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])
+    frames = synth_frames(warm + n_frames, H, W, dev, seed=0)
+    slam = slam_cls(model, config, (H, W), buffer=(warm + n_frames) // KF_EVERY + 16, device=dev)
+    closures = []
+    real_run = slam.backend.run
+
+    def timed_run():
+        torch.cuda.synchronize()
+        tic = time.perf_counter()
+        out = real_run()
+        torch.cuda.synchronize()
+        if out[0]:
+            closures.append(time.perf_counter() - tic)
+        return out
+    slam.backend.run = timed_run
+    for t in range(warm):
+        slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+    torch.cuda.synchronize()
+    n_warm = len(closures)
+    w0 = slam.tracker.t1
+    tic = time.perf_counter()
+    for t in range(warm, warm + n_frames):
+        slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - tic
+    timed = closures[n_warm:]
+    be = slam.backend
+    out = {"config": f"kf_every={KF_EVERY}, window_batch=1, Tracking.frontend.iteration={iters} (config/scannet_config.yaml:33), {n_frames} frames; weights = "
+                     "synth.loop_state_dict (every keyframe covisible with the early ones: the backend fires by itself every other eligible window)",
+           "frames_per_s": round(n_frames / el, 1), "ms_per_frame": round(1e3 * el / n_frames, 3), "windows": (slam.tracker.t1 - w0) // 5,
+           "closures": len(timed), "ms_per_closure": round(1e3 * sum(timed) / max(1, len(timed)), 2),
+           "ms_per_closure_max": round(1e3 * max(timed), 2) if timed else None,
+           "submaps_at_last_closure": (be.closed_loop["idx_current"][-1] // 5 + 1) if be.closed_loop["idx_current"] else 0,
+           "closed_loops": [[int(c), int(m)] for c, m in zip(be.closed_loop["idx_current"], be.closed_loop["idx_matched"])][-6:],
+           "health": tracking_health(slam)}
+    del slam, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def trajectory_parity_leg(dev, production_model=None, production_sd=None):
     """GPU path vs CPU restatement of the reference loop on the same seeded stream + weights: ATE-RMSE with Sim(3) alignment, keyframe
     agreement, edge lists.  Medium config at 64x96 in both keyframe modes (tests/test_e2e_gpu.py asserts the same) and -- a third entry
@@ -573,6 +624,8 @@ def main():
             del le
         log("operating points: overlap mode (kf_every=-1, skip=5, thresh=0.9)")
         op_points["overlap_mode"] = overlap_mode_leg(model, Cut3rSlam, dev)
+        log("operating points: loop closure on (BASELINE configs[2])")
+        op_points["loop_closure_on"] = loop_closure_leg(cfg, Cut3rSlam, dev)
         log("operating points: GS mapper on a synthetic window (rasteriser forward + backward, pose refinement, mapping)")
         op_points["gs_mapper_synthetic_window"] = synth.gs_mapper_window_leg(H, W, dev)
     if single and not args.no_trajectory_parity:

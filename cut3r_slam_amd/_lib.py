@@ -120,6 +120,12 @@ SIGNATURES = {
     "cut3r_refine_loss_backward": [c_void_p] * 5 + [c_float, c_int, c_int] + [c_void_p] * 4,
     "cut3r_ssim_forward": [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 5,
     "cut3r_ssim_backward": [c_void_p] * 5 + [c_int, c_int, c_int] + [c_void_p] * 3,
+    "cut3r_gs_activate": [c_int] + [c_void_p] * 8,
+    "cut3r_gs_activate_backward": [c_int] + [c_void_p] * 8 + [c_float] + [c_void_p] * 4,
+    "cut3r_gs_pose_step": [c_void_p, c_void_p, c_float, c_void_p, c_float, c_float, c_int, c_void_p],
+    "cut3r_gs_adam": [c_ll] + [c_void_p] * 5 + [c_float] * 5 + [c_void_p],
+    "cut3r_gs_map_coef": [c_void_p, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "cut3r_gs_refine_coef": [c_void_p, c_float, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "cut3r_knn3_chunks": [c_int],
     "cut3r_knn3_mean_dist2": [c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "cut3r_gs_render_backward": [c_void_p] * 3 + [c_int, c_int, c_int, c_float, c_float] + [c_void_p] * 16,

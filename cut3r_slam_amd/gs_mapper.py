@@ -60,6 +60,8 @@ class GaussianMap:
             self.lr[0, a:b] = lr[k]
         self.percent_dense = opt.get("percent_dense", 0.01)
         self.step_count = z(1)                                            # device scalar: a captured iteration increments it in place
+        self.steps = 0                                                    # the same count on the host (the fused trainer's bias corrections)
+        self._steps_dev_stale = False                                     # the fused trainer advanced `steps` without touching the device scalar
         self.kf_id = torch.zeros(0, dtype=torch.int32, device=self.device)
         self.max_radii2D = z(0)
         self.grad_accum, self.denom = z(0, 1), z(0, 1)
@@ -190,7 +192,11 @@ class GaussianMap:
         g = self.theta.grad
         if g is None:
             return
+        if self._steps_dev_stale:
+            self.step_count.fill_(float(self.steps))
+            self._steps_dev_stale = False
         self.step_count += 1
+        self.steps += 1
         self.m.mul_(b1).add_(g, alpha=1 - b1)
         self.v.mul_(b2).addcmul_(g, g, value=1 - b2)
         bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
@@ -392,6 +398,16 @@ class GSMapper:
         # (tools/bench_gs.py: 2.30 -> 1.41 ms per render iteration over 400 iterations): it pays for long loops over a fixed set of Gaussians (a final refinement), not for the 20-100 iteration calls of run()
         self.use_graphs = False
         self.graph_min_iters = 150
+        # optimization() / pose_refine() on the tape-free trainer of gs_step.py (direct C-ABI calls, ~4x fewer launches); False: the
+        # tensor-op formulation below (the tests compare the two)
+        self.fused = True
+        self._trainer = None
+
+    def _fused_trainer(self):
+        if self._trainer is None:
+            from .gs_step import FusedTrainer
+            self._trainer = FusedTrainer(self)
+        return self._trainer
 
     def _pose_optimizer(self, views, exposure=False, capturable=False):
         lr = self.config["opt_params"]["pose_lr"]
@@ -442,6 +458,7 @@ class GSMapper:
                 gc.enable()
         for _ in range(iters - warm):
             g.replay()
+        self.gaussians.steps += iters - warm - 1                          # (the capture pass advanced the host count once, every replay the device's)
         if int(flag):                                                     # one read after all replays
             import warnings
             warnings.warn(f"GSMapper: the captured iterations needed more than {cap} tile instances; their tile lists were truncated "
@@ -455,7 +472,9 @@ class GSMapper:
         scale-invariant log-depth variance, a small pull to the starting pose.  Returns (pointmaps_ds, valid_ds) of the refined poses."""
         views = [self.viewpoints[k] for k in BA_window]
         B = len(views)
-        if len(self.gaussians) > 0:
+        if len(self.gaussians) > 0 and self.fused and not graph and iters > 0:
+            self._fused_trainer().pose_refine(views, iters, alpha_th)
+        elif len(self.gaussians) > 0:
             use_graph = (graph if graph is not None else (self.use_graphs and iters >= self.graph_min_iters)) and iters >= 8
             opt = self._pose_optimizer(views, capturable=use_graph)
 
@@ -526,6 +545,8 @@ class GSMapper:
         views = [self.viewpoints[k] for k in current_window]
         N = len(views)
         exposure = bool(self.config["Training"].get("compensate_exposure", False))
+        if self.fused and not graph and not densify and not exposure and iters > 0 and len(self.gaussians) > 0 and N > 0:
+            return self._fused_trainer().optimization(views, iters, optimize_pose)
         use_graph = ((graph if graph is not None else (self.use_graphs and iters >= self.graph_min_iters)) and not densify and iters >= 8
                      and len(self.gaussians) > 0)
         opt = self._pose_optimizer(views, exposure, capturable=use_graph) if optimize_pose else None
@@ -822,6 +843,9 @@ class GSMapper:
         """the Gaussian map (parameters, optimiser moments, bookkeeping) as a safetensors file: nothing executable in the file"""
         from safetensors.torch import save_file
         g = self.gaussians
+        if g._steps_dev_stale:
+            g.step_count.fill_(float(g.steps))
+            g._steps_dev_stale = False
         save_file({"theta": g.theta.detach().contiguous(), "m": g.m.contiguous(), "v": g.v.contiguous(), "step_count": g.step_count.contiguous(),
                    "kf_id": g.kf_id.contiguous(), "max_radii2D": g.max_radii2D.contiguous(), "grad_accum": g.grad_accum.contiguous(),
                    "denom": g.denom.contiguous()}, path)
@@ -832,6 +856,7 @@ class GSMapper:
         g = self.gaussians
         g.theta = t["theta"].requires_grad_(True)
         g.m, g.v, g.step_count, g.kf_id = t["m"], t["v"], t["step_count"], t["kf_id"]
+        g.steps, g._steps_dev_stale = int(g.step_count.reshape(-1)[0]), False
         g.max_radii2D, g.grad_accum, g.denom = t["max_radii2D"], t["grad_accum"], t["denom"]
 
     @torch.no_grad()

@@ -74,7 +74,7 @@ class Cut3rSlam:
         depth = updated["depths"]
         ds = self.downsample_ratio
         for j, k in enumerate(idx):
-            if self.gs_depth_writeback:
+            if getattr(self, "gs_depth_writeback", False):
                 ok = depth[j] > 0
                 kf.depth[k][ok] = depth[j][ok]
             kf.submap_ds[k // 5, k % 5] = updated["pointmaps"][j, ::ds, ::ds]

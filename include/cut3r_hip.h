@@ -372,6 +372,35 @@ int cut3r_gs_preprocess_backward(int P, const float* means, const float* scales,
                                  const float* campos_host, int W, int H, float tanfovx, float tanfovy, float kernel_size, float scale_modifier,
                                  const float* geom, const float* dgeom, float* d_means, float* d_scales, float* d_rots, float* d_opacities,
                                  float* d_shs, float* d_colors, float* d_means2D, void* stream);
+/* ---- the mapper's training step without an autograd tape (csrc/gs_train.hip) ------------------------------------------------------
+ * What the reference spreads over torch autograd per rendered view: `render` moves the Gaussians into the camera frame
+ * (hislam2/gaussian/renderer/__init__.py:89-152 with utils/slam_utils.py:93-102 get_pose: pose = exp([tau, phi]) * T_w2c), the
+ * activations of scene/gaussian_model.py:77-101, torch.optim.Adam of every parameter group (:374-417) and of the pose increments
+ * (hislam2/gs_backend_per_frame.py:451-475), update_pose (slam_utils.py:77-91).
+ * pose_state: 32 floats per view -- [0:7] world->camera (t, q_xyzw), [7:13] increment (tau, phi), [13:19] / [19:25] Adam moments, [25] steps.
+ *   activate:          theta [P,14] (xyz | DC colour | opacity logit | log scale | quaternion rxyz) -> camera-frame means [P,3], scales
+ *                      [P,3], rotations [P,4] (rxyz, pose rotation applied), opacities [P], colours [P,3]: the rasteriser's inputs.
+ *   activate_backward: their gradients (cut3r_gs_preprocess_backward's outputs) -> gtheta [P,14] += (NULL: poses only) and pose_sums [16]
+ *                      += (NULL: Gaussians only); iso_coef != 0 adds the gradient of iso_coef * sum_visible |s - mean s| / max(3 n_visible, 1)
+ *                      (gs_backend_per_frame.py:533-538; radii > 0 = visible, nvis_ws: one float of scratch).
+ *   pose_step:         gradient of the increments from pose_sums through exp() + 2 * prior * (2 - *ratio) * delta (the pull of pose_refine,
+ *                      :262; ratio NULL: factor 1), Adam (lr_trans for tau, lr_rot for phi), fold != 0: T <- exp(delta) T, delta <- 0.
+ *   adam:              GaussianMap.step over n = 14 P elements with the per-column rates lr14 [14] and host-side bias corrections.
+ *   map_coef / refine_coef: the scalar algebra between cut3r_pixel_loss_forward / cut3r_refine_loss_forward and their backward passes
+ *                      (upstream gradient g, resp. g_rgb / g_var); loss_acc (nullable) += the weighted loss value. */
+int cut3r_gs_activate(int P, const float* theta, const float* pose_state, float* means, float* scales, float* rots, float* opac, float* shs,
+                      void* stream);
+int cut3r_gs_activate_backward(int P, const float* theta, const float* pose_state, const float* d_means, const float* d_scales,
+                               const float* d_rots, const float* d_opac, const float* d_shs, const int* radii, float iso_coef, float* nvis_ws,
+                               float* gtheta, float* pose_sums, void* stream);
+int cut3r_gs_pose_step(float* pose_state, const float* pose_sums, float prior, const float* ratio, float lr_rot, float lr_trans, int fold,
+                       void* stream);
+int cut3r_gs_adam(long long n, float* theta, float* m, float* v, const float* grad, const float* lr14, float b1, float b2, float bc1, float bc2,
+                  float eps, void* stream);
+int cut3r_gs_map_coef(const float* sums, float w_rgb, float w_depth, float w_normal, float g, int H, int W, float* coef, float* loss_acc,
+                      void* stream);
+int cut3r_gs_refine_coef(const float* sums, float g_rgb, float g_var, int H, int W, float* coef, float* ratio_out, float* loss_acc,
+                         void* stream);
 /* simple_knn._C.distCUDA2 (call sites hislam2/gaussian/scene/gaussian_model.py:191,313; the extension is not vendored in the
  * reference tree): points [P,3] -> out [P], the mean squared distance to the 3 nearest other points.  P >= 4.
  * workspace: cut3r_knn3_chunks(P) * P * 3 floats (the candidates are searched in that many chunks, merged by a second kernel). */

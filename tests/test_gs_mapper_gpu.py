@@ -54,21 +54,29 @@ def _psnr(a, b):
 
 
 def test_render_geometry_is_a_pinhole_camera():
-    """isolated Gaussians land at u = fx X/Z + cx, v = fy Y/Z + cy (alpha centroid), also with an off-centre principal point and a
-    moved camera; the rendered depth of the wall follows the analytic surface"""
+    """isolated Gaussians land where the REFERENCE's camera puts them: graphics_utils.getProjectionMatrix2 (P[0,2] = 2 cx / W - 1) through
+    the rasteriser's ndc2Pix gives u = fx X/Z + cx - 0.5, v = fy Y/Z + cy - 0.5 (alpha centroid) -- also with an off-centre principal
+    point and a moved camera; Camera.half_pixel_center = True (declared deviation, off by default) gives u = fx X/Z + cx exactly.  The
+    rendered depth of the wall follows the analytic surface"""
     pts = torch.tensor([[0.3, -0.2, 2.0], [-0.8, 0.5, 3.0], [0.9, 0.6, 4.0]])
     gm = GM.GaussianMap(CONFIG["opt_params"], DEV)
     gm._append({"xyz": pts, "f_dc": torch.ones(3, 3), "opacity": torch.full((3, 1), 3.0), "scaling": torch.full((3, 3), math.log(0.03)),
                 "rotation": torch.tensor([[1.0, 0, 0, 0]] * 3)}, torch.zeros(3))
     ys, xs = torch.meshgrid(torch.arange(H, device=DEV).float(), torch.arange(W, device=DEV).float(), indexing="ij")
-    for cx, cy, pose in ((64.0, 48.0, _pose7(0, 0, 0, 0, 0)), (70.25, 41.5, _pose7(0.1, -0.05, 0.2, 0.02, -0.03))):
+    for cx, cy, pose, half in ((64.0, 48.0, _pose7(0, 0, 0, 0, 0), False), (70.25, 41.5, _pose7(0.1, -0.05, 0.2, 0.02, -0.03), False),
+                               (70.25, 41.5, _pose7(0.1, -0.05, 0.2, 0.02, -0.03), True)):
         w2c = torch.inverse(GM.pose_vec_to_matrix(pose[None].to(DEV))[0])
-        cam = GM.Camera(0, torch.zeros(3, H, W), torch.ones(H, W), w2c, FX, FY, cx, cy, device=DEV)
+        GM.Camera.half_pixel_center = half
+        try:
+            cam = GM.Camera(0, torch.zeros(3, H, W), torch.ones(H, W), w2c, FX, FY, cx, cy, device=DEV)
+        finally:
+            GM.Camera.half_pixel_center = False
         with torch.no_grad():
             alpha = GM.render(cam, gm, torch.zeros(3, device=DEV))["mask"][0]
         pc = pts.to(DEV) @ w2c[:3, :3].T + w2c[:3, 3]
+        off = 0.0 if half else 0.5
         for k in range(3):
-            u, v = FX * pc[k, 0] / pc[k, 2] + cx, FY * pc[k, 1] / pc[k, 2] + cy
+            u, v = FX * pc[k, 0] / pc[k, 2] + cx - off, FY * pc[k, 1] / pc[k, 2] + cy - off
             win = ((xs - u).abs() < 6) & ((ys - v).abs() < 6)
             a = alpha * win
             cu, cv = float((a * xs).sum() / a.sum()), float((a * ys).sum() / a.sum())
@@ -340,3 +348,78 @@ def test_captured_iterations_follow_the_eager_loop():
     dth = (res[True][2] - res[False][2]).abs()
     print(f"[gs mapper] parameters, captured vs eager: mean |diff| {float(dth.mean()):.2e}, max {float(dth.max()):.2e}")
     assert float(dth.mean()) < 1e-3 and float(dth.max()) < 0.2
+
+
+def _two_view_mapper(fused):
+    truth = _truth()
+    poses = [_pose7(0, 0, 0, 0, 0), _pose7(0.15, 0.0, 0.0, 0.0, -0.04)]
+    obs = [_observe(truth, p) for p in poses]
+    m = GM.GSMapper(CONFIG, FX, FY, CX, CY, downsample_ratio=2, device=DEV)
+    m.fused = False                                   # identical set-up for both: the tensor-op path builds the map
+    g = torch.Generator().manual_seed(4)
+    for k, (p, (img, depth)) in enumerate(zip(poses, obs)):
+        m.add_new_view(img, p, depth.cpu().mul(1 + 0.01 * torch.randn(H, W, generator=g)).to(DEV), kf_sub_idx=k, iters=5)
+    m.fused = fused
+    return m
+
+
+def _pair():
+    """two mappers in the SAME state (the set-up runs through atomics: two builds differ in the last bits), one per formulation"""
+    a, b = _two_view_mapper(False), _two_view_mapper(True)
+    ga, gb = a.gaussians, b.gaussians
+    gb.theta = ga.theta.detach().clone().requires_grad_(True)
+    gb.m, gb.v, gb.step_count, gb.steps = ga.m.clone(), ga.v.clone(), ga.step_count.clone(), ga.steps
+    gb.kf_id, gb.max_radii2D, gb.grad_accum, gb.denom = ga.kf_id.clone(), ga.max_radii2D.clone(), ga.grad_accum.clone(), ga.denom.clone()
+    for k in a.viewpoints:
+        va, vb = a.viewpoints[k], b.viewpoints[k]
+        vb.update_RT(va.R, va.T, data=va.w2c_data)
+        vb.cam_rot_delta.data.copy_(va.cam_rot_delta.data)
+        vb.cam_trans_delta.data.copy_(va.cam_trans_delta.data)
+        vb.depth, vb.original_image = va.depth.clone(), va.original_image.clone()
+    return a, b
+
+
+def test_tape_free_trainer_matches_the_tensor_op_formulation():
+    """gs_step.FusedTrainer (direct C-ABI calls: cut3r_gs_activate / _activate_backward / _pose_step / _adam around the rasteriser and loss
+    kernels) against the autograd formulation of gs_mapper.py on the same map and views:
+      * one mapping iteration over two views: the gradient of every Gaussian parameter (read from Adam's first moment, m = 0.1 g) and of
+        both poses' increments agree to 1e-4 of their scale -- activations, isotropy term, SSIM + pixel losses, pose chain through exp();
+      * five pose-refinement iterations (increments NOT folded between iterations: the exp() Jacobian away from 0, the pull to the start);
+      * 40 mapping iterations: same loss and trajectory within the noise of the atomics (as the captured-graph test)."""
+    a, b = _pair()
+    assert torch.equal(a.gaussians.theta, b.gaussians.theta)
+    pa0 = a.trajectory().detach().clone()
+    la, lb = a.optimization(1, optimize_pose=True, current_window=[0, 1]), b.optimization(1, optimize_pose=True, current_window=[0, 1])
+    ga, gb = a.gaussians.m / 0.1, b.gaussians.m / 0.1
+    names = {"xyz": (0, 3), "colour": (3, 6), "opacity": (6, 7), "log scale": (7, 10), "quaternion": (10, 14)}
+    for name, (c0, c1) in names.items():
+        sc = float(ga[:, c0:c1].abs().max())
+        err = float((ga[:, c0:c1] - gb[:, c0:c1]).abs().max())
+        print(f"[gs fused] d loss / d {name}: scale {sc:.3e}, max |autograd - fused| {err:.3e}")
+        assert sc > 0 and err <= 2e-4 * sc + 1e-9, (name, sc, err)
+    assert abs(la - lb) <= 1e-5 * abs(la) + 1e-6, (la, lb)
+    assert a.gaussians.steps == b.gaussians.steps == int(a.gaussians.step_count) and b.gaussians._steps_dev_stale
+    # first Adam step of the poses: +-lr per component with the sign of the gradient -- the same move on both paths
+    da, db = a.trajectory().detach() - pa0, b.trajectory().detach() - pa0
+    assert float(da.abs().max()) > 1e-5
+    torch.testing.assert_close(db, da, atol=1e-5, rtol=0)
+    # ---- pose refinement: increments accumulate over the iterations
+    a2, b2 = _pair()
+    start = _pose7(0.15 + 0.02, 0.01, -0.015, 0.005, -0.04 - 0.006)
+    for m in (a2, b2):
+        m.viewpoints[1].update_RT(*(lambda T: (T[:3, :3], T[:3, 3]))(torch.inverse(GM.pose_vec_to_matrix(start[None].to(DEV))[0])))
+        m.pose_refine([0, 1], iters=5, return_args=False)
+    torch.testing.assert_close(b2.trajectory().detach(), a2.trajectory().detach(), atol=2e-5, rtol=0)
+    assert float((a2.trajectory()[1].detach() - GM.pose_vec_to_matrix(start[None].to(DEV))[0]).abs().max()) > 1e-4       # (it moved)
+    # ---- a real loop
+    a3, b3 = _pair()
+    l3a, l3b = a3.optimization(40, optimize_pose=True, current_window=[0, 1]), b3.optimization(40, optimize_pose=True, current_window=[0, 1])
+    print(f"[gs fused] 40 iterations: autograd loss {l3a:.5f}, fused {l3b:.5f}")
+    assert abs(l3a - l3b) < 0.02 * l3a
+    torch.testing.assert_close(b3.trajectory().detach(), a3.trajectory().detach(), atol=2e-4, rtol=0)
+    dth = (a3.gaussians.theta.detach() - b3.gaussians.theta.detach()).abs()
+    assert float(dth.mean()) < 1e-3 and float(dth.max()) < 0.2
+    # the autograd path picks the step count up again
+    b3.fused = False
+    b3.optimization(1, optimize_pose=False, current_window=[0])
+    assert int(b3.gaussians.step_count) == b3.gaussians.steps and not b3.gaussians._steps_dev_stale

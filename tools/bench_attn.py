@@ -19,7 +19,9 @@ if args.lib:
 from cut3r_slam_amd import ops  # noqa: E402
 
 DEV = "cuda:0"
-CASES = [(40, 16, 768, 768, 64, "enc self"), (8, 12, 769, 769, 64, "dec img self"), (8, 12, 769, 768, 64, "dec img cross"),
+CASES = [(140, 16, 768, 768, 64, "enc self 140 kf"), (28, 12, 769, 769, 64, "dec img self W28"), (28, 12, 769, 768, 64, "dec img cross W28"),
+         (28, 16, 768, 768, 48, "dec state self W28"), (28, 16, 768, 769, 48, "dec state cross W28"), (28, 12, 256, 256, 128, "mem write self W28"),
+         (40, 16, 768, 768, 64, "enc self"), (8, 12, 769, 769, 64, "dec img self"), (8, 12, 769, 768, 64, "dec img cross"),
          (8, 16, 768, 768, 48, "dec state self"), (8, 16, 768, 769, 48, "dec state cross"), (8, 12, 256, 256, 128, "mem write self"),
          (1, 12, 769, 769, 64, "dec img self W1"), (1, 16, 768, 769, 48, "dec state cross W1")]
 g = torch.Generator().manual_seed(0)
