@@ -851,6 +851,92 @@ __global__ __launch_bounds__(256) void pixel_loss_bwd_kernel(const float* __rest
     g_d[p] = g;
 }
 
+// agreement of the RENDERED normal image with the normal of the rendered depth (global_BA, gs_backend_per_frame.py:996-1001:
+// `normal_loss = (1 - (render_normal * depth_to_normal(depth)).sum(0)).mean()` over ALL pixels; the depth normal is zero on the image
+// border, utils.depth_to_normal / F.pad).  forward: sum[0] = sum_p (1 - N(p) . n(d)(p)).  backward with coef = upstream * weight / HW:
+// g_N = -coef n(d) and g_d += coef * d(-N . n)/d d gathered from the four neighbours whose normal reads d(p) (the stencil of
+// pixel_loss_bwd_kernel without its depth mask).
+__global__ __launch_bounds__(256) void normal_agree_fwd_kernel(const float* __restrict__ nrm, const float* __restrict__ d, int H, int W, PixCam k,
+                                                               float* __restrict__ sum) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int HW = H * W;
+    float v = 0.f;
+    if (p < HW) {
+        const int y = p / W, x = p - y * W;
+        float dot = 0.f;
+        if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
+            float dx[3], dy[3], c[3];
+            pl_diffs(d, k, W, x, y, dx, dy);
+            pl_cross(dx, dy, c);
+            const float il = 1.f / fmaxf(sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]), 1e-12f);
+            dot = (c[0] * nrm[p] + c[1] * nrm[HW + p] + c[2] * nrm[2 * HW + p]) * il;
+        }
+        v = 1.f - dot;
+    }
+    __shared__ float red[4];
+    const float t = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void normal_agree_bwd_kernel(const float* __restrict__ nrm, const float* __restrict__ d, int H, int W, PixCam k,
+                                                               float coef, float* __restrict__ g_nrm, float* __restrict__ g_d) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int HW = H * W;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    float gn[3] = {0.f, 0.f, 0.f};
+    if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
+        float dx[3], dy[3], c[3];
+        pl_diffs(d, k, W, x, y, dx, dy);
+        pl_cross(dx, dy, c);
+        const float il = 1.f / fmaxf(sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]), 1e-12f);
+#pragma unroll
+        for (int i = 0; i < 3; i++) gn[i] = -coef * c[i] * il;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) g_nrm[(size_t)i * HW + p] = gn[i];
+    float rp[3];
+    pl_ray(k, x, y, rp);
+    float g = 0.f;
+    const int qx[4] = {x - 1, x + 1, x, x}, qy[4] = {y, y, y - 1, y + 1};
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const int xx = qx[n], yy = qy[n];
+        if (xx < 1 || xx > W - 2 || yy < 1 || yy > H - 2) continue;
+        const int q = yy * W + xx;
+        float dx[3], dy[3], c[3], dc[3];
+        pl_diffs(d, k, W, xx, yy, dx, dy);
+        pl_cross(dx, dy, c);
+        const float len = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        if (!(len > 1e-12f)) continue;
+        const float il = 1.f / len;
+        const float nq[3] = {c[0] * il, c[1] * il, c[2] * il}, gq[3] = {nrm[q], nrm[HW + q], nrm[2 * HW + q]};
+        const float ng = nq[0] * gq[0] + nq[1] * gq[1] + nq[2] * gq[2];
+        const float h[3] = {-(gq[0] - nq[0] * ng) * il, -(gq[1] - nq[1] * ng) * il, -(gq[2] - nq[2] * ng) * il};
+        if (n < 2) pl_cross(rp, dy, dc); else pl_cross(dx, rp, dc);
+        const float sgn = (n == 0 || n == 2) ? 1.f : -1.f;
+        g += coef * sgn * (h[0] * dc[0] + h[1] * dc[1] + h[2] * dc[2]);
+    }
+    g_d[p] += g;
+}
+
+// densification statistics of one rendered view (gaussian_model.py:779-790 add_densification_stats + the max_radii2D update of
+// gs_backend_per_frame.py:1021-1027): visible = radii > 0
+__global__ __launch_bounds__(256) void densify_stats_kernel(int P, const int* __restrict__ radii, const float* __restrict__ d_means2D,
+                                                            float* __restrict__ max_radii, float* __restrict__ grad_accum, float* __restrict__ denom) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r > 0) {
+        max_radii[i] = fmaxf(max_radii[i], (float)r);
+        const float gx = d_means2D[3 * i], gy = d_means2D[3 * i + 1];
+        grad_accum[i] += sqrtf(gx * gx + gy * gy);
+        denom[i] += 1.f;
+    }
+}
+
 // pose refinement (gs_backend_per_frame.py:240-262): colour L1 over the covered pixels (alpha > th) and the variance of
 // log d - log gt_d over the covered pixels with both depths valid.  sums[5] = {sum_a |gt - img|, |a|, sum_m diff, sum_m diff^2, |m|}.
 // backward: coef[3] (device) = {c_rgb, c_var, mean diff}:  grad_img = c_rgb sign(img - gt) on a;  grad_d = c_var 2 (diff - mean) / d on m.
@@ -1066,6 +1152,31 @@ extern "C" int cut3r_pixel_loss_backward(const float* img, const float* gt_img, 
     if (!img || !gt_img || !depth || !gt_depth || !gt_normal || !coef || !grad_img || !grad_depth || H < 3 || W < 3) return CUT3R_ERR_ARG;
     hipLaunchKernelGGL(pixel_loss_bwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, img, gt_img, depth, gt_depth, gt_normal, H,
                        W, PixCam{fx, fy, cx, cy}, coef, grad_img, grad_depth);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_normal_agree_forward(const float* normal, const float* depth, int H, int W, float fx, float fy, float cx, float cy,
+                                          float* sum, void* stream) {
+    if (!normal || !depth || !sum || H < 3 || W < 3) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sum, 0, sizeof(float), s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    hipLaunchKernelGGL(normal_agree_fwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, normal, depth, H, W, PixCam{fx, fy, cx, cy}, sum);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_normal_agree_backward(const float* normal, const float* depth, int H, int W, float fx, float fy, float cx, float cy,
+                                           float coef, float* grad_normal, float* grad_depth, void* stream) {
+    if (!normal || !depth || !grad_normal || !grad_depth || H < 3 || W < 3) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(normal_agree_bwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, normal, depth, H, W,
+                       PixCam{fx, fy, cx, cy}, coef, grad_normal, grad_depth);
+    return cut3r_check_launch();
+}
+
+extern "C" int cut3r_gs_densify_stats(int P, const int* radii, const float* d_means2D, float* max_radii2D, float* grad_accum, float* denom,
+                                      void* stream) {
+    if (P <= 0 || !radii || !d_means2D || !max_radii2D || !grad_accum || !denom) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, radii, d_means2D, max_radii2D, grad_accum,
+                       denom);
     return cut3r_check_launch();
 }
 

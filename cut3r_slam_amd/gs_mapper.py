@@ -456,15 +456,41 @@ class GSMapper:
         finally:
             if was:
                 gc.enable()
+        # state at the start of the replays: if a replayed iteration overflows the capacity its tile lists were truncated, and NO such
+        # iteration may be kept -- the replays are then undone and redone eagerly with exact instance counts
+        gm = self.gaussians
+        snap = (gm.theta.detach().clone(), gm.m.clone(), gm.v.clone(), gm.step_count.clone(), gm.steps,
+                [(v.R.clone(), v.T.clone(), v.w2c_data.clone(), v.cam_rot_delta.detach().clone(), v.cam_trans_delta.detach().clone())
+                 for v in self.viewpoints.values()],
+                [[{k: (t.clone() if torch.is_tensor(t) else t) for k, t in opt.state[p].items()} for p in grp["params"]] for grp in opt.param_groups]
+                if opt is not None else None)
         for _ in range(iters - warm):
             g.replay()
-        self.gaussians.steps += iters - warm - 1                          # (the capture pass advanced the host count once, every replay the device's)
+        gm.steps += iters - warm - 1                                      # (the capture pass advanced the host count once, every replay the device's)
         if int(flag):                                                     # one read after all replays
             import warnings
-            warnings.warn(f"GSMapper: the captured iterations needed more than {cap} tile instances; their tile lists were truncated "
-                          "(falling back to the eager loop for this mapper)", RuntimeWarning)
+            warnings.warn(f"GSMapper: a captured iteration needed more than {cap} tile instances; the {iters - warm} replayed iterations are "
+                          "redone eagerly from their starting state (and this mapper stops capturing)", RuntimeWarning)
             self.use_graphs = False
             flag.zero_()
+            with torch.no_grad():
+                gm.theta.data.copy_(snap[0]); gm.m.copy_(snap[1]); gm.v.copy_(snap[2]); gm.step_count.copy_(snap[3])
+                gm.steps = snap[4]
+                for v, (R, T, data, dr, dt) in zip(self.viewpoints.values(), snap[5]):
+                    v.update_RT(R, T, data=data)
+                    v.cam_rot_delta.data.copy_(dr); v.cam_trans_delta.data.copy_(dt)
+                if opt is not None:
+                    for grp, saved in zip(opt.param_groups, snap[6]):
+                        for p, st in zip(grp["params"], saved):
+                            for k, t in st.items():
+                                if torch.is_tensor(t):
+                                    opt.state[p][k].copy_(t)
+            last = None
+            with torch.cuda.stream(side):
+                for it in range(warm, iters):
+                    last = one_iteration(it, True)
+            torch.cuda.current_stream().wait_stream(side)
+            return last
         return static_loss
 
     def pose_refine(self, BA_window, iters=50, return_args=True, alpha_th=0.5, graph=None):
@@ -606,6 +632,8 @@ class GSMapper:
         if not views or len(self.gaussians) == 0:
             return None
         exposure = bool(self.config["Training"].get("compensate_exposure", False))
+        if self.fused and not exposure and iteration_total > 0:
+            return self._fused_trainer().global_BA(iteration_total, densify, densify_every, opacity_reset, seed)
         opt = self._pose_optimizer(views, exposure)
         rng = random.Random(seed)
         tr, op = self.config["Training"], self.config["opt_params"]

@@ -130,7 +130,7 @@ class FusedTrainer:
                                           _p(self.n_contrib), _p(self.aux), _s()), "gs_render_forward")
         return n_read
 
-    def _backward(self, v, ps_v, g_color, g_depth, iso_coef, gtheta, sums_v):
+    def _backward(self, v, ps_v, g_color, g_depth, iso_coef, gtheta, sums_v, g_normal=None):
         """rasteriser backward + activation chain of one view (its forward buffers are still the current ones)"""
         lib, P = self.lib, self._shape[0]
         H, W = self._shape[1:]
@@ -138,7 +138,8 @@ class FusedTrainer:
         self.flat.zero_()
         check(lib.cut3r_gs_render_backward(_p(self.ranges), _p(self.point_list), _p(self.geom), P, W, H, cam["tanx"], cam["tany"], _ZERO3,
                                            _p(self.n_contrib), _p(self.aux), _p(im["alpha"]), _p(im["coord"]), _p(im["depth"]), _p(im["normal"]),
-                                           _p(g_color), _p(z), _p(z), _p(g_depth), _p(z), _p(z), _p(z), _p(self.dgeom), _s()), "gs_render_backward")
+                                           _p(g_color), _p(z), _p(z), _p(g_depth), _p(z), _p(z), _p(g_normal if g_normal is not None else z), _p(self.dgeom),
+                                           _s()), "gs_render_backward")
         check(lib.cut3r_gs_preprocess_backward(P, _p(self.means), _p(self.scales), _p(self.rots), _p(self.opac), _p(self.shs), 0, 1, _IDENTITY16,
                                                cam["proj"], _ZERO3, W, H, cam["tanx"], cam["tany"], 0.0, 1.0, _p(self.geom), _p(self.dgeom),
                                                _p(self.d_means), _p(self.d_scales), _p(self.d_rots), _p(self.d_opac), _p(self.d_shs), None,
@@ -296,3 +297,80 @@ class FusedTrainer:
         for k in range(B):                                # update_pose: T <- exp(delta) T, delta <- 0
             check(lib.cut3r_gs_pose_step(_p(ps[k]), _p(sums[k]), 0.0, None, 0.0, 0.0, 2, _s()), "gs_pose_step (fold)")
         self._store_poses(views, ps)
+
+    def global_BA(self, iteration_total, densify=True, densify_every=None, opacity_reset=True, seed=0):
+        """GSMapper.global_BA (gs_backend_per_frame.py:946-1058) without exposure compensation: one randomly drawn keyframe per iteration,
+        colour + (inverse depth) + depth-normal agreement + the rendered-normal term (cut3r_normal_agree_*), densification statistics
+        (cut3r_gs_densify_stats), clone / split / prune and opacity resets at the reference's iterations, position learning-rate decay.
+        The instance count is read every iteration (the set of Gaussians changes under densification)."""
+        import random
+        from .gs_mapper import depth_to_normal, position_lr
+        mp, lib = self.mp, self.lib
+        gm = mp.gaussians
+        views = list(mp.viewpoints.values())
+        H, W = int(views[0].image_height), int(views[0].image_width)
+        ps = self._load_poses(views)
+        sums = torch.zeros(len(views), 16, dtype=torch.float32, device=self.dev)
+        rng = random.Random(seed)
+        tr, op = mp.config["Training"], mp.config["opt_params"]
+        update_every, reset_every = tr.get("gaussian_update_every", 200), tr.get("gaussian_reset", 3001)
+        lr = op["pose_lr"]
+        w_d, w_n = (mp.lambda_depth / 10, mp.lambda_normal) if densify_every is not None else (0.0, mp.lambda_normal / 2)
+        self._buffers(len(gm), H, W)
+        self.ssim_scale.fill_(-0.2 / (3 * H * W))
+        g_nrm = torch.empty(3, H, W, dtype=torch.float32, device=self.dev)
+        last = None
+        for iteration in range(iteration_total):
+            mp.iteration_count += 1
+            gm = mp.gaussians
+            P = len(gm)
+            self._buffers(P, H, W)
+            k = rng.randint(0, len(views) - 1)
+            v = views[k]
+            gc = getattr(v, "_gt_normal", None)
+            if gc is None or gc[0] is not v.depth:
+                v._gt_normal = (v.depth, depth_to_normal(v, v.depth[None]).detach().contiguous())
+            final = iteration == iteration_total - 1
+            cam, im = self._cam(v), self.img
+            K = cam["K"]
+            self.gtheta.zero_()
+            sums[k].zero_()
+            if final:
+                self.loss_acc.zero_()
+            self._render(v, ps[k], True)
+            check(lib.cut3r_pixel_loss_forward(_p(im["color"]), _p(v.original_image), _p(im["depth"]), _p(v.depth), _p(v._gt_normal[1]), H, W, K[0], K[1],
+                                               K[2], K[3], _p(self.sums), _s()), "pixel_loss_forward")
+            check(lib.cut3r_gs_map_coef(_p(self.sums), 0.8, float(w_d), float(w_n), 1.0, H, W, _p(self.coef), _p(self.loss_acc) if final else None, _s()),
+                  "gs_map_coef")
+            check(lib.cut3r_pixel_loss_backward(_p(im["color"]), _p(v.original_image), _p(im["depth"]), _p(v.depth), _p(v._gt_normal[1]), H, W, K[0], K[1],
+                                                K[2], K[3], _p(self.coef), _p(self.g_img), _p(self.g_depth), _s()), "pixel_loss_backward")
+            check(lib.cut3r_ssim_forward(_p(im["color"]), _p(v.original_image), 3, H, W, _p(self.smap), _p(self.sd1), _p(self.sd2), _p(self.sd3), _s()),
+                  "ssim_forward")
+            check(lib.cut3r_ssim_backward(_p(im["color"]), _p(v.original_image), _p(self.sd1), _p(self.sd2), _p(self.sd3), 3, H, W, _p(self.ssim_scale),
+                                          _p(self.g_ssim), _s()), "ssim_backward")
+            self.g_img.add_(self.g_ssim)
+            if final:
+                check(lib.cut3r_normal_agree_forward(_p(im["normal"]), _p(im["depth"]), H, W, K[0], K[1], K[2], K[3], _p(self.nvis), _s()), "normal_agree_forward")
+                last = self.loss_acc[0] + 0.2 * (1.0 - self.smap.mean()) + w_n * self.nvis[0] / (H * W)
+            check(lib.cut3r_normal_agree_backward(_p(im["normal"]), _p(im["depth"]), H, W, K[0], K[1], K[2], K[3], float(w_n) / (H * W), _p(g_nrm),
+                                                  _p(self.g_depth), _s()), "normal_agree_backward")
+            self._backward(v, ps[k], self.g_img, self.g_depth, 0.0, self.gtheta, sums[k], g_normal=g_nrm)
+            if iteration < 10000 and densify:
+                check(lib.cut3r_gs_densify_stats(P, _p(self.radii), _p(self.d_means2D), _p(gm.max_radii2D), _p(gm.grad_accum), _p(gm.denom), _s()),
+                      "gs_densify_stats")
+            gm.steps += 1
+            gm._steps_dev_stale = True
+            b1, b2 = 0.9, 0.999
+            check(lib.cut3r_gs_adam(P * 14, _p(gm.theta), _p(gm.m), _p(gm.v), _p(self.gtheta), _p(gm.lr), b1, b2, 1 - b1 ** gm.steps, 1 - b2 ** gm.steps,
+                                    1e-15, _s()), "gs_adam")
+            if iteration < 10000 and densify:
+                do_densify = (iteration == iteration_total // 2) if densify_every is not None else ((mp.iteration_count + 1) % update_every == 0)
+                if do_densify:
+                    gm.densify_and_prune(op["densify_grad_threshold"], mp.gaussian_th, mp.gaussian_extent, mp.size_threshold)
+                if (mp.iteration_count + 1) % reset_every == 0 and opacity_reset:
+                    gm.reset_opacity()
+            if densify and "position_lr_final" in op:
+                gm.lr[0, 0:3] = position_lr(op, iteration)
+            check(lib.cut3r_gs_pose_step(_p(ps[k]), _p(sums[k]), 0.0, None, lr * 2, lr * 10, 1, _s()), "gs_pose_step")
+        self._store_poses(views, ps)
+        return float(last) if last is not None else None

@@ -159,21 +159,25 @@ def gs_wall_window(H: int = 384, W: int = 512, focal: float = 440.0, n_views: in
     return packet, torch.stack(imgs), cfg
 
 
-def gs_mapper_window_leg(H: int = 384, W: int = 512, device="cuda:0", use_graphs: bool = False):
+def gs_mapper_window_leg(H: int = 384, W: int = 512, device="cuda:0", use_graphs: bool = False, fused: bool = True):
     """one synthetic 6-keyframe window through GSMapper.run with the reference's iteration counts (gs_backend_per_frame.py:776-862: 100
     initial, per new keyframe 50 pose-refine + 20 window + 50 single-view, 10 per view global) -> timing / quality figures"""
     import time
     from . import gs_mapper as GM
     packet, imgs, cfg = gs_wall_window(H, W, device=device)
     n = len(packet["viz_idx"])
-    mapper = GM.GSMapper(cfg, float(packet["intrinsics"][0]), float(packet["intrinsics"][1]), W / 2, H / 2, downsample_ratio=2, device=device)
-    mapper.use_graphs, mapper.graph_min_iters = use_graphs, 12
-    torch.cuda.synchronize()
-    t0 = time.time()
-    with torch.enable_grad():
-        mapper.run(packet, iterations=100)
-    torch.cuda.synchronize()
-    dt = time.time() - t0
+    times = []
+    for _ in range(2):                                # the first pass pays the one-time costs of the process (code objects, allocator pools)
+        mapper = GM.GSMapper(cfg, float(packet["intrinsics"][0]), float(packet["intrinsics"][1]), W / 2, H / 2, downsample_ratio=2, device=device)
+        mapper.use_graphs, mapper.graph_min_iters = use_graphs, 12
+        mapper.fused = fused
+        torch.cuda.synchronize()
+        t0 = time.time()
+        with torch.enable_grad():
+            mapper.run(packet, iterations=100)
+        torch.cuda.synchronize()
+        times.append(time.time() - t0)
+    dt = times[1]
     with torch.no_grad():
         ps = []
         for k in range(n):
@@ -182,7 +186,9 @@ def gs_mapper_window_leg(H: int = 384, W: int = 512, device="cuda:0", use_graphs
     renders = 100 + (n - 1) * (50 + 50) + sum(20 * min(k + 1, 10) for k in range(1, n)) + 10 * n
     return {"config": f"synthetic wall, {n} keyframes at {W}x{H}, one Gaussian per stride-2 pixel of the first keyframe, the reference's iteration counts"
                       + (", iterations without densification replayed from a captured hipGraph" if use_graphs else ""),
-            "seconds": round(dt, 3), "ms_per_keyframe": round(1e3 * dt / n, 1), "render_iterations": renders,
+            "trainer": "tape-free (gs_step.FusedTrainer: direct C-ABI calls)" if fused else "tensor-op formulation with autograd",
+            "seconds": round(dt, 3), "seconds_first_pass_in_process": round(times[0], 3), "ms_per_keyframe": round(1e3 * dt / n, 1),
+            "realtime_budget_ms_per_keyframe_at_30fps_kf_every_10": 333.3, "render_iterations": renders,
             "ms_per_render_iteration": round(1e3 * dt / renders, 3), "gaussians": len(mapper.gaussians), "psnr_db": round(sum(ps) / n, 2)}
 
 

@@ -424,6 +424,18 @@ int cut3r_pixel_loss_forward(const float* img, const float* gt_img, const float*
 int cut3r_pixel_loss_backward(const float* img, const float* gt_img, const float* depth, const float* gt_depth, const float* gt_normal, int H,
                               int W, float fx, float fy, float cx, float cy, const float* coef, float* grad_img, float* grad_depth,
                               void* stream);
+/* global_BA's rendered-normal term (hislam2/gs_backend_per_frame.py:996-1001): mean over ALL pixels of 1 - N . n(depth), N the rendered
+ * normal image [3,H,W], n(depth) the camera-frame normal of the rendered depth [H,W] (central differences of the back-projected
+ * neighbours, zero on the border).  forward: sum[0] (device) = the pixel sum.  backward: coef = upstream gradient * weight / (H W);
+ * grad_normal [3,H,W] is written, grad_depth [H,W] is ACCUMULATED into (after cut3r_pixel_loss_backward wrote it). */
+int cut3r_normal_agree_forward(const float* normal, const float* depth, int H, int W, float fx, float fy, float cx, float cy, float* sum,
+                               void* stream);
+int cut3r_normal_agree_backward(const float* normal, const float* depth, int H, int W, float fx, float fy, float cx, float cy, float coef,
+                                float* grad_normal, float* grad_depth, void* stream);
+/* densification statistics of one rendered view (hislam2/gaussian/scene/gaussian_model.py:779-790 add_densification_stats and the
+ * max_radii2D update of gs_backend_per_frame.py:1021-1027): for visible Gaussians (radii > 0) max_radii2D = max(., radius),
+ * grad_accum += |d_means2D.xy|, denom += 1. */
+int cut3r_gs_densify_stats(int P, const int* radii, const float* d_means2D, float* max_radii2D, float* grad_accum, float* denom, void* stream);
 /* the pose-refinement loss terms (hislam2/gs_backend_per_frame.py:240-262) in one pass: a = alpha > alpha_th, m = a and both depths >
  * 0.001.  forward: sums[5] = {sum_a |gt - img|, |a|, sum_m diff, sum_m diff^2, |m|}, diff = log d - log gt_d.  backward: coef[3] (device)
  * = {c_rgb, c_var, mean diff} -> grad_img = c_rgb sign(img - gt) on a, grad_depth = 2 c_var (diff - mean) / d on m. */

@@ -423,3 +423,28 @@ def test_tape_free_trainer_matches_the_tensor_op_formulation():
     b3.fused = False
     b3.optimization(1, optimize_pose=False, current_window=[0])
     assert int(b3.gaussians.step_count) == b3.gaussians.steps and not b3.gaussians._steps_dev_stale
+
+
+def test_tape_free_global_ba_matches_the_tensor_op_formulation():
+    """GSMapper.global_BA on the tape-free trainer (rendered-normal term on cut3r_normal_agree_*, statistics on cut3r_gs_densify_stats)
+    against the autograd formulation: one iteration -> the same gradient of every parameter (m = 0.1 g), the same densification
+    statistics, the same loss; 30 iterations with a densification at half time -> the same number of Gaussians and close losses."""
+    a, b = _pair()
+    la = a.global_BA(1, densify=True, densify_every=5, opacity_reset=False, seed=3)
+    lb = b.global_BA(1, densify=True, densify_every=5, opacity_reset=False, seed=3)
+    ga, gb = a.gaussians.m / 0.1, b.gaussians.m / 0.1
+    for name, (c0, c1) in {"xyz": (0, 3), "colour": (3, 6), "opacity": (6, 7), "log scale": (7, 10)}.items():
+        sc, err = float(ga[:, c0:c1].abs().max()), float((ga[:, c0:c1] - gb[:, c0:c1]).abs().max())
+        print(f"[gs fused global BA] d loss / d {name}: scale {sc:.3e}, max |autograd - fused| {err:.3e}")
+        assert sc > 0 and err <= 2e-4 * sc + 1e-9, (name, sc, err)
+    assert abs(la - lb) <= 1e-5 * abs(la) + 1e-6, (la, lb)
+    torch.testing.assert_close(b.gaussians.denom, a.gaussians.denom)
+    torch.testing.assert_close(b.gaussians.max_radii2D, a.gaussians.max_radii2D)
+    torch.testing.assert_close(b.gaussians.grad_accum, a.gaussians.grad_accum, rtol=1e-4, atol=1e-9)
+    torch.testing.assert_close(b.trajectory().detach(), a.trajectory().detach(), atol=1e-5, rtol=0)
+    a2, b2 = _pair()
+    l2a = a2.global_BA(30, densify=True, densify_every=15, opacity_reset=False, seed=5)
+    l2b = b2.global_BA(30, densify=True, densify_every=15, opacity_reset=False, seed=5)
+    print(f"[gs fused global BA] 30 iterations: autograd loss {l2a:.5f} ({len(a2.gaussians)} Gaussians), fused {l2b:.5f} ({len(b2.gaussians)})")
+    assert abs(len(a2.gaussians) - len(b2.gaussians)) <= 0.02 * len(a2.gaussians) + 2
+    assert abs(l2a - l2b) < 0.03 * l2a
