@@ -398,6 +398,7 @@ class GSMapper:
         # (tools/bench_gs.py: 2.30 -> 1.41 ms per render iteration over 400 iterations): it pays for long loops over a fixed set of Gaussians (a final refinement), not for the 20-100 iteration calls of run()
         self.use_graphs = False
         self.graph_min_iters = 150
+        self.graph_capacity = (1.25, 8192)       # tile-instance capacity of captured iterations: factor on the largest count seen + margin
         # optimization() / pose_refine() on the tape-free trainer of gs_step.py (direct C-ABI calls, ~4x fewer launches); False: the
         # tensor-op formulation below (the tests compare the two)
         self.fused = True
@@ -439,7 +440,7 @@ class GSMapper:
         with torch.cuda.stream(side):
             for it in range(warm):
                 last = one_iteration(it, True)
-            cap = int(1.25 * GR.LAST_INSTANCES[0]) + 8192
+            cap = int(self.graph_capacity[0] * GR.LAST_INSTANCES[0]) + int(self.graph_capacity[1])
             flag = GR.overflow_flag(self.device)
             flag.zero_()
             GR.workspace_bytes(len(self.gaussians), 0), GR.workspace_bytes(len(self.gaussians), cap)      # (size queries outside the capture)
@@ -459,7 +460,7 @@ class GSMapper:
         # state at the start of the replays: if a replayed iteration overflows the capacity its tile lists were truncated, and NO such
         # iteration may be kept -- the replays are then undone and redone eagerly with exact instance counts
         gm = self.gaussians
-        snap = (gm.theta.detach().clone(), gm.m.clone(), gm.v.clone(), gm.step_count.clone(), gm.steps,
+        snap = (gm.theta.detach().clone(), gm.m.clone(), gm.v.clone(), gm.step_count.clone(), gm.steps - 1,      # (- 1: the capture pass's host increment)
                 [(v.R.clone(), v.T.clone(), v.w2c_data.clone(), v.cam_rot_delta.detach().clone(), v.cam_trans_delta.detach().clone())
                  for v in self.viewpoints.values()],
                 [[{k: (t.clone() if torch.is_tensor(t) else t) for k, t in opt.state[p].items()} for p in grp["params"]] for grp in opt.param_groups]

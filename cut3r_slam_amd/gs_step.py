@@ -52,6 +52,8 @@ class FusedTrainer:
         self.lib = _lib.load()
         self._shape = None
         self._cap = 0
+        self.capacity = (1.5, 16384)             # capacity-mode iterations: factor on the largest instance count of iteration 0 + margin
+        self.redone = 0                          # calls that overflowed their capacity and were redone from the snapshot
 
     # ------------------------------------------------------------------ buffers
     def _buffers(self, P, H, W):
@@ -171,12 +173,13 @@ class FusedTrainer:
         flag = GR.overflow_flag(self.dev)
         flag.zero_()
         counts = body(0, True)
-        self._n_cap = int(1.5 * max(counts)) + 16384
+        self._n_cap = int(self.capacity[0] * max(counts)) + int(self.capacity[1])
         self._sort_buffers(self._n_cap)
         for it in range(1, iters):
             body(it, False)
         if iters > 1 and int(flag.item()):
             flag.zero_()
+            self.redone += 1
             snapshot(restore=True)
             for it in range(iters):
                 body(it, True)

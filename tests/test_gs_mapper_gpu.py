@@ -448,3 +448,35 @@ def test_tape_free_global_ba_matches_the_tensor_op_formulation():
     print(f"[gs fused global BA] 30 iterations: autograd loss {l2a:.5f} ({len(a2.gaussians)} Gaussians), fused {l2b:.5f} ({len(b2.gaussians)})")
     assert abs(len(a2.gaussians) - len(b2.gaussians)) <= 0.02 * len(a2.gaussians) + 2
     assert abs(l2a - l2b) < 0.03 * l2a
+
+
+def test_an_overflowed_capacity_is_never_kept():
+    """capacity mode (no instance-count read) must not change results: with a capacity that is far too small the tape-free trainer restores
+    its snapshot and redoes the call with exact counts, and the captured-graph loop of the tensor-op formulation redoes its replays eagerly
+    -- both end where the exact loops end (truncated tile lists used to stay applied)"""
+    import warnings
+    a, b = _pair()                                    # b: tape-free
+    ref_pair = _pair()[1]
+    ref_pair.gaussians.theta = b.gaussians.theta.detach().clone().requires_grad_(True)
+    ref_pair.gaussians.m, ref_pair.gaussians.v = b.gaussians.m.clone(), b.gaussians.v.clone()
+    for k in b.viewpoints:
+        ref_pair.viewpoints[k].update_RT(b.viewpoints[k].R, b.viewpoints[k].T, data=b.viewpoints[k].w2c_data)
+    b._fused_trainer().capacity = (0.0, 64)
+    lb = b.optimization(6, optimize_pose=True, current_window=[0, 1])
+    assert b._fused_trainer().redone == 1
+    lr_ = ref_pair.optimization(6, optimize_pose=True, current_window=[0, 1])
+    assert ref_pair._fused_trainer().redone == 0
+    assert abs(lb - lr_) < 0.02 * lr_
+    torch.testing.assert_close(b.trajectory().detach(), ref_pair.trajectory().detach(), atol=1e-4, rtol=0)
+    assert b.gaussians.steps == ref_pair.gaussians.steps
+    # tensor-op formulation, captured iterations
+    c, _ = _pair()
+    c.graph_capacity = (0.0, 64)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lc = c.optimization(12, optimize_pose=True, current_window=[0, 1], graph=True)
+    assert any("redone eagerly" in str(x.message) for x in w) and not c.use_graphs
+    la = a.optimization(12, optimize_pose=True, current_window=[0, 1], graph=False)
+    assert abs(lc - la) < 0.02 * la
+    torch.testing.assert_close(c.trajectory().detach(), a.trajectory().detach(), atol=2e-4, rtol=0)
+    assert int(c.gaussians.step_count) == int(a.gaussians.step_count) == c.gaussians.steps
