@@ -110,10 +110,13 @@ class KernelProbe:
     kernels (the C-ABI entry points are wrapped; events bracket live launches of an eager pass, never a graph replay)."""
 
     GEMM = {128: "gemm_kernel<128,128,2,4,2> (v_mfma_f32_16x16x32_f16, 8 waves, 2 workgroups/CU)",
-            256: "gemm256_kernel (256x256x64, v_mfma_f32_16x16x32_f16, 8 waves ping-pong, 1 workgroup/CU)"}
+            256: "gemm256_kernel (256x256x64, v_mfma_f32_16x16x32_f16, 8 waves ping-pong, 1 workgroup/CU)",
+            64: "gemm_kernel<64,64> (4 waves)", 192: "gemm_kernel<192,128> (DPT 3x3 convolutions, 128 output channels)",
+            128192: "gemm_kernel<128,192> (48-wide heads)", 16: "gemm_skinny_kernel (M <= 64: weight stream, HBM-bound)"}
 
-    def __init__(self):
+    def __init__(self, all_tiles=False):
         self.rec = {}          # key -> [events, flops, bytes]
+        self.all_tiles = all_tiles
 
     def _add(self, key, s, e, flops, nbytes):
         r = self.rec.setdefault(key, [[], 0.0, 0.0])
@@ -130,7 +133,7 @@ class KernelProbe:
         def gemm(dref, stream):
             d = dref._obj
             tile = lib.cut3r_gemm_tile_for(dref)
-            if tile not in (128, 256):
+            if tile not in (128, 256) and not probe.all_tiles:
                 return raw_gemm(dref, stream)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -138,8 +141,10 @@ class KernelProbe:
             e.record()
             nb = max(d.batch, 1)
             a_bytes = d.M * d.Cin * 2 if d.conv_k == 3 else d.M * d.K * 2        # a conv input is read once
-            probe._add(("gemm", tile), s, e, 2.0 * d.M * d.N * d.K * nb,
-                       nb * (a_bytes + d.N * d.K * 2 + d.M * d.N * (2 if d.out_f16 else 4) + (d.M * d.N * (2 if d.res1_f16 else 4) if d.res1 else 0)))
+            fl = 2.0 * d.M * d.N * d.K * nb
+            by = nb * (a_bytes + d.N * d.K * 2 + d.M * d.N * (2 if d.out_f16 else 4) + (d.M * d.N * (2 if d.res1_f16 else 4) if d.res1 else 0))
+            probe._add(("gemm", tile), s, e, fl, by)
+            probe._add(("shape", tile, d.M, d.N, d.K, int(d.conv_k), "f16" if d.out_f16 else "f32", "res" if d.res1 else "", int(d.act)), s, e, fl, by)
             return rc
 
         def attn(q, k, v, o, B, Hh, Nq, Nk, D, *rest):
@@ -148,7 +153,7 @@ class KernelProbe:
             rc = raw_attn(q, k, v, o, B, Hh, Nq, Nk, D, *rest)
             e.record()
             if Nq >= 128 and Nk >= 128:
-                probe._add(("attn", D, "enc" if B * Nq >= 8 * 768 and D == 64 and Hh == 16 else "dec"), s, e, 4.0 * B * Hh * Nq * Nk * D,
+                probe._add(("attn", D, "enc" if D == 64 and Hh == 16 else "dec"), s, e, 4.0 * B * Hh * Nq * Nk * D,
                            2.0 * B * Hh * D * (2 * Nq + 2 * Nk))
             return rc
 
@@ -162,6 +167,40 @@ class KernelProbe:
         """{key: (launches, total ms, flops, algorithmic bytes)}"""
         torch.cuda.synchronize()
         return {k: (len(ev), sum(s.elapsed_time(e) for s, e in ev), fl, by) for k, (ev, fl, by) in self.rec.items()}
+
+
+PEAK_HBM = 8000.0          # GB/s (MI355X_MICROARCH.md)
+
+
+def shape_entries(res, top=14):
+    """the GEMM launches of an instrumented pass by shape: algorithmic FLOPs and bytes per launch, the time each roof alone would allow
+    (dense fp16 MFMA peak, HBM peak), which one binds, and the achieved fraction of THAT roof -- short-K projections with an fp32
+    residual read + write are HBM-bound, not MFMA-bound"""
+    out = []
+    sh = {k: v for k, v in res.items() if k[0] == "shape" and v[0]}
+    tot = sum(v[1] for v in sh.values())
+    for k, (n, ms, fl, by) in sorted(sh.items(), key=lambda kv: -kv[1][1])[:top]:
+        us = ms * 1e3 / n
+        t_mfma, t_hbm = fl / n / (PEAK_F16 * 1e12) * 1e6, by / n / (PEAK_HBM * 1e9) * 1e6
+        out.append({"tile": k[1], "M": k[2], "N": k[3], "K": k[4], "conv": k[5], "out": k[6], "residual": bool(k[7]), "act": k[8], "launches": n,
+                    "avg_launch_us": round(us, 2), "share_of_gemm_time": round(ms / tot, 4), "tflops": round(fl / n / us / 1e6, 1),
+                    "algorithmic_gb_per_s": round(by / n / us / 1e3, 1), "roof_us_mfma": round(t_mfma, 2), "roof_us_hbm": round(t_hbm, 2),
+                    "bound": "hbm" if t_hbm > t_mfma else "mfma", "frac_of_binding_roof": round(max(t_mfma, t_hbm) / us, 4)})
+    return out
+
+
+def probe_entries(res):
+    """[{kernel, launches, avg_launch_us, achieved TFLOP/s, frac of the dense fp16 MFMA peak}] of an instrumented pass, by total time"""
+    out = []
+    for k, (n, ms, fl, by) in sorted(res.items(), key=lambda kv: -kv[1][1]):
+        if not n or ms <= 0 or k[0] == "shape":
+            continue
+        name = KernelProbe.GEMM.get(k[1], f"gemm tile {k[1]}") if k[0] == "gemm" else \
+            f"attn_kernel<{k[1]},4> ({'encoder self-attention' if k[2] == 'enc' else 'decoder self/cross attention'})"
+        out.append({"kernel": name, "bound": "mfma" if not (k[0] == "gemm" and k[1] == 16) else "hbm", "launches": n,
+                    "avg_launch_us": round(ms * 1e3 / n, 2), "total_ms": round(ms, 3), "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_F16,
+                    "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_F16, 4), "flops_per_launch": fl / n})
+    return out
 
 
 def log(msg):
@@ -193,7 +232,7 @@ def traffic_from_profile(tile, launches_in_run):
     correction of MI355X_MICROARCH.md).  PMC counters need the profiler, so this is never measured inside the run itself: it is
     emitted with its provenance.  FETCH_SIZE counts what the 8 per-XCD L2s request from the fabric, so operands every XCD reads
     (the weight panel) count 8 times although the Infinity Cache serves them."""
-    pj = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+    pj = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
     if os.path.isfile(pj):
         j = json.load(open(pj))
         cand = [v for n, v in j.get("kernels", {}).items() if tile in PMC_KEYS and n.startswith(PMC_KEYS[tile]) and v.get("launches")]
@@ -204,7 +243,7 @@ def traffic_from_profile(tile, launches_in_run):
         if k:
             return {"bytes_per_launch": k.get("traffic_bytes_per_launch"), "source": os.path.relpath(pj, ROOT),
                     "profile_launches": k.get("launches"), "profile_git_sha": j.get("git_sha"), "run_launches": launches_in_run,
-                    "note": "separate rocprofv3 --pmc passes of `bench.py --steps 2` (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE), averaged over "
+                    "note": "separate rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1` (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE), averaged over "
                             "every launch of this kernel in the step; not measured in this run"}
     return None
 
@@ -601,16 +640,36 @@ def main():
                             "frac": round(ach / PEAK_F16, 4), "traffic": (tfp or {}).get("bytes_per_launch"), "traffic_from_profile": tfp,
                             "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n,
                             "algorithmic_bytes_per_launch": by / n, "share_of_large_gemm_time": round(ms / tot_ms, 3),
-                            "second_kernel": others[0] if others else None, "other_kernels": others}
+                            "second_kernel": others[0] if others else None, "other_kernels": others, "gemm_shapes": shape_entries(res)}
     if single and not args.small and not args.no_operating_points:
         log("operating points: fixed cadence with one window at a time")
         del leg, runner, slam
         op_points = {}
-        l1 = fixed_cadence_leg(model, Cut3rSlam, cdist, dev, 1, 16, 4, barrier=barrier)
+        l1 = fixed_cadence_leg(model, Cut3rSlam, cdist, dev, 1, 16, 4, barrier=barrier, probe_steps=4)
         op_points["fixed_cadence_window_batch_1"] = {
             "config": "kf_every=10, window_batch=1: the reference's one-window-at-a-time schedule (50 frames of buffering)",
             "frames_per_s": round(16 * l1["frames_per_step"] / l1["elapsed"], 1), "ms_per_window": round(1e3 * l1["elapsed"] / 16, 3), "windows": 16,
             "health": l1["health"]}
+        if not args.no_roofline:
+            # the M = 769 / 768 shapes of ONE window (decoder GEMMs of 4 x 7 row tiles of 128^2, encoder batch 5): HIP events around
+            # every GEMM / attention launch of four eager windows
+            pr = KernelProbe(all_tiles=True)
+            pr.install()
+            model.use_graphs = False
+            tt = l1["t"]
+            for _ in range(4):
+                tt = l1["runner"].step(l1["frames"], tt, KF_EVERY, WIN, l1["intr"])
+            l1["runner"].flush()
+            r1 = pr.result()
+            pr.remove()
+            model.use_graphs = True
+            ent = probe_entries(r1)
+            tot_fl, tot_ms = sum(v[2] for k, v in r1.items() if k[0] != "shape"), sum(v[1] for k, v in r1.items() if k[0] != "shape")
+            op_points["fixed_cadence_window_batch_1"]["roofline"] = {
+                "note": "eager pass, HIP events on the launch stream: per-kernel rates of the one-window shapes (M = 769 / 768 rows; in the timed graph "
+                        "replay the two decoder streams and the DPT head of the previous view run side by side)",
+                "mfma_frac_of_probed_kernel_time": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F16, 4) if tot_ms > 0 else None,
+                "kernels": ent, "gemm_shapes": shape_entries(r1, 8)}
         del l1
         if SEQ > 0:
             log("operating points: the same schedule over ONE endless stream (covisibility tests against every earlier keyframe)")
