@@ -183,3 +183,27 @@ def test_reference_import_names_resolve_from_the_compat_directory():
             % os.path.join(root, "cut3r_slam_amd", "compat"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_position_learning_rate_keeps_decaying_beyond_iteration_10000():
+    """the reference calls update_learning_rate(iteration) on EVERY iteration of a densifying global BA
+    (hislam2/gs_backend_per_frame.py:1043-1044; general_utils.py:41-56 log-linear from position_lr_init to position_lr_final over
+    position_lr_max_steps + 1000 steps); only the densification statistics stop at 10000.  finalize() runs 20000-26000 iterations."""
+    import math
+    from cut3r_slam_amd.gs_mapper import position_lr
+    op = {"position_lr_init": 1.6e-4, "position_lr_final": 1.6e-6, "position_lr_max_steps": 20000}
+    assert abs(position_lr(op, 0) - 1.6e-4) < 1e-12
+    assert abs(position_lr(op, 21000) - 1.6e-6) < 1e-12 and abs(position_lr(op, 30000) - 1.6e-6) < 1e-12
+    for it in (9999, 10000, 15000, 20000):
+        t = it / 21000.0
+        assert abs(position_lr(op, it) - math.exp(math.log(1.6e-4) * (1 - t) + math.log(1.6e-6) * t)) < 1e-15
+    assert position_lr(op, 15000) < 0.4 * position_lr(op, 9999)          # it did not freeze at its iteration-9999 value
+    # both formulations of global_BA apply it outside the `iteration < 10000` guard
+    import inspect
+    from cut3r_slam_amd import gs_mapper, gs_step
+    for src in (inspect.getsource(gs_mapper.GSMapper.global_BA), inspect.getsource(gs_step.FusedTrainer.global_BA)):
+        guard = src.index("if densify and \"position_lr_final\" in op")
+        line_start = src.rfind("\n", 0, guard) + 1
+        indent = guard - line_start
+        inner = src.index("if iteration < 10000 and densify")
+        assert indent <= inner - (src.rfind("\n", 0, inner) + 1), "the learning-rate decay sits inside the 10000-iteration guard again"
