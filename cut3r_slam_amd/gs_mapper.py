@@ -701,6 +701,8 @@ class GSMapper:
         views = list(self.viewpoints.values())
         if not views or len(self.gaussians) == 0:
             return None
+        if self.fused and iteration_total > 0:
+            return self._fused_trainer().reinit_loop(iteration_total, seed)
         rng = random.Random(seed)
         update_every = self.config["Training"].get("gaussian_update_every", 200)
         last = None

@@ -377,3 +377,61 @@ class FusedTrainer:
             check(lib.cut3r_gs_pose_step(_p(ps[k]), _p(sums[k]), 0.0, None, lr * 2, lr * 10, 1, _s()), "gs_pose_step")
         self._store_poses(views, ps)
         return float(last) if last is not None else None
+
+    def reinit_loop(self, iteration_total, seed=0):
+        """the training loop of GSMapper.gaussian_reinit (gs_backend_per_frame.py:865-944): single-view iterations with FIXED poses --
+        colour, inverse depth and the depth-normal term -- densification statistics and clone / split / prune every
+        Training.gaussian_update_every iterations after the first 1000"""
+        import random
+        from .gs_mapper import depth_to_normal
+        mp, lib = self.mp, self.lib
+        views = list(mp.viewpoints.values())
+        H, W = int(views[0].image_height), int(views[0].image_width)
+        ps = self._load_poses(views)
+        rng = random.Random(seed)
+        update_every = mp.config["Training"].get("gaussian_update_every", 200)
+        op = mp.config["opt_params"]
+        self._buffers(len(mp.gaussians), H, W)
+        self.ssim_scale.fill_(-0.2 / (3 * H * W))
+        last = None
+        for iteration in range(iteration_total):
+            gm = mp.gaussians
+            P = len(gm)
+            self._buffers(P, H, W)
+            k = rng.randint(0, len(views) - 1)
+            v = views[k]
+            gc = getattr(v, "_gt_normal", None)
+            if gc is None or gc[0] is not v.depth:
+                v._gt_normal = (v.depth, depth_to_normal(v, v.depth[None]).detach().contiguous())
+            final = iteration == iteration_total - 1
+            cam, im = self._cam(v), self.img
+            K = cam["K"]
+            self.gtheta.zero_()
+            if final:
+                self.loss_acc.zero_()
+            self._render(v, ps[k], True)
+            check(lib.cut3r_pixel_loss_forward(_p(im["color"]), _p(v.original_image), _p(im["depth"]), _p(v.depth), _p(v._gt_normal[1]), H, W, K[0], K[1],
+                                               K[2], K[3], _p(self.sums), _s()), "pixel_loss_forward")
+            check(lib.cut3r_gs_map_coef(_p(self.sums), 0.8, float(mp.lambda_depth), float(mp.lambda_normal), 1.0, H, W, _p(self.coef),
+                                        _p(self.loss_acc) if final else None, _s()), "gs_map_coef")
+            check(lib.cut3r_pixel_loss_backward(_p(im["color"]), _p(v.original_image), _p(im["depth"]), _p(v.depth), _p(v._gt_normal[1]), H, W, K[0], K[1],
+                                                K[2], K[3], _p(self.coef), _p(self.g_img), _p(self.g_depth), _s()), "pixel_loss_backward")
+            check(lib.cut3r_ssim_forward(_p(im["color"]), _p(v.original_image), 3, H, W, _p(self.smap), _p(self.sd1), _p(self.sd2), _p(self.sd3), _s()),
+                  "ssim_forward")
+            check(lib.cut3r_ssim_backward(_p(im["color"]), _p(v.original_image), _p(self.sd1), _p(self.sd2), _p(self.sd3), 3, H, W, _p(self.ssim_scale),
+                                          _p(self.g_ssim), _s()), "ssim_backward")
+            self.g_img.add_(self.g_ssim)
+            if final:
+                last = self.loss_acc[0] + 0.2 * (1.0 - self.smap.mean())
+            self._backward(v, ps[k], self.g_img, self.g_depth, 0.0, self.gtheta, None)
+            if iteration > 1000:
+                check(lib.cut3r_gs_densify_stats(P, _p(self.radii), _p(self.d_means2D), _p(gm.max_radii2D), _p(gm.grad_accum), _p(gm.denom), _s()),
+                      "gs_densify_stats")
+            gm.steps += 1
+            gm._steps_dev_stale = True
+            b1, b2 = 0.9, 0.999
+            check(lib.cut3r_gs_adam(P * 14, _p(gm.theta), _p(gm.m), _p(gm.v), _p(self.gtheta), _p(gm.lr), b1, b2, 1 - b1 ** gm.steps, 1 - b2 ** gm.steps,
+                                    1e-15, _s()), "gs_adam")
+            if iteration > 1000 and (iteration + 1) % update_every == 0:
+                gm.densify_and_prune(op["densify_grad_threshold"], mp.gaussian_th, mp.gaussian_extent, mp.size_threshold)
+        return float(last) if last is not None else None
