@@ -131,10 +131,13 @@ SIGNATURES = {
     "cut3r_gs_refine_coef": [c_void_p, c_float, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "cut3r_knn3_chunks": [c_int],
     "cut3r_knn3_mean_dist2": [c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "cut3r_knn3_grid_workspace_bytes": [c_int],
+    "cut3r_knn3_grid_mean_dist2": [c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p],
     "cut3r_gs_render_backward": [c_void_p] * 3 + [c_int, c_int, c_int, c_float, c_float] + [c_void_p] * 16,
     "cut3r_gs_preprocess_backward": [c_int] + [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 3 + [c_int, c_int] + [c_float] * 4 + [c_void_p] * 10,
 }
-RESTYPES = {"cut3r_ba_workspace_floats": c_ll, "cut3r_gs_workspace_bytes": c_ll, "cut3r_schur_mono_prior_workspace_floats": c_ll}
+RESTYPES = {"cut3r_ba_workspace_floats": c_ll, "cut3r_gs_workspace_bytes": c_ll, "cut3r_schur_mono_prior_workspace_floats": c_ll,
+            "cut3r_knn3_grid_workspace_bytes": c_ll}
 
 _lib = None
 

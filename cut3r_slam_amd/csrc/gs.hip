@@ -655,6 +655,111 @@ __global__ __launch_bounds__(256) void knn3_merge_kernel(const float* __restrict
     out[i] = (b0 + b1 + b2) / 3.f;
 }
 
+// ------------------------------------------------------------------------------------------------ 3-NN on a uniform grid (large maps)
+// The exhaustive search above costs P^2 pairs (200 ms at 800 k points).  For large P the points are binned into a uniform grid
+// (cell edge = longest bounding-box extent / G, G ~ sqrt(P) / 2 capped at 160: pointmaps are surfaces, so an occupied cell then holds a
+// few tens of points), sorted by cell with a counting sort, and every point searches the shells of cells around its own in growing
+// Chebyshev radius R until its third-best squared distance is <= (R * edge)^2 -- every unseen point lies in a cell at least R + 1 away,
+// i.e. at least R * edge from the query -- so the result is EXACT: the same three distances as the exhaustive search.
+struct KnnHdr { float minx, miny, minz, cs, inv_cs; int gx, gy, gz; };
+
+DEVINL unsigned knn_enc(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }     // order-preserving
+DEVINL float knn_dec(unsigned e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
+
+__global__ __launch_bounds__(256) void knn_bbox_kernel(const float* __restrict__ pts, int P, unsigned* __restrict__ bb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    if (i < P) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) lo[a] = hi[a] = pts[3 * (size_t)i + a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float l = lo[a], h = hi[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { l = fminf(l, __shfl_xor(l, o, 64)); h = fmaxf(h, __shfl_xor(h, o, 64)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(bb + a, knn_enc(l)); atomicMax(bb + 3 + a, knn_enc(h)); }
+    }
+}
+
+__global__ void knn_header_kernel(const unsigned* __restrict__ bb, int G, KnnHdr* __restrict__ hdr) {
+    if (threadIdx.x != 0) return;
+    const float lx = knn_dec(bb[0]), ly = knn_dec(bb[1]), lz = knn_dec(bb[2]);
+    const float ex = knn_dec(bb[3]) - lx, ey = knn_dec(bb[4]) - ly, ez = knn_dec(bb[5]) - lz;
+    float cs = fmaxf(ex, fmaxf(ey, ez)) / (float)G;
+    if (!(cs > 0.f)) cs = 1.f;                                   // all points identical
+    KnnHdr h;
+    h.minx = lx; h.miny = ly; h.minz = lz; h.cs = cs; h.inv_cs = 1.0f / cs;
+    h.gx = min(G + 1, (int)(ex * h.inv_cs) + 1); h.gy = min(G + 1, (int)(ey * h.inv_cs) + 1); h.gz = min(G + 1, (int)(ez * h.inv_cs) + 1);
+    *hdr = h;
+}
+
+DEVINL void knn_cell(const KnnHdr& h, float x, float y, float z, int& cx, int& cy, int& cz) {
+    cx = min(h.gx - 1, max(0, (int)((x - h.minx) * h.inv_cs)));
+    cy = min(h.gy - 1, max(0, (int)((y - h.miny) * h.inv_cs)));
+    cz = min(h.gz - 1, max(0, (int)((z - h.minz) * h.inv_cs)));
+}
+
+__global__ __launch_bounds__(256) void knn_count_kernel(const float* __restrict__ pts, int P, const KnnHdr* __restrict__ hdr, int* __restrict__ cell_of,
+                                                        unsigned* __restrict__ counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const KnnHdr h = *hdr;
+    int cx, cy, cz;
+    knn_cell(h, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], cx, cy, cz);
+    const int c = (cz * h.gy + cy) * h.gx + cx;
+    cell_of[i] = c;
+    atomicAdd(counts + c, 1u);
+}
+
+__global__ __launch_bounds__(256) void knn_scatter_kernel(const float* __restrict__ pts, int P, const int* __restrict__ cell_of,
+                                                          const unsigned* __restrict__ starts, unsigned* __restrict__ cursor,
+                                                          float* __restrict__ spts, int* __restrict__ sidx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int c = cell_of[i];
+    const unsigned pos = starts[c] + atomicAdd(cursor + c, 1u);
+    spts[3 * (size_t)pos] = pts[3 * (size_t)i]; spts[3 * (size_t)pos + 1] = pts[3 * (size_t)i + 1]; spts[3 * (size_t)pos + 2] = pts[3 * (size_t)i + 2];
+    sidx[pos] = i;
+}
+
+// one thread per point in SORTED order (neighbouring threads share cells)
+__global__ __launch_bounds__(256) void knn_query_kernel(int P, const KnnHdr* __restrict__ hdr, const unsigned* __restrict__ starts,
+                                                        const float* __restrict__ spts, const int* __restrict__ sidx, float* __restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= P) return;
+    const KnnHdr h = *hdr;
+    const float x = spts[3 * (size_t)t], y = spts[3 * (size_t)t + 1], z = spts[3 * (size_t)t + 2];
+    int cx, cy, cz;
+    knn_cell(h, x, y, z, cx, cy, cz);
+    float b0 = 3.402823466e38f, b1 = b0, b2 = b0;
+    const int rmax = max(h.gx, max(h.gy, h.gz));
+    for (int R = 0; R <= rmax; R++) {
+        const int z0 = max(0, cz - R), z1 = min(h.gz - 1, cz + R), y0 = max(0, cy - R), y1 = min(h.gy - 1, cy + R);
+        const int x0 = max(0, cx - R), x1 = min(h.gx - 1, cx + R);
+        for (int zz = z0; zz <= z1; zz++)
+            for (int yy = y0; yy <= y1; yy++) {
+                const bool face = (zz == cz - R) || (zz == cz + R) || (yy == cy - R) || (yy == cy + R);      // whole row on the shell
+                for (int xx = x0; xx <= x1; xx += (face || R == 0) ? 1 : max(1, x1 - x0)) {
+                    if (!face && R > 0 && xx != cx - R && xx != cx + R) continue;                            // interior rows: the two end cells only
+                    const int c = (zz * h.gy + yy) * h.gx + xx;
+                    const unsigned a = starts[c], e = starts[c + 1];
+                    for (unsigned j = a; j < e; j++) {
+                        if ((int)j == t) continue;                                                           // the point itself
+                        const float dx = spts[3 * (size_t)j] - x, dy = spts[3 * (size_t)j + 1] - y, dz = spts[3 * (size_t)j + 2] - z;
+                        float d = dx * dx + dy * dy + dz * dz;
+                        const float t0 = fminf(b0, d); d = fmaxf(b0, d); b0 = t0;
+                        const float t1 = fminf(b1, d); d = fmaxf(b1, d); b1 = t1;
+                        b2 = fminf(b2, d);
+                    }
+                }
+            }
+        const float reach = (float)R * h.cs;
+        if (b2 <= reach * reach) break;
+    }
+    out[sidx[t]] = (b0 + b1 + b2) / 3.f;
+}
+
 // ------------------------------------------------------------------------------------------------ SSIM (the mapper's colour loss)
 // hislam2/gaussian/utils/loss_utils.py:129-170 (`ssim`, 11x11 Gaussian window sigma 1.5, zero padding, per channel) as two
 // separable passes through LDS: a 16x16 output tile reads its 26x26 neighbourhood of both images once, filters the five moments
@@ -1117,6 +1222,50 @@ extern "C" int cut3r_knn3_mean_dist2(const float* points, int P, float* out, flo
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(knn3_kernel, dim3((P + 255) / 256, chunks), dim3(256), 0, s, points, P, chunk, workspace);
     hipLaunchKernelGGL(knn3_merge_kernel, dim3((P + 255) / 256), dim3(256), 0, s, workspace, P, chunks, out);
+    return cut3r_check_launch();
+}
+
+static int knn3_grid_G(int P) {
+    int G = (int)ceil(sqrt((double)P) / 2.0);
+    return G < 8 ? 8 : (G > 160 ? 160 : G);
+}
+
+extern "C" long long cut3r_knn3_grid_workspace_bytes(int P) {
+    if (P <= 0) return 0;
+    const long long G = knn3_grid_G(P), nc = (G + 1) * (G + 1) * (G + 1);
+    size_t scan = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (unsigned*)nullptr, (unsigned*)nullptr, (int)(nc + 1), (hipStream_t)0);
+    // header + bbox | cell_of [P] | counts [nc+1] | starts [nc+1] | cursor [nc] | sorted points [P,3] | sorted index [P] | scan scratch
+    return 256 + 4LL * P + 4 * (nc + 1) + 4 * (nc + 1) + 4 * nc + 12LL * P + 4LL * P + (long long)scan + 1024;
+}
+
+extern "C" int cut3r_knn3_grid_mean_dist2(const float* points, int P, float* out, void* workspace, long long workspace_bytes, void* stream) {
+    if (!points || !out || !workspace || P < 4 || workspace_bytes < cut3r_knn3_grid_workspace_bytes(P)) return CUT3R_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = knn3_grid_G(P);
+    const long long nc = (long long)(G + 1) * (G + 1) * (G + 1);
+    char* w = (char*)workspace;
+    KnnHdr* hdr = (KnnHdr*)w;
+    unsigned* bb = (unsigned*)(w + 64);
+    int* cell_of = (int*)(w + 256);
+    unsigned* counts = (unsigned*)(cell_of + P);
+    unsigned* starts = counts + (nc + 1);
+    unsigned* cursor = starts + (nc + 1);
+    float* spts = (float*)(cursor + nc);
+    int* sidx = (int*)(spts + 3 * (size_t)P);
+    void* scan_ws = (void*)(((uintptr_t)(sidx + P) + 255) & ~(uintptr_t)255);
+    size_t scan_bytes = (size_t)((char*)workspace + workspace_bytes - (char*)scan_ws);
+    if (hipMemsetAsync(bb, 0xFF, 3 * sizeof(unsigned), s) != hipSuccess) return CUT3R_ERR_LAUNCH;          // encoded minima start at the top
+    if (hipMemsetAsync(bb + 3, 0, 3 * sizeof(unsigned), s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    if (hipMemsetAsync(counts, 0, sizeof(unsigned) * (size_t)(nc + 1), s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    if (hipMemsetAsync(cursor, 0, sizeof(unsigned) * (size_t)nc, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    const unsigned nb = (unsigned)((P + 255) / 256);
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(nb), dim3(256), 0, s, points, P, bb);
+    hipLaunchKernelGGL(knn_header_kernel, dim3(1), dim3(64), 0, s, bb, G, hdr);
+    hipLaunchKernelGGL(knn_count_kernel, dim3(nb), dim3(256), 0, s, points, P, hdr, cell_of, counts);
+    if (hipcub::DeviceScan::ExclusiveSum(scan_ws, scan_bytes, counts, starts, (int)(nc + 1), s) != hipSuccess) return CUT3R_ERR_ARG;
+    hipLaunchKernelGGL(knn_scatter_kernel, dim3(nb), dim3(256), 0, s, points, P, cell_of, starts, cursor, spts, sidx);
+    hipLaunchKernelGGL(knn_query_kernel, dim3(nb), dim3(256), 0, s, P, hdr, starts, spts, sidx, out);
     return cut3r_check_launch();
 }
 

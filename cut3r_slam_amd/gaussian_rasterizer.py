@@ -64,6 +64,7 @@ class fixed_capacity:
         _CAPACITY[0] = self.prev
         return False
 
+KNN_GRID_MIN = 200_000           # distCUDA2: from this many points on, the grid search (exact) replaces the exhaustive one
 MAX_INSTANCES = 1 << 27          # sort buffers are sized from the data: refuse sizes that only a diverged map produces (3.2 GB at the limit)
 
 
@@ -266,6 +267,11 @@ def distCUDA2(points):
     lib = _lib.load()
     P = pts.shape[0]
     out = torch.empty(P, dtype=torch.float32, device=pts.device)
+    if P >= KNN_GRID_MIN:          # large maps: exact search through a uniform grid instead of P^2 pairs
+        nb = int(lib.cut3r_knn3_grid_workspace_bytes(P))
+        ws = torch.empty(nb, dtype=torch.uint8, device=pts.device)
+        check(lib.cut3r_knn3_grid_mean_dist2(_p(pts), P, _p(out), _p(ws), nb, _s()), "knn3_grid_mean_dist2")
+        return out
     ws = torch.empty(max(1, lib.cut3r_knn3_chunks(P)) * P * 3, dtype=torch.float32, device=pts.device)
     check(lib.cut3r_knn3_mean_dist2(_p(pts), P, _p(out), _p(ws), _s()), "knn3_mean_dist2")
     return out

@@ -406,6 +406,11 @@ int cut3r_gs_refine_coef(const float* sums, float g_rgb, float g_var, int H, int
  * workspace: cut3r_knn3_chunks(P) * P * 3 floats (the candidates are searched in that many chunks, merged by a second kernel). */
 int cut3r_knn3_chunks(int P);
 int cut3r_knn3_mean_dist2(const float* points, int P, float* out, float* workspace, void* stream);
+/* the same quantity (exact: the three nearest squared distances of the exhaustive search) through a uniform grid, for large maps
+ * (P >= ~2e5: `gaussian_reinit` over every keyframe's pointmap, hislam2/gs_backend_per_frame.py:865-944): counting sort by cell, shells of
+ * growing Chebyshev radius until the third-best distance is covered.  workspace: cut3r_knn3_grid_workspace_bytes(P) bytes. */
+long long cut3r_knn3_grid_workspace_bytes(int P);
+int cut3r_knn3_grid_mean_dist2(const float* points, int P, float* out, void* workspace, long long workspace_bytes, void* stream);
 /* SSIM of the mapper's colour loss (hislam2/gaussian/utils/loss_utils.py:129-170: 11x11 Gaussian window, sigma 1.5, zero padding,
  * per channel).  forward: a, b [C,H,W] -> ssim_map [C,H,W] and the three partials the backward pass filters (d S / d mu1,
  * d S / d E[a^2], d S / d E[ab]).  backward: grad_a = grad_scale[0] * d(sum ssim_map)/d a  (grad_scale: ONE device float, e.g. the

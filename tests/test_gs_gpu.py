@@ -185,6 +185,47 @@ def test_knn_mean_distance_matches_kdtree_and_alias_imports():
         sys.path.remove(compat)
 
 
+def test_grid_knn_is_exact_against_the_exhaustive_search_and_a_kdtree():
+    """the uniform-grid 3-NN (cut3r_knn3_grid_mean_dist2: large maps, P >= 2e5 by default) returns the SAME three nearest squared
+    distances as the exhaustive kernel -- on a pointmap-like surface, on heavy clustering with exact duplicates, on a degenerate plane
+    (one empty grid axis), on a tiny cloud (G = 8) -- and agrees with scipy's cKDTree in fp64"""
+    import time
+    from scipy.spatial import cKDTree
+    from cut3r_slam_amd import gaussian_rasterizer as GR
+    g = torch.Generator().manual_seed(9)
+
+    def both(pts):
+        was = GR.KNN_GRID_MIN
+        try:
+            GR.KNN_GRID_MIN = 1 << 30
+            ex = GR.distCUDA2(pts)
+            GR.KNN_GRID_MIN = 4
+            torch.cuda.synchronize()
+            t0 = time.time()
+            gr = GR.distCUDA2(pts)
+            torch.cuda.synchronize()
+            return ex, gr, time.time() - t0
+        finally:
+            GR.KNN_GRID_MIN = was
+
+    # a stride-2 pointmap-like surface of 250 k points with noise
+    u, v = torch.meshgrid(torch.linspace(-2, 2, 500), torch.linspace(-1.5, 1.5, 500), indexing="ij")
+    surf = torch.stack([u, v, 3 + 0.3 * torch.sin(2 * u) * torch.cos(3 * v)], -1).reshape(-1, 3) + 1e-3 * torch.randn(250000, 3, generator=g)
+    clus = torch.cat([torch.randn(3000, 3, generator=g) * 0.01 + c for c in torch.randn(70, 3, generator=g)], 0)
+    clus[100:200] = clus[0:100]                                            # exact duplicates
+    plane = torch.cat([torch.rand(50000, 2, generator=g), torch.zeros(50000, 1)], 1)
+    tiny = torch.randn(9, 3, generator=g)
+    for name, pts in (("surface 250k", surf), ("clusters 210k + duplicates", clus), ("plane 50k", plane), ("tiny 9", tiny)):
+        ex, gr, dt = both(pts.to(DEV).contiguous())
+        err = float((ex - gr).abs().max() / ex.abs().max().clamp_min(1e-30))
+        print(f"[gs knn grid] {name}: max |grid - exhaustive| / max = {err:.2e}, grid search {1e3 * dt:.2f} ms")
+        assert err < 1e-6, (name, err)
+    d, _ = cKDTree(surf.double().numpy()).query(surf[:2000].double().numpy(), k=4)
+    ref = (d[:, 1:] ** 2).mean(axis=1)
+    np.testing.assert_allclose(both(surf.to(DEV).contiguous())[1][:2000].cpu().numpy(), ref, rtol=2e-4, atol=1e-9)
+    assert GR.KNN_GRID_MIN == 200_000
+
+
 @pytest.mark.parametrize("C,H,W", [(3, 96, 128), (3, 37, 50), (1, 16, 16)])
 def test_fused_ssim_matches_convolutions_forward_and_backward(C, H, W):
     """cut3r_ssim_forward/backward vs the conv2d formulation of loss_utils.py:140-170 (fp64): value and gradient w.r.t. the first image"""
