@@ -274,264 +274,10 @@ __global__ __launch_bounds__(NW * 64, (D <= 64 && NW == 4) ? 3 : 1) void attn_ke
     }
 }
 
-// ------------------------------------------------------------------------------------------------ two query blocks per wave
-// The same arithmetic (bit for bit: same MFMA operand order, same softmax expressions) with TWO 32-row query blocks per wave: the K
-// fragments of a tile are read from LDS once for both, and the instruction stream of a wave holds two independent chains -- the QK^T /
-// PV MFMAs of one block beside the softmax VALU work of the other -- instead of leaving that overlap to three resident waves.  One wave
-// now carries 64 query rows (64 accumulator registers of O^T, 64 of S^T): two waves per SIMD.
-template <int D, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(const AttnArgs a) {
-    constexpr int NTHR = NW * 64;
-    constexpr int KT = 64;
-    constexpr int DQ = D / 16;
-    constexpr int DP = (D + 31) / 32;
-    constexpr int KS_LD = D + 8;
-    constexpr int VS_BYTES = (64 * DP) % 128 == 0 ? 64 * DP + 64 : 64 * DP;
-    constexpr int V_LD = VS_BYTES / 2;
-    constexpr int CHUNKS = KT * (D / 8);
-    constexpr int NCH = (CHUNKS + NTHR - 1) / NTHR;
-    __shared__ __attribute__((aligned(16))) h16 Ks[KT * KS_LD];
-    __shared__ __attribute__((aligned(16))) h16 Vs[KT * V_LD];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * (64 * NW) + wave * 64;
-    const h16* qp = a.q + (size_t)b * a.q_sb + (size_t)h * D;
-    const h16* kp = a.k + (size_t)b * a.k_sb + (size_t)h * D;
-    const h16* vp = a.v + (size_t)b * a.v_sb + (size_t)h * D;
-
-    for (int i = tid; i < KT * V_LD; i += NTHR) Vs[i] = (h16)0;
-
-    half8_t qf[2][DQ];
-#pragma unroll
-    for (int qb = 0; qb < 2; qb++) {
-        int qr = q0 + 32 * qb + r;
-        if (qr > a.Nq - 1) qr = a.Nq - 1;
-        const h16* qrow = qp + (size_t)qr * a.q_sn;
-#pragma unroll
-        for (int s = 0; s < DQ; s++) qf[qb][s] = *reinterpret_cast<const half8_t*>(qrow + 16 * s + 8 * hh);
-    }
-
-    f32x16 ot[2][DP];
-#pragma unroll
-    for (int qb = 0; qb < 2; qb++)
-#pragma unroll
-        for (int d = 0; d < DP; d++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) ot[qb][d][i] = 0.f;
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-    const bool active = q0 < a.Nq;               // wave-uniform
-    const int extra = (a.Nk > KT && (a.Nk % KT) == 1) ? 1 : 0;
-    if (extra) {
-#pragma unroll
-        for (int qb = 0; qb < 2; qb++) {
-            float dot = 0.f;
-#pragma unroll
-            for (int s = 0; s < DQ; s++) {
-                const half8_t k0 = *reinterpret_cast<const half8_t*>(kp + 16 * s + 8 * hh);
-#pragma unroll
-                for (int j = 0; j < 8; j++) dot = fmaf((float)qf[qb][s][j], (float)k0[j], dot);
-            }
-            { float d0, d1; halves(dot, d0, d1); dot = d0 + d1; }
-            m_run[qb] = dot * a.scale_log2;
-            l_run[qb] = hh == 0 ? 1.f : 0.f;
-#pragma unroll
-            for (int d = 0; d < DP; d++)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    const int dd = d * 32 + 8 * g4 + 4 * hh;
-                    if (dd < D) {
-                        const half4_t v0 = *reinterpret_cast<const half4_t*>(vp + dd);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) ot[qb][d][4 * g4 + e] = (float)v0[e];
-                    }
-                }
-        }
-    }
-
-    half8_t rk[NCH], rv[NCH];
-    const h16* kptr[NCH];
-    const h16* vptr[NCH];
-    int kkey[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        const int id = tid + c * NTHR;
-        const int key = id / (D / 8), ch = id - key * (D / 8);
-        kkey[c] = key;
-        kptr[c] = kp + (size_t)(extra + key) * a.k_sn + ch * 8;
-        vptr[c] = vp + (size_t)(extra + key) * a.v_sn + ch * 8;
-    }
-    auto load_kv = [&](int t) {
-        const int kbase = extra + t * KT;
-        const bool full = kbase + KT <= a.Nk;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            half8_t zk = {0, 0, 0, 0, 0, 0, 0, 0}, zv = zk;
-            if (NCH * NTHR == CHUNKS || tid + c * NTHR < CHUNKS) {
-                if (full || kbase + kkey[c] < a.Nk) {
-                    zk = *reinterpret_cast<const half8_t*>(kptr[c]);
-                    zv = *reinterpret_cast<const half8_t*>(vptr[c]);
-                }
-            }
-            rk[c] = zk; rv[c] = zv;
-            kptr[c] += (size_t)KT * a.k_sn;
-            vptr[c] += (size_t)KT * a.v_sn;
-        }
-    };
-    auto store_kv = [&]() {
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            int id = tid + c * NTHR;
-            if (NCH * NTHR == CHUNKS || id < CHUNKS) {
-                int key = id / (D / 8), ch = id - key * (D / 8);
-                *reinterpret_cast<half8_t*>(&Ks[key * KS_LD + ch * 8]) = rk[c];
-                *reinterpret_cast<half8_t*>(&Vs[key * V_LD + ch * 8]) = rv[c];
-            }
-        }
-    };
-
-    const int g16 = lane >> 4, j16 = lane & 15;
-    const int ntiles = (a.Nk - extra + KT - 1) / KT;
-    load_kv(0);
-    for (int t = 0; t < ntiles; t++) {
-        __syncthreads();
-        store_kv();
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
-        __syncthreads();
-        if (t + 1 < ntiles) load_kv(t + 1);
-        if (!active) continue;
-
-        // ---- S^T = K Q^T: the K fragments of the tile once, for both query blocks
-        half8_t kf[2][DQ];
-#pragma unroll
-        for (int kt2 = 0; kt2 < 2; kt2++)
-#pragma unroll
-            for (int s = 0; s < DQ; s++) kf[kt2][s] = *reinterpret_cast<const half8_t*>(&Ks[(kt2 * 32 + r) * KS_LD + 16 * s + 8 * hh]);
-        f32x16 st[2][2];
-#pragma unroll
-        for (int qb = 0; qb < 2; qb++)
-#pragma unroll
-            for (int kt2 = 0; kt2 < 2; kt2++) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) st[qb][kt2][i] = 0.f;
-#pragma unroll
-                for (int s = 0; s < DQ; s++) st[qb][kt2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt2][s], qf[qb][s], st[qb][kt2], 0, 0, 0);
-            }
-        const int kbase = extra + t * KT;
-        const bool full_tile = kbase + KT <= a.Nk;
-        float alpha[2];
-        bool grew_any = false;
-#pragma unroll
-        for (int qb = 0; qb < 2; qb++) {
-            float mloc = -INFINITY;
-            if (full_tile) {
-#pragma unroll
-                for (int kt2 = 0; kt2 < 2; kt2++)
-#pragma unroll
-                    for (int i = 0; i < 16; i++) mloc = fmaxf(mloc, st[qb][kt2][i]);
-            } else {
-#pragma unroll
-                for (int kt2 = 0; kt2 < 2; kt2++)
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const int key = kbase + kt2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                        const float sv = key < a.Nk ? st[qb][kt2][i] : -INFINITY;
-                        st[qb][kt2][i] = sv;
-                        mloc = fmaxf(mloc, sv);
-                    }
-            }
-            { float m0_, m1_; halves(mloc, m0_, m1_); mloc = fmaxf(m0_, m1_) * a.scale_log2; }
-            const float m_new = fmaxf(m_run[qb], mloc);
-            grew_any = grew_any || (m_new > m_run[qb]);
-            alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
-            m_run[qb] = m_new;
-            float lsum = 0.f;
-#pragma unroll
-            for (int kt2 = 0; kt2 < 2; kt2++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(st[qb][kt2][i], a.scale_log2, -m_new));
-                    st[qb][kt2][i] = p;
-                    lsum += p;
-                }
-            l_run[qb] = l_run[qb] * alpha[qb] + lsum;
-        }
-        if (__any(grew_any)) {                    // wave-uniform: after the first tiles the running maxima rarely move
-#pragma unroll
-            for (int qb = 0; qb < 2; qb++)
-#pragma unroll
-                for (int d = 0; d < DP; d++)
-#pragma unroll
-                    for (int i = 0; i < 16; i++) ot[qb][d][i] *= alpha[qb];
-        }
-        // ---- O^T += V^T P^T: every V fragment once, for both query blocks
-#pragma unroll
-        for (int kt2 = 0; kt2 < 2; kt2++)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) {
-                half8_t pf[2];
-#pragma unroll
-                for (int qb = 0; qb < 2; qb++)
-#pragma unroll
-                    for (int j = 0; j < 8; j++) pf[qb][j] = (h16)st[qb][kt2][8 * s2 + j];
-#pragma unroll
-                for (int d = 0; d < DP; d++) {
-                    const int k0 = kt2 * 32 + 16 * s2 + 4 * (g16 >> 1);
-                    const int c0 = d * 32 + 16 * (g16 & 1);
-                    const h16* vq = &Vs[(k0 + (j16 >> 2)) * V_LD + c0 + 4 * (j16 & 3)];
-                    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vq));
-                    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vq + 8 * V_LD));
-                    half8_t vf;
-                    __builtin_memcpy(&vf, &lo, 8);
-                    __builtin_memcpy(reinterpret_cast<char*>(&vf) + 8, &hi, 8);
-                    ot[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[0], ot[0][d], 0, 0, 0);
-                    ot[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[1], ot[1][d], 0, 0, 0);
-                }
-            }
-    }
-
-#pragma unroll
-    for (int qb = 0; qb < 2; qb++) {
-        float l0_, l1_;
-        halves(l_run[qb], l0_, l1_);
-        const float inv = 1.0f / (l0_ + l1_);
-        const int qr = q0 + 32 * qb + r;
-        if (qr < a.Nq) {
-            h16* orow = a.o + (size_t)b * a.o_sb + (size_t)qr * a.o_sn + (size_t)h * D;
-#pragma unroll
-            for (int d = 0; d < DP; d++)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    int dd = d * 32 + 8 * g4 + 4 * hh;
-                    if (dd < D) {
-                        half4_t o = {(h16)(ot[qb][d][4 * g4 + 0] * inv), (h16)(ot[qb][d][4 * g4 + 1] * inv), (h16)(ot[qb][d][4 * g4 + 2] * inv),
-                                     (h16)(ot[qb][d][4 * g4 + 3] * inv)};
-                        *reinterpret_cast<half4_t*>(orow + dd) = o;
-                    }
-                }
-        }
-    }
-}
-
 template <int D>
 int launch_attn(const AttnArgs& a, int B, int H, hipStream_t s) {
     const long long blocks128 = (long long)B * H * ((a.Nq + 127) / 128);
     static const long long nw4_min = [] { const char* e = getenv("CUT3R_ATTN_NW4_MIN"); return e ? atoll(e) : 384LL; }();
-    // two query blocks per wave (attn2_kernel): CUT3R_ATTN2 = 0 (off), 2 / 4 (waves per workgroup)
-    static const int attn2 = [] { const char* e = getenv("CUT3R_ATTN2"); return e ? atoi(e) : 0; }();
-    if constexpr (D <= 64) {
-        if (attn2 == 4 && blocks128 >= nw4_min) {
-            dim3 grid((a.Nq + 255) / 256, H, B);
-            hipLaunchKernelGGL((attn2_kernel<D, 4>), grid, dim3(256), 0, s, a);
-            return cut3r_check_launch();
-        }
-        if (attn2 == 2 && blocks128 >= nw4_min) {
-            dim3 grid((a.Nq + 127) / 128, H, B);
-            hipLaunchKernelGGL((attn2_kernel<D, 2>), grid, dim3(128), 0, s, a);
-            return cut3r_check_launch();
-        }
-    }
     if (blocks128 >= nw4_min || D >= 128) {
         dim3 grid((a.Nq + 127) / 128, H, B);
         hipLaunchKernelGGL((attn_kernel<D, 4>), grid, dim3(256), 0, s, a);

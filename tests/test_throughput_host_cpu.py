@@ -109,3 +109,29 @@ def test_non_finite_window_scale_warns():
         _check_scale(5, np.float32(1.25))                      # finite: silent
     with pytest.warns(RuntimeWarning, match="keyframe 10"):
         _check_scale(10, np.float32("nan"))
+
+
+def test_chained_scale_bookkeeping_tells_geometric_growth_from_a_bad_depth():
+    """track_frontend._check_scale: the chained window scale s_k = exp(mean(log stored depth - log predicted depth)) is
+    recorded per steady-state window; a non-finite scale is counted, its first keyframe kept, and the warning says whether the scale GREW out
+    of the fp32 range (|log s| > 40 before: what an uncut stream through a random-weight network does) or came from one bad depth"""
+    import math
+    import warnings
+    from cut3r_slam_amd.track_frontend import _check_scale, new_scale_stats
+    st = new_scale_stats()
+    for k in range(1, 6):
+        _check_scale(5 * k, math.exp(0.2 * k), st)
+    assert st["windows"] == 5 and st["nonfinite_windows"] == 0 and abs(st["log_scale_last"] - 1.0) < 1e-9 and abs(st["log_scale_absmax"] - 1.0) < 1e-9
+    _check_scale(30, math.exp(-60.0), st)
+    assert abs(st["log_scale_absmax"] - 60.0) < 1e-6 and st["log_scale_last"] < 0
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _check_scale(35, float("inf"), st)
+        _check_scale(40, float("nan"), st)
+    assert st["nonfinite_windows"] == 2 and st["first_nonfinite_keyframe"] == 35 and st["windows"] == 8
+    assert "grew geometrically" in str(w[0].message) and "60.0" in str(w[0].message)
+    st2 = new_scale_stats()
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        _check_scale(10, float("nan"), st2)
+    assert "non-positive or non-finite predicted depth" in str(w2[0].message) and st2["first_nonfinite_keyframe"] == 10
