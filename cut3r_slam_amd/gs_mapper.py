@@ -224,8 +224,10 @@ class Camera:
     def __init__(self, uid, image, depth, w2c, fx, fy, cx, cy, tstamp=None, device="cuda:0"):
         dev = torch.device(device)
         self.uid, self.tstamp, self.device = uid, tstamp, dev
-        self.original_image = image.to(dev, torch.float32)
-        self.depth = depth.to(dev, torch.float32)
+        # dense row-major copies: the loss kernels of the tape-free trainer read these through raw pointers (a permuted HWC view handed in by
+        # a caller would otherwise be read with the wrong strides)
+        self.original_image = image.to(dev, torch.float32).contiguous()
+        self.depth = depth.to(dev, torch.float32).contiguous()
         self.image_height, self.image_width = image.shape[-2:]
         self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
         self.FoVx, self.FoVy = 2 * math.atan(self.image_width / (2 * self.fx)), 2 * math.atan(self.image_height / (2 * self.fy))

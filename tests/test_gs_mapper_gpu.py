@@ -480,3 +480,67 @@ def test_an_overflowed_capacity_is_never_kept():
     assert abs(lc - la) < 0.02 * la
     torch.testing.assert_close(c.trajectory().detach(), a.trajectory().detach(), atol=2e-4, rtol=0)
     assert int(c.gaussians.step_count) == int(a.gaussians.step_count) == c.gaussians.steps
+
+
+def test_one_mapping_iteration_matches_the_fp64_restatement_of_the_loss():
+    """the WHOLE mapping iteration -- pose composition exp([tau, phi]) T, activations, rasteriser, colour L1 + SSIM, inverse-depth L1,
+    depth-normal agreement, isotropy -- against oracle/gs_loss_oracle.py (fp64 torch autograd over the fp64 rasteriser restatement): the
+    loss value and the gradient of every Gaussian parameter, for the tape-free trainer AND the tensor-op formulation; the first Adam step
+    of the pose increments moves against the oracle's pose gradient.  Parity unpinned vs the reference (its CUDA rasteriser cannot run
+    here): this pins the mapper's iteration to an independent reading of gs_backend_per_frame.py:451-587."""
+    from oracle import gs_loss_oracle as LO
+    Hs, Ws, f = 32, 48, 40.0
+    K = (f, f, Ws / 2, Hs / 2)
+    g = torch.Generator().manual_seed(21)
+    P = 160
+    xyz = torch.cat([(torch.rand(P, 2, generator=g) - 0.5) * torch.tensor([3.2, 2.2]), 2.5 + 1.5 * torch.rand(P, 1, generator=g)], 1)
+    theta0 = torch.cat([xyz, torch.randn(P, 3, generator=g) * 0.8, torch.randn(P, 1, generator=g) * 0.8 + 0.5,
+                        torch.log(0.05 + 0.12 * torch.rand(P, 3, generator=g)), torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=-1)], 1)
+    w2c = SE3.exp(torch.tensor([[0.05, -0.03, 0.04, 0.02, -0.03, 0.01]], device=DEV)).matrix()[0].cpu()
+    # observations: a rendering of a perturbed copy of the map (so every loss term is active), depth with holes
+    with torch.no_grad():
+        pert = theta0.double().clone()
+        pert[:, 0:3] += 0.05 * torch.randn(P, 3, generator=g).double()
+        pert[:, 3:6] += 0.3 * torch.randn(P, 3, generator=g).double()
+        obs = LO.render(pert, w2c.double(), torch.zeros(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64), Hs, Ws, K)
+        gt_image = obs["color"].clamp(0, 1).float()
+        gt_depth = (obs["depth"][0] * (1 + 0.02 * torch.randn(Hs, Ws, generator=g).double())).float()
+        gt_depth[5:9, 10:20] = 0.0
+    cfg = dict(CONFIG, Training=dict(CONFIG["Training"], lambda_depth=2.0, lambda_normal=0.3, lambda_iso=4.0))
+    res = {}
+    for fused in (True, False):
+        m = GM.GSMapper(cfg, f, f, Ws / 2, Hs / 2, downsample_ratio=2, device=DEV)
+        m.fused = fused
+        gm = m.gaussians
+        gm._append({"xyz": theta0[:, 0:3], "f_dc": theta0[:, 3:6], "opacity": theta0[:, 6:7], "scaling": theta0[:, 7:10], "rotation": theta0[:, 10:14]},
+                   torch.zeros(P))
+        m.viewpoints[0] = GM.Camera(0, gt_image, gt_depth, w2c.to(DEV), f, f, Ws / 2, Hs / 2, device=DEV)
+        loss = m.optimization(1, optimize_pose=True, current_window=[0])
+        v = m.viewpoints[0]
+        res[fused] = (loss, (gm.m / 0.1).cpu().double(), torch.inverse(GM.get_pose(v).detach()).cpu())
+    # ---- the restatement
+    th = theta0.double().clone().requires_grad_(True)
+    tau, phi = torch.zeros(3, dtype=torch.float64, requires_grad=True), torch.zeros(3, dtype=torch.float64, requires_grad=True)
+    ref = LO.mapping_loss(th, w2c.double(), tau, phi, gt_image.double(), gt_depth.double(), K, 2.0, 0.3, 4.0)
+    ref.backward()
+    for fused, (loss, grad, _) in res.items():
+        tag = "tape-free" if fused else "autograd"
+        assert abs(loss - float(ref)) <= 2e-4 * abs(float(ref)), (tag, loss, float(ref))
+        for name, (c0, c1) in {"xyz": (0, 3), "colour": (3, 6), "opacity": (6, 7), "log scale": (7, 10), "quaternion": (10, 14)}.items():
+            gr = th.grad[:, c0:c1]
+            sc = float(gr.abs().max())
+            err = (grad[:, c0:c1] - gr).abs()
+            bad = float((err > 2e-3 * sc + 1e-9).double().mean())
+            print(f"[gs iteration vs fp64, {tag}] d loss / d {name}: scale {sc:.3e}, median |err| {float(err.median()):.2e}, max {float(err.max()):.2e}, "
+                  f"beyond 2e-3 of the scale {100 * bad:.2f} %")
+            assert float(err.median()) <= 2e-5 * sc + 1e-12 and bad <= 0.02, (tag, name, sc, float(err.max()), bad)
+    # ---- poses: one Adam step = -lr * sign(gradient) per component: compare with the oracle's pose gradient
+    lr = cfg["opt_params"]["pose_lr"]
+    Tn = torch.inverse(res[True][2].double())                                    # new world->camera = exp(delta) T
+    D = Tn @ torch.inverse(w2c.double())
+    d_tau, d_phi = D[:3, 3], torch.stack([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]]) / 2
+    for got, gref, step in ((d_tau, tau.grad, 10 * lr), (d_phi, phi.grad, 2 * lr)):
+        big = gref.abs() > 1e-3 * gref.abs().max()
+        assert bool((torch.sign(got[big]) == -torch.sign(gref[big])).all()), (got, gref)
+        assert float((got[big].abs() - step).abs().max()) < 0.05 * step, (got, step)
+    torch.testing.assert_close(res[True][2], res[False][2], atol=1e-6, rtol=0)
