@@ -859,6 +859,34 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
             pb0 = *reinterpret_cast<const f32x4*>(bias + pc);
             pb1 = *reinterpret_cast<const f32x4*>(bias + pc + 4);
         }
+        // EPI 6: the wave keeps the first ROPE_LDS rows of the cos|sin table (row = 16 cos | 16 sin) and the clamped table rows of its
+        // 128 output rows behind its staging band, in its own 16 KiB: the rotation of a row then costs LDS reads instead of a dependent
+        // chain position -> table in global memory per row (measured: that chain made this epilogue 2.4x the plain fp16 one).  Rows of
+        // the table beyond ROPE_LDS (images wider than 46 patches) keep the global path, decided per wave and row group.
+        constexpr int ROPE_LDS = 48;
+        float* tl = cs + 32 * CP;
+        int* psl = reinterpret_cast<int*>(tl + ROPE_LDS * 32);
+        if (EPI == 6 && __builtin_amdgcn_readfirstlane((n0 + wc * 64) < g.rope_cols)) {
+#pragma unroll
+            for (int f0 = 0; f0 < ROPE_LDS * 8; f0 += 64) {
+                const int f = f0 + lane, p = f >> 3, part = f & 7;
+                f32x4 v = zero4;
+                if (p < g.rope_npos) v = *reinterpret_cast<const f32x4*>(g.rope_table + (size_t)(part >> 2) * g.rope_npos * 16 + p * 16 + (part & 3) * 4);
+                *reinterpret_cast<f32x4*>(tl + p * 32 + part * 4) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int r = lane + 64 * i;
+                const int gmr = min(m0 + wr * 128 + r, M - 1);
+                const longlong2 pp = *reinterpret_cast<const longlong2*>(g.rope_pos + (size_t)gmr * 2);
+                long long py = pp.x - g.rope_pmin, px = pp.y - g.rope_pmin;
+                py = py < 0 ? 0 : (py >= g.rope_npos ? g.rope_npos - 1 : py);
+                px = px < 0 ? 0 : (px >= g.rope_npos ? g.rope_npos - 1 : px);
+                psl[r * 2] = (int)py;
+                psl[r * 2 + 1] = (int)px;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         h16* crow = (h16*)g.C + (size_t)z * g.sC + (size_t)(m0 + wr * 128 + er) * g.ldc + gnc;
         const size_t step8 = (size_t)8 * g.ldc;
 #pragma unroll
@@ -907,13 +935,18 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
                     const int po = (ec & 16) ? -16 : 16;
                     f32x4 p0 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + po) + pb0;
                     f32x4 p1 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + po + 4) + pb1;
-                    const int gmr = min(m0 + wr * 128 + mp * 32 + rr, M - 1);
-                    long long pv = g.rope_pos[(size_t)gmr * 2 + (ec >> 5)] - g.rope_pmin;
-                    pv = pv < 0 ? 0 : (pv >= g.rope_npos ? g.rope_npos - 1 : pv);
-                    const float* ct = g.rope_table + (size_t)pv * 16 + (ec & 15);
-                    const float* st = ct + (size_t)g.rope_npos * 16;
-                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(ct), c1 = *reinterpret_cast<const f32x4*>(ct + 4);
-                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(st), s1 = *reinterpret_cast<const f32x4*>(st + 4);
+                    const int pv = psl[(mp * 32 + rr) * 2 + (ec >> 5)];
+                    f32x4 c0, c1, s0, s1;
+                    if (__builtin_amdgcn_ballot_w64(pv >= ROPE_LDS) == 0) {
+                        const float* ct = tl + pv * 32 + (ec & 15);
+                        c0 = *reinterpret_cast<const f32x4*>(ct); c1 = *reinterpret_cast<const f32x4*>(ct + 4);
+                        s0 = *reinterpret_cast<const f32x4*>(ct + 16); s1 = *reinterpret_cast<const f32x4*>(ct + 20);
+                    } else {
+                        const float* ct = g.rope_table + (size_t)pv * 16 + (ec & 15);
+                        const float* st = ct + (size_t)g.rope_npos * 16;
+                        c0 = *reinterpret_cast<const f32x4*>(ct); c1 = *reinterpret_cast<const f32x4*>(ct + 4);
+                        s0 = *reinterpret_cast<const f32x4*>(st); s1 = *reinterpret_cast<const f32x4*>(st + 4);
+                    }
                     const bool lower = !(ec & 16);
 #pragma unroll
                     for (int e = 0; e < 4; e++) {

@@ -114,6 +114,26 @@ def test_gemm_fused_rope_equals_gemm_then_rope_kernel(M, N, cols, hd, tile):
     assert not torch.equal(out[:, :cols], (A.float() @ W.float().t() + b).half()[:, :cols])      # RoPE did something
 
 
+@pytest.mark.parametrize("hi", [47, 48, 100, 256])
+def test_gemm256_fused_rope_beyond_the_table_rows_it_keeps_in_lds(hi):
+    """the 256^2 kernel keeps table rows 0..47 (positions -1..46) per wave in LDS and reads the others from global memory: positions on
+    both sides of that line, mixed inside one row group, and beyond the table (clamped like the stand-alone kernel) give the same bits"""
+    M, N, K, cols = 1100, 1536, 192, 1024
+    g = torch.Generator().manual_seed(hi)
+    A = torch.randn(M, K, generator=g).half().to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    pos = torch.randint(-1, hi + 1, (M, 2), generator=g, dtype=torch.int64).to(DEV)
+    pos[512:768] = torch.randint(-1, 40, (256, 2), generator=g, dtype=torch.int64).to(DEV)       # a whole tile of rows inside the LDS rows
+    ref = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.linear(A, W, ref, b, 0, tile=128)
+    ops.rope_2d(ref.view(1, M, N // 64, 64)[:, :, :cols // 64], pos.view(1, M, 2), 100.0, 1.0)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+    ops.linear(A, W, out, b, 0, tile=256, rope=(pos, cols, 100.0, 64))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref), f"{(out != ref).sum().item()} elements differ, max {(out.float() - ref.float()).abs().max().item()}"
+
+
 def test_skinny_gemm_rows_do_not_depend_on_the_batch():
     """a row of the M <= 64 kernel must come out bit-identical whatever M is (window-batch invariance of the pose path)"""
     g = torch.Generator().manual_seed(4)
