@@ -95,6 +95,18 @@ class FusedTrainer:
         self.point_list = torch.empty(self._cap, dtype=torch.int32, device=dev)
         self.sort_ws = torch.empty(GR.workspace_bytes(self._shape[0], self._cap), dtype=torch.uint8, device=dev)
 
+    @staticmethod
+    def _image_size(views):
+        """(H, W) shared by the views; the image buffers and the kernels' raw pointers assume ONE size and dense fp32 observations"""
+        H, W = int(views[0].image_height), int(views[0].image_width)
+        for v in views:
+            if (int(v.image_height), int(v.image_width)) != (H, W):
+                raise ValueError(f"tape-free GS trainer: views of different sizes ({v.image_height}x{v.image_width} vs {H}x{W})")
+            if (tuple(v.original_image.shape) != (3, H, W) or tuple(v.depth.shape) != (H, W) or not v.original_image.is_contiguous()
+                    or not v.depth.is_contiguous() or v.original_image.dtype != torch.float32 or v.depth.dtype != torch.float32):
+                raise ValueError("tape-free GS trainer: a view's image / depth must be dense fp32 [3,H,W] / [H,W]")
+        return H, W
+
     # ------------------------------------------------------------------ per-view pieces
     @staticmethod
     def _cam(v):
@@ -188,7 +200,7 @@ class FusedTrainer:
         """GSMapper.optimization without densification / exposure compensation; returns the loss of the last iteration (float)"""
         mp, gm, lib = self.mp, self.mp.gaussians, self.lib
         P = len(gm)
-        H, W = int(views[0].image_height), int(views[0].image_width)
+        H, W = self._image_size(views)
         self._buffers(P, H, W)
         N = len(views)
         g = 1.0 / N
@@ -264,7 +276,7 @@ class FusedTrainer:
         until the end, as the reference's update_pose after the loop)"""
         mp, gm, lib = self.mp, self.mp.gaussians, self.lib
         P = len(gm)
-        H, W = int(views[0].image_height), int(views[0].image_width)
+        H, W = self._image_size(views)
         self._buffers(P, H, W)
         B = len(views)
         ps = self._load_poses(views)
@@ -311,7 +323,7 @@ class FusedTrainer:
         mp, lib = self.mp, self.lib
         gm = mp.gaussians
         views = list(mp.viewpoints.values())
-        H, W = int(views[0].image_height), int(views[0].image_width)
+        H, W = self._image_size(views)
         ps = self._load_poses(views)
         sums = torch.zeros(len(views), 16, dtype=torch.float32, device=self.dev)
         rng = random.Random(seed)
@@ -386,7 +398,7 @@ class FusedTrainer:
         from .gs_mapper import depth_to_normal
         mp, lib = self.mp, self.lib
         views = list(mp.viewpoints.values())
-        H, W = int(views[0].image_height), int(views[0].image_width)
+        H, W = self._image_size(views)
         ps = self._load_poses(views)
         rng = random.Random(seed)
         update_every = mp.config["Training"].get("gaussian_update_every", 200)
