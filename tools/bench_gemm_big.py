@@ -11,7 +11,8 @@ from tools.bench_gemm import timeit
 
 DEV = "cuda:0"
 g = torch.Generator().manual_seed(0)
-print("library:", _lib.LIB_PATH)
+ZEROS = "--zeros" in sys.argv          # all-zero operands: the same instruction stream at the clock the chip holds without data toggling
+print("library:", _lib.LIB_PATH, "| operands:", "zeros" if ZEROS else "random")
 CASES = [  # M, N, K, act, residual(fp32, in place), out dtype, label
     (107520, 4096, 1024, 1, False, torch.float16, "enc fc1 gelu"), (107520, 1024, 4096, 0, True, torch.float32, "enc fc2+res"),
     (107520, 3072, 1024, 0, False, torch.float16, "enc qkv"), (107520, 1024, 1024, 0, True, torch.float32, "enc proj+res"),
@@ -22,6 +23,8 @@ for M, N, K, act, use_res, odt, label in CASES:
     A = torch.randn(M, K, generator=g).half().to(DEV)
     W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(DEV)
     b = torch.randn(N, generator=g).to(DEV)
+    if ZEROS:
+        A.zero_(); W.zero_(); b.zero_()
     out = torch.zeros(M, N, dtype=odt, device=DEV)
     us = min(timeit(lambda: ops.linear(A, W, out, b, act, out if use_res else None, tile=256), reps=20) for _ in range(3))
     print(f"{label:16s} {M:6d}x{N:5d}x{K:5d}  {us:8.1f} us  {2.0*M*N*K/us/1e6:6.0f} TF/s", flush=True)
