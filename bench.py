@@ -203,6 +203,48 @@ def probe_entries(res):
     return out
 
 
+def mfma_probe(dev, seconds=1.2):
+    """what the matrix pipe of THIS device sustains on operands that toggle: cut3r_mfma_probe (bare v_mfma_f32_16x16x32_f16 loop, two waves
+    per SIMD on every CU) launched back to back for `seconds`, HIP events around the last launches, in-kernel clock from the s_memtime /
+    s_memrealtime stamps of the last one.  Reported BESIDE the nominal 2.5 PFLOP/s peak, never instead of it."""
+    import ctypes
+    from cut3r_slam_amd import _lib
+    lib = _lib.load()
+    grid, iters = 256, 6000
+    out = {}
+    for label, data in (("random_operands", torch.randn(1 << 20, device=dev).half()), ("zero_operands", torch.zeros(1 << 20, device=dev, dtype=torch.float16))):
+        sink = torch.empty(grid * 512, device=dev)
+        stamps = torch.zeros(grid, 2, dtype=torch.int64, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def launch():
+            rc = lib.cut3r_mfma_probe(ctypes.c_void_p(data.data_ptr()), data.numel(), iters, grid, ctypes.c_void_p(sink.data_ptr()),
+                                      ctypes.c_void_p(stamps.data_ptr()), st)
+            if rc != 0:
+                raise RuntimeError(f"cut3r_mfma_probe: error {rc}")
+        launch()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < seconds:
+            for _ in range(20):
+                launch()
+            torch.cuda.synchronize()
+            n += 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        s_ = stamps.cpu().double()
+        clk = float((s_[:, 0] / s_[:, 1].clamp_min(1)).median()) * 0.1                 # GHz: shader cycles per 100-MHz tick
+        tf = grid * 8 * iters * 16 * 16384 / (us * 1e-6) / 1e12
+        out[label] = {"in_kernel_clock_ghz": round(clk, 3), "tflops": round(tf, 1), "us_per_launch": round(us, 1), "launches_before": n}
+    return out
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -641,6 +683,14 @@ def main():
                             "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": fl / n,
                             "algorithmic_bytes_per_launch": by / n, "share_of_large_gemm_time": round(ms / tot_ms, 3),
                             "second_kernel": others[0] if others else None, "other_kernels": others, "gemm_shapes": shape_entries(res)}
+                try:
+                    mp = mfma_probe(dev)
+                    sus = mp["random_operands"]["tflops"]
+                    roofline["sustained_mfma"] = dict(mp, note="bare MFMA loop of this device (no LDS, no memory traffic), N(0,1) vs all-zero fp16 operands: "
+                                                                "the 2.5 PFLOP/s `peak` assumes 2.4 GHz, which the chip does not hold while its operands toggle",
+                                                      frac_of_sustained=round(ach / sus, 4) if sus > 0 else None)
+                except Exception as ex:      # a measurement aid: never fails the bench line
+                    roofline["sustained_mfma"] = {"error": str(ex)}
     if single and not args.small and not args.no_operating_points:
         log("operating points: fixed cadence with one window at a time")
         del leg, runner, slam

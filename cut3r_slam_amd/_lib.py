@@ -77,6 +77,7 @@ SIGNATURES = {
                             c_void_p, c_int, c_void_p, c_void_p],
     "cut3r_logdepth_accum": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "cut3r_resize_linear_u8": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
+    "cut3r_mfma_probe": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "cut3r_remap_linear_u8": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "cut3r_align_view": [c_void_p, c_void_p, c_int, c_int, C.POINTER(c_float), c_float, c_int, c_void_p, c_void_p,
                          c_void_p, c_void_p],

@@ -449,6 +449,12 @@ int cut3r_refine_loss_forward(const float* img, const float* gt_img, const float
 int cut3r_refine_loss_backward(const float* img, const float* gt_img, const float* depth, const float* gt_depth, const float* alpha,
                                float alpha_th, int H, int W, const float* coef, float* grad_img, float* grad_depth, void* stream);
 
+/* Measurement aid of bench.py's roofline (no reference counterpart; not on the product path): a bare MFMA loop (v_mfma_f32_16x16x32_f16,
+ * 16 independent accumulator chains per wave, 8 waves per workgroup, `grid` workgroups, `iters` x 16 MFMAs per wave, operands = 16-byte
+ * chunks of data[nhalf] fp16, nhalf a power of two >= 32768) with s_memtime / s_memrealtime stamps around the loop.  stamps [grid,2] u64 =
+ * (shader cycles, 100-MHz ticks) per workgroup; sink [grid*512] receives the accumulator sums.  FLOP = grid * 8 * iters * 16 * 16384. */
+int cut3r_mfma_probe(const void* data, int nhalf, int iters, int grid, float* sink, unsigned long long* stamps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -624,3 +624,34 @@ def test_window_update_matches_per_keyframe_calls():
         i = t0 + v
         assert torch.equal(c[v, 0, :i], ref_f[v]) and torch.equal(c[v, 1, :i], ref_b[v]), f"view {v}"
         assert int(c[v, 0, :i].sum()) > 0 and int(c[v, 1, :i].sum()) > 0          # the case is not vacuous
+
+
+def test_mfma_probe_reports_a_plausible_clock_and_rate():
+    """bench.py's measurement aid: the stamps give a shader clock between 0.8 and 2.6 GHz, the rate stays below the nominal 2.5 PFLOP/s, and
+    the accumulators of a launch on random operands are finite (the loop really multiplied)"""
+    import ctypes
+    from cut3r_slam_amd import _lib
+    lib = _lib.load()
+    grid, iters = 256, 2000
+    data = torch.randn(1 << 16, device=DEV).half()
+    sink = torch.empty(grid * 512, device=DEV)
+    stamps = torch.zeros(grid, 2, dtype=torch.int64, device=DEV)
+    args = (ctypes.c_void_p(data.data_ptr()), data.numel(), iters, grid, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(stamps.data_ptr()),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert lib.cut3r_mfma_probe(*args) == 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        assert lib.cut3r_mfma_probe(*args) == 0
+    e1.record()
+    torch.cuda.synchronize()
+    s = stamps.cpu().double()
+    assert bool((s > 0).all())
+    clk = float((s[:, 0] / s[:, 1]).median()) * 0.1
+    tf = grid * 8 * iters * 16 * 16384 / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e12
+    print(f"[mfma probe] in-kernel clock {clk:.2f} GHz, {tf:.0f} TFLOP/s on N(0,1) operands")
+    assert 0.8 < clk < 2.6 and 300 < tf < 2500, (clk, tf)
+    assert bool(torch.isfinite(sink).all()) and float(sink.abs().max()) > 0
+    # argument checks
+    assert lib.cut3r_mfma_probe(args[0], 1000, iters, grid, args[4], args[5], args[6]) != 0

@@ -11,6 +11,7 @@ import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None)
 ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--zeros", action="store_true", help="all-zero q, k, v: the same instruction stream without data toggling (clock check)")
 args = ap.parse_args()
 from cut3r_slam_amd import _lib
 if args.lib:
@@ -30,6 +31,8 @@ for B, H, Nq, Nk, D, label in CASES:
     q = torch.randn(B, Nq, H, D, generator=g).half().to(DEV)
     k = torch.randn(B, Nk, H, D, generator=g).half().to(DEV)
     v = torch.randn(B, Nk, H, D, generator=g).half().to(DEV)
+    if args.zeros:
+        q.zero_(); k.zero_(); v.zero_()
     o = torch.empty(B, Nq, H, D, dtype=torch.float16, device=DEV)
     fn = lambda: ops.attention(q, k, v, o, D ** -0.5)
     reps = 20
