@@ -245,6 +245,18 @@ def mfma_probe(dev, seconds=1.2):
     return out
 
 
+def guarded(label, fn, *a, **k):
+    """a secondary leg (operating point, parity table, CPU baseline) must not take the headline line with it: its failure is logged
+    with the traceback and reported in its place"""
+    try:
+        return fn(*a, **k)
+    except Exception as ex:
+        import traceback
+        log(f"{label} FAILED: {type(ex).__name__}: {ex}")
+        traceback.print_exc(file=sys.stderr)
+        return {"error": f"{type(ex).__name__}: {ex}"}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -732,17 +744,17 @@ def main():
                 "health": le["health"]}
             del le
         log("operating points: overlap mode (kf_every=-1, skip=5, thresh=0.9)")
-        op_points["overlap_mode"] = overlap_mode_leg(model, Cut3rSlam, dev)
+        op_points["overlap_mode"] = guarded("overlap mode leg", overlap_mode_leg, model, Cut3rSlam, dev)
         log("operating points: loop closure on (BASELINE configs[2])")
-        op_points["loop_closure_on"] = loop_closure_leg(cfg, Cut3rSlam, dev)
+        op_points["loop_closure_on"] = guarded("loop closure leg", loop_closure_leg, cfg, Cut3rSlam, dev)
         log("operating points: GS mapper on a synthetic window (rasteriser forward + backward, pose refinement, mapping)")
-        op_points["gs_mapper_synthetic_window"] = synth.gs_mapper_window_leg(H, W, dev)
+        op_points["gs_mapper_synthetic_window"] = guarded("GS mapper leg", synth.gs_mapper_window_leg, H, W, dev)
     if single and not args.no_trajectory_parity:
         log("trajectory parity leg (medium config, GPU vs CPU oracle)")
-        traj = trajectory_parity_leg(dev, None if (args.small or args.no_production_parity) else model, sd)
+        traj = guarded("trajectory parity leg", trajectory_parity_leg, dev, None if (args.small or args.no_production_parity) else model, sd)
     if single and not args.no_cpu_baseline and not args.small:
         log("cpu baseline (oracle on host cores)")
-        cpu_base = cpu_baseline(cfg, sd, torch.cat([to_tracking(frames[i:i + 1]) for i in range(2)], 0).cpu())
+        cpu_base = guarded("cpu baseline", cpu_baseline, cfg, sd, torch.cat([to_tracking(frames[i:i + 1]) for i in range(2)], 0).cpu())
         log("cpu baseline done")
 
     if rank == 0:
