@@ -123,6 +123,23 @@ def slideshow_stream(n: int, H: int, W: int, hold: int = 10, seed: int = 0, devi
     return out
 
 
+def blend_stream(n: int, H: int, W: int, period: int = 12, seed: int = 0, device="cpu") -> torch.Tensor:
+    """u8 [n,3,H,W]: cross-fades between unrelated white-noise textures, one fade per `period` frames: the patch-overlap ratio against
+    the last keyframe falls gradually from 1 to 0 along a fade, so an overlap-mode motion filter passes through INTERMEDIATE ratios
+    (the slideshow stream only produces 0 and 1)."""
+    g = torch.Generator().manual_seed(seed)
+    out = torch.empty(n, 3, H, W, dtype=torch.uint8, device=device)
+    a = torch.randint(8, 240, (3, H, W), generator=g).float()
+    b = torch.randint(8, 240, (3, H, W), generator=g).float()
+    for t in range(n):
+        k = t % period
+        if t > 0 and k == 0:
+            a, b = b, torch.randint(8, 240, (3, H, W), generator=g).float()
+        w = k / period
+        out[t] = ((1 - w) * a + w * b).round().to(torch.uint8).to(device)
+    return out
+
+
 def gs_wall_window(H: int = 384, W: int = 512, focal: float = 440.0, n_views: int = 6, device="cuda:0"):
     """A synthetic keyframe window for the GS mapper: a textured, gently curved wall modelled by one ground-truth Gaussian per pixel,
     rendered through the HIP rasteriser from `n_views` poses.  Returns (packet for GSMapper.run, images u8 [n,3,H,W], config dict)."""

@@ -283,8 +283,202 @@ def gen_camera_fixture():
     print("wrote camera", {k: v.shape for k, v in fx.items()})
 
 
+def gen_frontend_fixture():
+    """TrackFrontend.track (hislam2/track_frontend.py:166-262) ITSELF on the CPU: the initialisation window and two steady-state windows
+    of the reference's tracker -- its own prepare_input / inference / prepare_output, log-depth scale chaining, pose composition, stride-2
+    stores and FactorGraph calls -- over 16 keyframes of a seeded pan, with the reference model (medium config, seeded weights).
+    Harness-side adapters (the reference file is untouched): the tracker object is created without its __init__ (which builds a
+    FactorGraph on "cuda:0") and given the attributes track() reads; the keyframe store is a namespace with the tensors of
+    keyframe.py:19-36 (its constructor allocates three of them on "cuda"); the one `.to('cuda')` of prepare_input (:48) is redirected
+    to the CPU for the duration of the calls."""
+    AR, ARCfg, inference = import_reference_model()          # (before the stub modules: transformers probes torchvision on import)
+    import_reference_graph()
+    from track_frontend import TrackFrontend
+    from factor_graph import FactorGraph
+    from cut3r_slam_amd import synth
+    cfg = synth.medium_config()
+    seed = 11
+    sd = synth.tracking_state_dict(cfg, seed)
+    torch.manual_seed(0)
+    model = AR(ref_config(ARCfg, cfg)).eval()
+    print("frontend: load_state_dict:", torch.nn.Module.load_state_dict(model, sd, strict=True))
+    H, W = cfg.img_size
+    n, buffer, ds = 16, 20, 2
+    frames = synth.pan_stream(n, H, W, pool=5, num=6, den=1, seed=4)          # 6 px per keyframe: consecutive keyframes overlap
+    intr = torch.tensor([80.0, 80.0, 47.5, 31.5])
+    kf = types.SimpleNamespace(
+        image=torch.zeros(buffer, 3, H, W, dtype=torch.uint8), intrinsic=torch.zeros(buffer, 4), pose=torch.zeros(buffer, 7),
+        submap_ds=torch.ones(buffer // 5, 6, H // ds, W // ds, 3), conf_ds=torch.zeros(buffer // 5, 6, H // ds, W // ds),
+        depth=torch.ones(buffer, H, W), tstamp=torch.zeros(buffer), mono_depth_alpha=None)
+    kf.pose[:] = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0])
+    kf.image[:n] = frames
+    kf.intrinsic[:n] = intr
+    graph = FactorGraph(kf, device="cpu", max_factors=48)
+    tr = object.__new__(TrackFrontend)
+    tr.device, tr.keyframes, tr.model, tr.graph = "cpu", kf, model, graph
+    tr.verbose, tr.output_dir, tr.use_gt, tr.conf_th, tr.downsample_ratio, tr.t1 = False, None, False, 0.5, ds, 0
+    real_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
+        return real_to(self, *a, **k)
+    # (the frames are not stored: synth.pan_stream(16, 64, 96, pool=5, num=6, den=1, seed=4) regenerates them; their sum is)
+    fx = {"frames_sum": np.int64(int(frames.long().sum())), "intrinsic": intr.numpy(), "seed": np.int64(seed),
+          "windows": np.asarray([[0, 6, 1], [5, 11, 0], [10, 16, 0]], np.int64)}
+    torch.Tensor.to = to_cpu
+    try:
+        with torch.no_grad():
+            for w, (t0, t1, init) in enumerate(fx["windows"].tolist()):
+                tr.track(t0, t1, init=bool(init))
+                # what the window wrote: poses / depths of its keyframes t0..t1-1, its submap (index t0 // 5), the edge list after it
+                fx[f"pose_{w}"] = kf.pose[t0:t1].numpy().copy()
+                fx[f"depth_{w}"] = kf.depth[t0:t1].numpy().copy()
+                fx[f"submap_ds_{w}"] = kf.submap_ds[t0 // 5].numpy().copy()
+                fx[f"conf_ds_{w}"] = kf.conf_ds[t0 // 5].numpy().copy()
+                fx[f"ii_{w}"], fx[f"jj_{w}"], fx[f"age_{w}"] = graph.ii.numpy().copy(), graph.jj.numpy().copy(), graph.age.numpy().copy()
+    finally:
+        torch.Tensor.to = real_to
+    np.savez_compressed(os.path.join(HERE, "frontend.npz"), **fx)
+    print("wrote frontend:", {k: v.shape for k, v in fx.items() if hasattr(v, "shape")})
+    print("  edges after each window:", [len(fx[f"ii_{w}"]) for w in range(3)], "| log-depth scales of the chained windows:",
+          [float(np.log(fx[f"depth_{w}"][0]).mean()) for w in (1, 2)])
+
+
+def gen_loop_fixture():
+    """The per-frame loop of Hi2.run without its backend / mapper calls (hislam2/hi2.py:101-111): MotionFilter.kfFilter followed by
+    TrackFrontend.run for every frame of a seeded stream (fixed cadence kf_every = 2, 45 frames, the second-last / last frame flags of
+    demo_s.py) -- the reference's own window scheduling (warm-up of 6, `t1 < counter - 5`, the closing window of the last frame), its
+    return values (run_backend flag, keyframe range, submap index) and the final stores and edge list.  Adapters as in the two fixtures
+    above (KeyFrame / TrackFrontend created without their __init__, `.to('cuda')` redirected)."""
+    AR, ARCfg, inference = import_reference_model()
+    import_reference_graph()
+    import motion_filter as MF
+    from keyframe import KeyFrame
+    from track_frontend import TrackFrontend
+    from factor_graph import FactorGraph
+    from torch.multiprocessing import Value
+    from cut3r_slam_amd import synth
+    cfg = synth.medium_config()
+    seed = 11
+    sd = synth.tracking_state_dict(cfg, seed)
+    torch.manual_seed(0)
+    model = AR(ref_config(ARCfg, cfg)).eval()
+    torch.nn.Module.load_state_dict(model, sd, strict=True)
+    H, W = cfg.img_size
+    n, buffer, ds = 45, 32, 2
+    frames = synth.pan_stream(n, H, W, pool=5, num=3, den=1, seed=2)
+    kf = object.__new__(KeyFrame)
+    kf.counter, kf.ready, kf.is_initialized, kf.downsample_ratio = Value("i", 0), Value("i", 0), False, ds
+    kf.tstamp = torch.zeros(buffer)
+    kf.image = torch.zeros(buffer, 3, H, W, dtype=torch.uint8)
+    kf.intrinsic, kf.pose, kf.depth = torch.zeros(buffer, 4), torch.zeros(buffer, 7), torch.ones(buffer, H, W)
+    kf.pose[:] = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0])
+    kf.submap_ds = torch.ones(buffer // 5, 6, H // ds, W // ds, 3)
+    kf.conf_ds = torch.zeros(buffer // 5, 6, H // ds, W // ds)
+    kf.featI = torch.zeros(buffer, (H // 16) * (W // 16), cfg.enc_embed_dim)
+    kf.pos = torch.zeros(buffer, (H // 16) * (W // 16), 2, dtype=torch.int64)
+    filt = MF.MotionFilter(model, kf, {"thresh": 0.9, "skip": 1, "kf_every": 2, "skip_blur": False}, device="cpu")
+    graph = FactorGraph(kf, device="cpu", max_factors=48)
+    tr = object.__new__(TrackFrontend)
+    tr.device, tr.keyframes, tr.model, tr.graph = "cpu", kf, model, graph
+    tr.verbose, tr.output_dir, tr.use_gt, tr.conf_th, tr.downsample_ratio, tr.t1, tr.warmup = False, None, False, 0.5, ds, 0, 6
+    real_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
+        return real_to(self, *a, **k)
+    intr = torch.tensor([80.0, 80.0, 47.5, 31.5])
+    calls = []
+    torch.Tensor.to = to_cpu
+    try:
+        with torch.no_grad():
+            for t in range(n):
+                filt.kfFilter(t, frames[t:t + 1], intrinsics=intr, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+                flag, rng, sub = tr.run(t, last_frame=(t == n - 1))
+                if rng is not None:
+                    calls.append([t, int(bool(flag)), rng.start, rng.stop, int(sub)])
+    finally:
+        torch.Tensor.to = real_to
+    k, t1 = kf.counter.value, tr.t1
+    fx = {"seed": np.int64(seed), "frames_sum": np.int64(int(frames.long().sum())), "intrinsic": intr.numpy(), "calls": np.asarray(calls, np.int64),
+          "keyframes": kf.tstamp[:k].numpy().astype(np.int64), "t1": np.int64(t1), "pose": kf.pose[:t1].numpy().copy(),
+          "depth_mean": kf.depth[:t1].mean(dim=(1, 2)).numpy().copy(), "submap_ds": kf.submap_ds[:(t1 - 1) // 5 + 1].numpy().copy(),
+          "conf_mean": kf.conf_ds[:(t1 - 1) // 5 + 1].mean(dim=(2, 3)).numpy().copy(),
+          "ii": graph.ii.numpy().copy(), "jj": graph.jj.numpy().copy(), "age": graph.age.numpy().copy()}
+    np.savez_compressed(os.path.join(HERE, "loop.npz"), **fx)
+    print("wrote loop: keyframes", k, "tracked", t1, "calls (frame, run_backend, t0, t1, submap):", calls, "| edges", len(fx["ii"]))
+
+
+def gen_motion_filter_fixture():
+    """MotionFilter.kfFilter (hislam2/motion_filter.py:70-135) ITSELF on the CPU over two seeded streams: overlap mode (kf_every = -1,
+    skip = 2, thresh = 0.9: a slideshow whose content changes every 4 frames) and fixed cadence (kf_every = 3), both with the
+    second-last / last frame flags of demo_s.py.  Recorded: the time stamps that became keyframes and every overlap ratio the filter
+    computed (a spy around the module's compute_patch_overlap_ratio).  Adapters: the keyframe store is the reference's KeyFrame class
+    created without its __init__ (which allocates on "cuda") and given CPU tensors; `.to('cuda')` is redirected to the CPU."""
+    AR, ARCfg, inference = import_reference_model()
+    import_reference_graph()
+    import motion_filter as MF
+    from keyframe import KeyFrame
+    from torch.multiprocessing import Value
+    from cut3r_slam_amd import synth
+    cfg = synth.medium_config()
+    seed = 11
+    sd = synth.tracking_state_dict(cfg, seed)
+    torch.manual_seed(0)
+    model = AR(ref_config(ARCfg, cfg)).eval()
+    torch.nn.Module.load_state_dict(model, sd, strict=True)
+    H, W = cfg.img_size
+    real_to, real_ratio = torch.Tensor.to, MF.compute_patch_overlap_ratio
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
+        return real_to(self, *a, **k)
+    fx = {"seed": np.int64(seed)}
+    torch.Tensor.to = to_cpu
+    try:
+        for name, frames, mf in (("overlap", synth.slideshow_stream(41, H, W, hold=4, seed=3), {"thresh": 0.9, "skip": 2, "kf_every": -1}),
+                                 ("blend", synth.blend_stream(40, H, W, period=12, seed=5), {"thresh": 0.9, "skip": 1, "kf_every": -1}),
+                                 ("cadence", synth.pan_stream(20, H, W, pool=5, num=2, den=1, seed=0), {"thresh": 0.9, "skip": 1, "kf_every": 3})):
+            n, buffer = frames.shape[0], 48
+            kf = object.__new__(KeyFrame)
+            kf.counter, kf.ready = Value("i", 0), Value("i", 0)
+            kf.tstamp = torch.zeros(buffer)
+            kf.image = torch.zeros(buffer, 3, H, W, dtype=torch.uint8)
+            kf.intrinsic, kf.pose, kf.depth = torch.zeros(buffer, 4), torch.zeros(buffer, 7), torch.ones(buffer, H, W)
+            kf.featI = torch.zeros(buffer, (H // 16) * (W // 16), cfg.enc_embed_dim)
+            kf.pos = torch.zeros(buffer, (H // 16) * (W // 16), 2, dtype=torch.int64)
+            filt = MF.MotionFilter(model, kf, dict(mf, skip_blur=False), device="cpu")
+            ratios = []
+
+            def spy(f0, f1, _r=ratios, **k):
+                r = real_ratio(f0, f1, **k)
+                _r.append(float(r))
+                return r
+            MF.compute_patch_overlap_ratio = spy
+            intr = torch.tensor([80.0, 80.0, 47.5, 31.5])
+            with torch.no_grad():
+                for t in range(n):
+                    filt.kfFilter(t, frames[t:t + 1], intrinsics=intr, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+            k = kf.counter.value
+            fx[f"{name}_frames_sum"] = np.int64(int(frames.long().sum()))
+            fx[f"{name}_keyframes"] = kf.tstamp[:k].numpy().astype(np.int64)
+            fx[f"{name}_ratios"] = np.asarray(ratios, np.float64)
+            fx[f"{name}_feat_last"] = kf.featI[k - 1].numpy().copy()
+            print(name, "keyframes", fx[f"{name}_keyframes"].tolist(), "ratios", np.round(fx[f"{name}_ratios"], 3).tolist())
+    finally:
+        torch.Tensor.to = real_to
+        MF.compute_patch_overlap_ratio = real_ratio
+    np.savez_compressed(os.path.join(HERE, "motion_filter.npz"), **fx)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera"]
+    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop"]
+    if "motion_filter" in what:
+        gen_motion_filter_fixture()
+    if "loop" in what:
+        gen_loop_fixture()
+    if "frontend" in what:
+        gen_frontend_fixture()
     if "nms" in what:
         gen_nms_fixture()
     if "camera" in what:
