@@ -409,6 +409,122 @@ def gen_loop_fixture():
     print("wrote loop: keyframes", k, "tracked", t1, "calls (frame, run_backend, t0, t1, submap):", calls, "| edges", len(fx["ii"]))
 
 
+def gen_backend_fixture():
+    """TrackBackend.run (hislam2/track_backend.py:527-586) ITSELF on the CPU up to its optimiser call: the per-frame loop of Hi2.run
+    (hi2.py:101-121: kfFilter, TrackFrontend.run, every other eligible window the backend) over a seeded stream with weights for which
+    the loop detector fires (synth.loop_state_dict); at the first backend call the reference's own detect_loop scan, FactorGraph.NMS
+    choice and 6-view re-tracking (TrackBackend.track, :137-217) run, and the arguments it hands to loop_closure_init are recorded --
+    the optimiser itself needs lietorch, which the reference tree does not hold, so it is replaced by the recorder and the
+    fixture ends there.  Adapters as above, plus `.cuda()` as a no-op (NMS) and an empty `lietorch` module for the import line."""
+    AR, ARCfg, inference = import_reference_model()
+    import_reference_graph()
+    for m in ("tqdm",):
+        if m not in sys.modules:
+            try:
+                __import__(m)
+            except Exception:
+                sys.modules[m] = types.ModuleType(m)
+                sys.modules[m].tqdm = lambda x, *a, **k: x
+    import motion_filter as MF
+    from keyframe import KeyFrame
+    from track_frontend import TrackFrontend
+    from track_backend import TrackBackend
+    from factor_graph import FactorGraph
+    from torch.multiprocessing import Value
+    from cut3r_slam_amd import synth
+    cfg = synth.medium_config()
+    seed = 11
+    sd = synth.loop_state_dict(cfg, seed)
+    torch.manual_seed(0)
+    model = AR(ref_config(ARCfg, cfg)).eval()
+    torch.nn.Module.load_state_dict(model, sd, strict=True)
+    H, W = cfg.img_size
+    n, buffer, ds = 90, 64, 2
+    frames = synth.pan_stream(n, H, W, pool=5, num=2, den=1, seed=0)
+    kf = object.__new__(KeyFrame)
+    kf.counter, kf.ready, kf.is_initialized, kf.downsample_ratio = Value("i", 0), Value("i", 0), False, ds
+    kf.tstamp = torch.zeros(buffer)
+    kf.image = torch.zeros(buffer, 3, H, W, dtype=torch.uint8)
+    kf.intrinsic, kf.pose, kf.depth = torch.zeros(buffer, 4), torch.zeros(buffer, 7), torch.ones(buffer, H, W)
+    kf.pose[:] = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0])
+    kf.submap_ds = torch.ones(buffer // 5, 6, H // ds, W // ds, 3)
+    kf.conf_ds = torch.zeros(buffer // 5, 6, H // ds, W // ds)
+    kf.featI = torch.zeros(buffer, (H // 16) * (W // 16), cfg.enc_embed_dim)
+    kf.pos = torch.zeros(buffer, (H // 16) * (W // 16), 2, dtype=torch.int64)
+    filt = MF.MotionFilter(model, kf, {"thresh": 0.9, "skip": 1, "kf_every": 2, "skip_blur": False}, device="cpu")
+    graph = FactorGraph(kf, device="cpu", max_factors=48)
+    tr = object.__new__(TrackFrontend)
+    tr.device, tr.keyframes, tr.model, tr.graph = "cpu", kf, model, graph
+    tr.verbose, tr.output_dir, tr.use_gt, tr.conf_th, tr.downsample_ratio, tr.t1, tr.warmup = False, None, False, 0.5, ds, 0, 6
+    be = object.__new__(TrackBackend)
+    be.device, be.keyframes, be.model, be.graph = "cpu", kf, model, graph
+    be.verbose, be.output_dir, be.conf_th, be.downsample_ratio, be.lc_initialized = False, None, 0.05, ds, False
+    be.closed_loop = {"idx_current": [], "idx_matched": [], "pointmaps_lc": []}
+    rec = {}
+
+    def recorder(pointmap_current_lc, idx_matched, idx_current):
+        rec.update(pointmap_current_lc=pointmap_current_lc.detach().clone(), idx_matched=int(idx_matched), idx_current=int(idx_current))
+        return None
+    be.loop_closure_init = recorder
+    real_track, real_detect, real_nms = be.track, graph.detect_loop, graph.NMS
+
+    def track_spy(selected_idx, anchor_sub_num):
+        out = real_track(selected_idx, anchor_sub_num)
+        rec.update(selected_idx=selected_idx.numpy().copy(), anchor_sub_num=int(anchor_sub_num), pointmaps_lc=out[0].clone(), confs_lc=out[1].clone(), poses_lc=out[2].clone())
+        return out
+
+    def detect_spy(idx, *a, **k):
+        r = real_detect(idx, *a, **k)
+        rec.setdefault("scan", []).append((int(idx), None if r is None else np.asarray(r).copy()))
+        return r
+
+    def nms_spy(*a, **k):
+        r = real_nms(*a, **k)
+        rec["k_th"] = -1 if r is None else int(r)
+        return r
+    be.track, graph.detect_loop, graph.NMS = track_spy, detect_spy, nms_spy
+    real_to, real_cuda = torch.Tensor.to, torch.Tensor.cuda
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
+        return real_to(self, *a, **k)
+    intr = torch.tensor([80.0, 80.0, 47.5, 31.5])
+    torch.Tensor.to, torch.Tensor.cuda = to_cpu, (lambda self, *a, **k: self)
+    fired_at, freeze, windows = None, 0, []
+    try:
+        with torch.no_grad():
+            for t in range(n):
+                filt.kfFilter(t, frames[t:t + 1], intrinsics=intr, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+                flag, rng, sub = tr.run(t, last_frame=(t == n - 1))
+                if rng is not None:
+                    windows.append([t, int(bool(flag)), rng.start, rng.stop])
+                if flag:                                   # hi2.py:112-121
+                    if freeze > 0:
+                        rec.clear()
+                        ok, _ = be.run()
+                        freeze = 0
+                        if ok:
+                            fired_at = t
+                            break
+                    else:
+                        freeze += 1
+    finally:
+        torch.Tensor.to, torch.Tensor.cuda = real_to, real_cuda
+    assert fired_at is not None, "the reference backend never closed a loop on this stream"
+    k, t1 = kf.counter.value, tr.t1
+    cand = [c for _, c in rec["scan"] if c is not None][-1]
+    fx = {"seed": np.int64(seed), "frames_sum": np.int64(int(frames.long().sum())), "intrinsic": intr.numpy(), "fired_at_frame": np.int64(fired_at),
+          "windows": np.asarray(windows, np.int64), "keyframes": kf.tstamp[:k].numpy().astype(np.int64),
+          "scan_idx": np.asarray([i for i, _ in rec["scan"]], np.int64), "candidates": np.asarray(cand, np.int64), "k_th": np.int64(rec["k_th"]),
+          "idx_current": np.int64(rec["idx_current"]), "idx_matched": np.int64(rec["idx_matched"]), "selected_idx": rec["selected_idx"].astype(np.int64),
+          "anchor_sub_num": np.int64(rec["anchor_sub_num"]), "pointmaps_lc": rec["pointmaps_lc"].numpy(), "confs_lc": rec["confs_lc"].numpy(),
+          "poses_lc": rec["poses_lc"].numpy(), "pointmap_current_lc": rec["pointmap_current_lc"].numpy(),
+          "pose_before": kf.pose[:t1].numpy().copy(), "ii": graph.ii.numpy().copy(), "jj": graph.jj.numpy().copy()}
+    np.savez_compressed(os.path.join(HERE, "backend.npz"), **fx)
+    print("wrote backend: fired at frame", fired_at, "keyframes", k, "| scan", fx["scan_idx"].tolist(), "candidates", fx["candidates"].tolist(), "k_th", int(fx["k_th"]),
+          "-> matched", int(fx["idx_matched"]), "current", int(fx["idx_current"]), "| selected", fx["selected_idx"].tolist())
+
+
 def gen_motion_filter_fixture():
     """MotionFilter.kfFilter (hislam2/motion_filter.py:70-135) ITSELF on the CPU over two seeded streams: overlap mode (kf_every = -1,
     skip = 2, thresh = 0.9: a slideshow whose content changes every 4 frames) and fixed cadence (kf_every = 3), both with the
@@ -472,11 +588,13 @@ def gen_motion_filter_fixture():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop"]
+    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop", "backend"]
     if "motion_filter" in what:
         gen_motion_filter_fixture()
     if "loop" in what:
         gen_loop_fixture()
+    if "backend" in what:
+        gen_backend_fixture()
     if "frontend" in what:
         gen_frontend_fixture()
     if "nms" in what:

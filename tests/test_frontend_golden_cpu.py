@@ -123,3 +123,59 @@ def test_oracle_loop_equals_the_reference_kffilter_plus_trackfrontend_run():
     ii, jj = so.graph.edges_numpy()[:2]
     np.testing.assert_array_equal(ii, f["ii"])
     np.testing.assert_array_equal(jj, f["jj"])
+
+
+def load_backend_fixture():
+    f = np.load(os.path.join(GOLD, "backend.npz"))
+    cfg = synth.medium_config()
+    sd = synth.loop_state_dict(cfg, int(f["seed"]))
+    frames = synth.pan_stream(90, *cfg.img_size, pool=5, num=2, den=1, seed=0)
+    assert int(frames.long().sum()) == int(f["frames_sum"]), "the regenerated frames are not the fixture's"
+    return f, cfg, sd, frames
+
+
+def test_oracle_backend_equals_the_reference_trackbackend_up_to_the_optimiser():
+    """TrackBackend.run of the reference, run on the CPU up to its optimiser call (`backend.npz`; the optimiser needs lietorch, absent from
+    the reference tree): WHEN the backend first fires in the per-frame loop (every other eligible window, hi2.py:112-121), the keyframe
+    its detect_loop scan stops at, the candidate list, the NMS choice, the six keyframes it re-tracks and the re-tracked submap, its
+    confidences and poses (TrackBackend.track, :137-217) -- the inputs of loop_closure_init."""
+    f, cfg, sd, frames = load_backend_fixture()
+    mf = {"thresh": 0.9, "skip": 1, "kf_every": 2}
+    t_fire = int(f["fired_at_frame"])
+    # (a) the loop with the backend on closes its first loop at the same frame, on the same pair, from the same candidates
+    so = SR.SlamOracle(cfg, sd, cfg.img_size, 64, mf, iteration=1)
+    for t in range(t_fire + 1):
+        so.run(t, frames[t], f["intrinsic"])
+        assert len(so.closures) == (1 if t == t_fire else 0), t
+    c = so.closures[0]
+    assert (c["idx_current"], c["idx_matched"], c["at_keyframe"]) == (int(f["idx_current"]), int(f["idx_matched"]), len(f["keyframes"]))
+    np.testing.assert_array_equal(np.sort(c["candidates"]), np.sort(f["candidates"]))
+    np.testing.assert_array_equal(so.tstamp[:so.counter].astype(np.int64), f["keyframes"])
+    np.testing.assert_array_equal(np.asarray([[a, b] for a, b, _ in so.windows]), f["windows"][:, 2:4])
+    # (b) the pieces, on the state the reference had when it called the backend (no closure applied)
+    so = SR.SlamOracle(cfg, sd, cfg.img_size, 64, mf, iteration=0)
+    for t in range(t_fire + 1):
+        so.run(t, frames[t], f["intrinsic"])
+    np.testing.assert_allclose(so.state["pose"][:so.t1].numpy(), f["pose_before"], atol=2e-5)
+    ii, jj = so.graph.edges_numpy()[:2]
+    np.testing.assert_array_equal(ii, f["ii"])
+    np.testing.assert_array_equal(jj, f["jj"])
+    t1 = so.counter - 1
+    scan = []
+    for idx_current in range(t1 - 6, t1 - 1):
+        ids = so.graph.detect_loop(idx_current)
+        scan.append(idx_current)
+        if ids is not None:
+            break
+    assert scan == f["scan_idx"].tolist() and sorted(np.asarray(ids).tolist()) == sorted(f["candidates"].tolist())
+    K4 = (so.intrinsic[0] / np.float32(2)).astype(np.float32)
+    scores = so.nms_scores(f["candidates"], idx_current, K4)
+    assert float(scores.max()) > 0.4 and int(np.argmax(scores)) == int(f["k_th"])
+    sel = f["selected_idx"].tolist()
+    anchor = int(f["idx_matched"]) // 5
+    assert sel == list(range(anchor * 5, anchor * 5 + 5)) + [idx_current] and anchor == int(f["anchor_sub_num"])
+    pm, cf, ps = so.backend_track(sel, anchor)
+    for name, got, ref in (("pointmaps_lc", pm.numpy(), f["pointmaps_lc"]), ("confs_lc", cf.numpy(), f["confs_lc"]), ("poses_lc", ps.numpy(), f["poses_lc"])):
+        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+        assert err < 2e-5, (name, err)
+    np.testing.assert_allclose(pm[-1:].numpy(), f["pointmap_current_lc"], atol=2e-5 * np.abs(f["pointmap_current_lc"]).max())
