@@ -525,6 +525,52 @@ def gen_backend_fixture():
           "-> matched", int(fx["idx_matched"]), "current", int(fx["idx_current"]), "| selected", fx["selected_idx"].tolist())
 
 
+def gen_chol_fixture():
+    """hislam2/geom/chol.py ITSELF on the CPU (pure torch; its `import geom.projective_ops` pulls `lietorch` names that only the
+    projective functions use: the empty stub module of import_reference_graph() serves the import line): block_solve, schur_solve (full and
+    sless) and schur_solve_mono_prior on seeded SPD systems with GENERAL (not block-diagonal) blocks, in the reference's fp32 and once more
+    with fp64 inputs (same code) as the tight target.  Pins the reduced solves of the legacy dense-BA stack."""
+    import_reference_graph()
+    sys.modules["lietorch"].Sim3 = object
+    sys.path[:0] = [os.path.join(REF, "hislam2")]
+    from geom import chol
+    g = torch.Generator().manual_seed(17)
+    fx = {}
+    # ---- schur_solve: P poses of 6 dof, M disparity maps of HW pixels
+    P, M, D, HW = 4, 3, 6, 24
+    A = torch.randn(P * D, P * D, generator=g, dtype=torch.float64)
+    Hf = A @ A.T + 6.0 * torch.eye(P * D, dtype=torch.float64)
+    H = Hf.reshape(P, D, P, D).permute(0, 2, 1, 3)[None].contiguous()                     # [1,P,P,D,D]
+    E = torch.randn(1, P, M, D, HW, generator=g, dtype=torch.float64) * 0.25
+    C = torch.rand(1, M, HW, generator=g, dtype=torch.float64) * 2 + 6.0
+    v = torch.randn(1, P, D, generator=g, dtype=torch.float64)
+    w = torch.randn(1, M, HW, generator=g, dtype=torch.float64)
+    fx.update(ss_H=H.numpy(), ss_E=E.numpy(), ss_C=C.numpy(), ss_v=v.numpy(), ss_w=w.numpy())
+    for tag, cast in (("f32", torch.float32), ("f64", torch.float64)):
+        c = lambda t: t.to(cast)
+        dx, dz, cov = chol.schur_solve(c(H), c(E), c(C), c(v), c(w))
+        fx[f"ss_dx_{tag}"], fx[f"ss_dz_{tag}"], fx[f"ss_cov_{tag}"] = dx.double().numpy(), dz.double().numpy(), cov.double().numpy()
+        fx[f"ss_dx_sless_{tag}"] = chol.schur_solve(c(H), c(E), c(C), c(v), c(w), sless=True).double().numpy()
+        fx[f"bs_x_{tag}"] = chol.block_solve(c(H), c(v)).double().numpy()
+    # ---- schur_solve_mono_prior: M frames, D = hs * ws scale-grid nodes each
+    M2, D2, HW2 = 3, 6, 40
+    A = torch.randn(M2 * D2, M2 * D2, generator=g, dtype=torch.float64)
+    Hf = A @ A.T + 4.0 * torch.eye(M2 * D2, dtype=torch.float64)
+    Hs = Hf.reshape(M2, D2, M2, D2).permute(0, 2, 1, 3)[None].contiguous()
+    Es = torch.randn(1, M2, M2, D2, HW2, generator=g, dtype=torch.float64) * 0.3
+    vs = torch.randn(1, M2, D2, generator=g, dtype=torch.float64)
+    C2 = torch.rand(1, M2, HW2, generator=g, dtype=torch.float64) * 2 + 6.0
+    w2 = torch.randn(1, M2, HW2, generator=g, dtype=torch.float64)
+    fx.update(mp_Hs=Hs.numpy(), mp_Es=Es.numpy(), mp_vs=vs.numpy(), mp_C=C2.numpy(), mp_w=w2.numpy())
+    for tag, cast in (("f32", torch.float32), ("f64", torch.float64)):
+        c = lambda t: t.to(cast)
+        dso, dz, cov = chol.schur_solve_mono_prior(c(C2), c(w2), c(Hs), c(Es), c(vs), dzcov=True)
+        fx[f"mp_dso_{tag}"], fx[f"mp_dz_{tag}"], fx[f"mp_cov_{tag}"] = dso.double().numpy(), dz.double().numpy(), cov.double().numpy()
+    np.savez_compressed(os.path.join(HERE, "chol.npz"), **fx)
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    print("wrote chol: reference fp32 vs its fp64 run:", {k: f"{rel(fx[k + '_f32'], fx[k + '_f64']):.1e}" for k in ("ss_dx", "ss_dz", "ss_cov", "bs_x", "mp_dso", "mp_dz", "mp_cov")})
+
+
 def gen_motion_filter_fixture():
     """MotionFilter.kfFilter (hislam2/motion_filter.py:70-135) ITSELF on the CPU over two seeded streams: overlap mode (kf_every = -1,
     skip = 2, thresh = 0.9: a slideshow whose content changes every 4 frames) and fixed cadence (kf_every = 3), both with the
@@ -588,13 +634,15 @@ def gen_motion_filter_fixture():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop", "backend"]
+    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop", "backend", "chol"]
     if "motion_filter" in what:
         gen_motion_filter_fixture()
     if "loop" in what:
         gen_loop_fixture()
     if "backend" in what:
         gen_backend_fixture()
+    if "chol" in what:
+        gen_chol_fixture()
     if "frontend" in what:
         gen_frontend_fixture()
     if "nms" in what:

@@ -277,3 +277,48 @@ def test_depth_filter_counts_match_restatement():
     assert ref[1, 5:12, 8:20].mean() < 0.5 * ref[1].mean()       # the blob is rejected
     with pytest.raises(IndexError):
         db.depth_filter(poses.to(DEV), disps.to(DEV), intr.to(DEV), torch.tensor([9]).to(DEV), thresh[:1].to(DEV))
+
+
+def _chol_fixture():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chol.npz"))
+
+
+def test_schur_solve_mono_prior_equals_the_reference_chol_py():
+    """cut3r_schur_mono_prior against the REFERENCE'S OWN geom/chol.py:80-107, run on the CPU by tests/golden/make_fixtures.py (`chol.npz`;
+    general blocks): dso, dz and the covariance.  (The reference's fp32 run is 3e-7 from its fp64 run; the fp64 outputs are the target.)"""
+    from cut3r_slam_amd.ba import schur_solve_mono_prior
+    f = _chol_fixture()
+    t = lambda k: torch.from_numpy(f[k]).float().to(DEV)
+    dso, dz, cov = schur_solve_mono_prior(t("mp_C"), t("mp_w"), t("mp_Hs"), t("mp_Es"), t("mp_vs"), dzcov=True)
+    torch.cuda.synchronize()
+    for got, name in ((dso, "mp_dso"), (dz, "mp_dz"), (cov, "mp_cov")):
+        ref = f[name + "_f64"]
+        err = float(np.abs(got.cpu().double().numpy() - ref).max() / np.abs(ref).max())
+        print(f"[schur_solve_mono_prior vs reference chol.py] {name}: {err:.1e}")
+        assert err < 5e-5, (name, err)
+
+
+def test_pose_system_solve_equals_the_reference_schur_solve():
+    """cut3r_ba_solve (damping with diag H, in-LDS Cholesky) on the reduced system of the fixture against the reference's schur_solve
+    (geom/chol.py:45-78, `chol.npz`): S = H - E C^-1 E^T and vS = v - E C^-1 w are formed on the host in fp64 exactly as :60-61 do, the
+    kernel adds (ep + lm H_ii) and solves; dx equals the reference's (full and `sless` call), and the back-substituted dz = (w - E^T dx) / C."""
+    from cut3r_slam_amd.ba import _solve
+    f = _chol_fixture()
+    H, E, C, v, w = (torch.from_numpy(f[k]) for k in ("ss_H", "ss_E", "ss_C", "ss_v", "ss_w"))
+    _, P, M, D, HW = E.shape
+    Hm = H.permute(0, 1, 3, 2, 4).reshape(P * D, P * D)
+    Em = E.permute(0, 1, 3, 2, 4).reshape(P * D, M * HW)
+    Q = (1.0 / C).reshape(M * HW)
+    S = Hm - (Em * Q) @ Em.T
+    vS = v.reshape(-1) - Em @ (Q * w.reshape(-1))
+    dx, flag = _solve(S.float().to(DEV).contiguous(), vS.float().to(DEV).contiguous(), torch.diagonal(Hm).float().to(DEV).contiguous(), 0.1, 1e-4)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    got = dx.cpu().double().numpy().reshape(1, P, D)
+    for name in ("ss_dx_f64", "ss_dx_sless_f64"):
+        err = float(np.abs(got - f[name]).max() / np.abs(f[name]).max())
+        print(f"[cut3r_ba_solve vs reference schur_solve] {name}: {err:.1e}")
+        assert err < 5e-5, (name, err)
+    dz = (Q * (w.reshape(-1) - Em.T @ torch.from_numpy(got).reshape(-1))).reshape(1, M, HW).numpy()
+    assert float(np.abs(dz - f["ss_dz_f64"]).max() / np.abs(f["ss_dz_f64"]).max()) < 5e-5
