@@ -69,9 +69,12 @@ def depth_to_normal(depth, K):
 
 
 def ssim(a, b, window=11, sigma=1.5):
-    g = torch.exp(-((torch.arange(window, dtype=DT) - window // 2) ** 2) / (2 * sigma * sigma))
+    """gaussian/utils/loss_utils.py:51-68,129-170.  The reference builds its window in fp32 (torch.Tensor of Python floats, normalised and
+    multiplied out in fp32) and only then casts it to the image type: the same here, so that the fp64 value equals the reference's
+    (tests/golden/gs_utils.npz) to rounding."""
+    g = torch.tensor([math.exp(-((x - window // 2) ** 2) / float(2 * sigma ** 2)) for x in range(window)], dtype=torch.float32)
     g = (g / g.sum())[:, None]
-    w = (g @ g.T)[None, None].expand(a.shape[0], 1, window, window).contiguous()
+    w = (g @ g.T)[None, None].expand(a.shape[0], 1, window, window).contiguous().to(a.dtype)
     f = lambda t: F.conv2d(t[None], w, padding=window // 2, groups=a.shape[0])[0]
     mu1, mu2 = f(a), f(b)
     s11, s22, s12 = f(a * a) - mu1 * mu1, f(b * b) - mu2 * mu2, f(a * b) - mu1 * mu2

@@ -571,6 +571,65 @@ def gen_chol_fixture():
     print("wrote chol: reference fp32 vs its fp64 run:", {k: f"{rel(fx[k + '_f32'], fx[k + '_f64']):.1e}" for k in ("ss_dx", "ss_dz", "ss_cov", "bs_x", "mp_dso", "mp_dz", "mp_cov")})
 
 
+def gen_gs_utils_fixture():
+    """The pure-torch pieces of the reference's Gaussian-splatting backend, run on the CPU (the rasteriser itself is a CUDA extension and
+    cannot run here): loss_utils.ssim with its autograd gradient, graphics_utils.getProjectionMatrix2 / getWorld2View2, slam_utils.SE3_exp
+    (small and large angles), slam_utils.update_pose / get_pose on a camera namespace, project2world, general_utils.helper (the position
+    learning-rate schedule) and inverse_sigmoid.  Stub modules for cv2 / matplotlib serve the import lines only."""
+    for m in ("cv2", "matplotlib", "matplotlib.cm"):
+        if m not in sys.modules:
+            sys.modules[m] = types.ModuleType(m)
+    sys.modules["matplotlib"].cm = sys.modules["matplotlib.cm"]
+    sys.path[:0] = [os.path.join(REF, "hislam2")]
+    from gaussian.utils import loss_utils, graphics_utils, slam_utils, general_utils
+    g = torch.Generator().manual_seed(29)
+    fx = {}
+    # ---- SSIM value + gradient (the mapper's 0.2 (1 - ssim) term)
+    a = torch.rand(3, 40, 56, generator=g, dtype=torch.float64)
+    b = (a + 0.15 * torch.randn(3, 40, 56, generator=g, dtype=torch.float64)).clamp(0, 1)
+    ar = a.clone().requires_grad_(True)
+    val = loss_utils.ssim(ar, b)
+    val.backward()
+    fx.update(ssim_a=a.numpy(), ssim_b=b.numpy(), ssim_value=np.float64(val.item()), ssim_grad_a=ar.grad.numpy(),
+              l1_value=np.float64(loss_utils.l1_loss(a, b).item()))
+    # ---- projection / view matrices
+    cams = [(0.01, 100.0, 31.5, 23.5, 40.0, 42.0, 64, 48), (0.01, 100.0, 250.3, 190.9, 440.0, 441.5, 512, 384)]
+    fx["proj_args"] = np.asarray(cams, np.float64)
+    fx["proj"] = np.stack([graphics_utils.getProjectionMatrix2(*c).numpy() for c in cams])
+    Rm = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    tv = torch.randn(3, generator=g)
+    fx.update(w2v_R=Rm.numpy(), w2v_t=tv.numpy(), w2v=graphics_utils.getWorld2View2(Rm, tv).numpy())
+    # ---- SE3_exp and the pose update
+    taus = torch.cat([torch.randn(6, 6, generator=g, dtype=torch.float64) * 0.3, torch.randn(2, 6, generator=g, dtype=torch.float64) * 1e-7,
+                      torch.tensor([[0.1, -0.2, 0.3, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 2.5, -1.0, 0.7]], dtype=torch.float64)], 0)
+    fx["tau"] = taus.numpy()
+    fx["se3_exp"] = np.stack([slam_utils.SE3_exp(t).numpy() for t in taus])
+    cam = types.SimpleNamespace(R=torch.linalg.qr(torch.randn(3, 3, generator=g))[0], T=torch.randn(3, generator=g),
+                                cam_trans_delta=torch.tensor([0.02, -0.01, 0.03]), cam_rot_delta=torch.tensor([0.01, 0.02, -0.015]))
+
+    def update_RT(R, t):
+        cam.R, cam.T = R.clone(), t.clone()
+    cam.update_RT = update_RT
+    fx.update(cam_R=cam.R.numpy().copy(), cam_T=cam.T.numpy().copy(), cam_trans_delta=cam.cam_trans_delta.numpy().copy(),
+              cam_rot_delta=cam.cam_rot_delta.numpy().copy(), get_pose=slam_utils.get_pose(cam).numpy())
+    slam_utils.update_pose(cam)
+    fx.update(updated_R=cam.R.numpy().copy(), updated_T=cam.T.numpy().copy())
+    # ---- project2world, learning-rate schedule, inverse sigmoid
+    c2w = torch.eye(4)[None].repeat(2, 1, 1)
+    c2w[:, :3, :3] = torch.linalg.qr(torch.randn(2, 3, 3, generator=g))[0]
+    c2w[:, :3, 3] = torch.randn(2, 3, generator=g)
+    dep = torch.rand(2, 12, 16, generator=g) * 3 + 0.5
+    fx.update(p2w_c2w=c2w.numpy(), p2w_depth=dep.numpy(), p2w=slam_utils.project2world(c2w, dep, 20.0, 21.0, 7.5, 5.5).numpy())
+    steps = np.asarray([0, 1, 10, 100, 999, 1000, 5000, 29999, 30000, 40000], np.int64)
+    fx["lr_steps"] = steps
+    fx["lr"] = np.asarray([general_utils.helper(int(st), 0.00016, 0.0000016, 0, 0.01, 30000) for st in steps], np.float64)
+    fx["lr_delay"] = np.asarray([general_utils.helper(int(st), 0.00016, 0.0000016, 500, 0.01, 30000) for st in steps], np.float64)
+    x = torch.tensor([0.01, 0.1, 0.5, 0.9, 0.99])
+    fx.update(isig_x=x.numpy(), isig=general_utils.inverse_sigmoid(x).numpy())
+    np.savez_compressed(os.path.join(HERE, "gs_utils.npz"), **fx)
+    print("wrote gs_utils: ssim", float(val), "| proj[0]", fx["proj"][0].round(4).tolist())
+
+
 def gen_motion_filter_fixture():
     """MotionFilter.kfFilter (hislam2/motion_filter.py:70-135) ITSELF on the CPU over two seeded streams: overlap mode (kf_every = -1,
     skip = 2, thresh = 0.9: a slideshow whose content changes every 4 frames) and fixed cadence (kf_every = 3), both with the
@@ -634,7 +693,7 @@ def gen_motion_filter_fixture():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop", "backend", "chol"]
+    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop", "backend", "chol", "gs_utils"]
     if "motion_filter" in what:
         gen_motion_filter_fixture()
     if "loop" in what:
@@ -643,6 +702,8 @@ if __name__ == "__main__":
         gen_backend_fixture()
     if "chol" in what:
         gen_chol_fixture()
+    if "gs_utils" in what:
+        gen_gs_utils_fixture()
     if "frontend" in what:
         gen_frontend_fixture()
     if "nms" in what:
