@@ -119,7 +119,7 @@ SIGNATURES = {
     "cut3r_pixel_loss_backward": [c_void_p] * 5 + [c_int, c_int] + [c_float] * 4 + [c_void_p] * 4,
     "cut3r_normal_agree_forward": [c_void_p, c_void_p, c_int, c_int] + [c_float] * 4 + [c_void_p, c_void_p],
     "cut3r_normal_agree_backward": [c_void_p, c_void_p, c_int, c_int] + [c_float] * 5 + [c_void_p, c_void_p, c_void_p],
-    "cut3r_gs_densify_stats": [c_int] + [c_void_p] * 6,
+    "cut3r_gs_densify_stats": [c_int] + [c_void_p] * 7,
     "cut3r_refine_loss_forward": [c_void_p] * 5 + [c_float, c_int, c_int, c_void_p, c_void_p],
     "cut3r_refine_loss_backward": [c_void_p] * 5 + [c_float, c_int, c_int] + [c_void_p] * 4,
     "cut3r_ssim_forward": [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 5,

@@ -1030,7 +1030,8 @@ __global__ __launch_bounds__(256) void normal_agree_bwd_kernel(const float* __re
 // densification statistics of one rendered view (gaussian_model.py:779-790 add_densification_stats + the max_radii2D update of
 // gs_backend_per_frame.py:1021-1027): visible = radii > 0
 __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const int* __restrict__ radii, const float* __restrict__ d_means2D,
-                                                            float* __restrict__ max_radii, float* __restrict__ grad_accum, float* __restrict__ denom) {
+                                                            float* __restrict__ max_radii, float* __restrict__ grad_accum,
+                                                            float* __restrict__ grad_accum_abs, float* __restrict__ denom) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const int r = radii[i];
@@ -1038,6 +1039,7 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const int* __
         max_radii[i] = fmaxf(max_radii[i], (float)r);
         const float gx = d_means2D[3 * i], gy = d_means2D[3 * i + 1];
         grad_accum[i] += sqrtf(gx * gx + gy * gy);
+        grad_accum_abs[i] += fabsf(d_means2D[3 * i + 2]);            // (:781: the norm of the remaining channel = the absolute-gradient statistic)
         denom[i] += 1.f;
     }
 }
@@ -1321,11 +1323,11 @@ extern "C" int cut3r_normal_agree_backward(const float* normal, const float* dep
     return cut3r_check_launch();
 }
 
-extern "C" int cut3r_gs_densify_stats(int P, const int* radii, const float* d_means2D, float* max_radii2D, float* grad_accum, float* denom,
-                                      void* stream) {
-    if (P <= 0 || !radii || !d_means2D || !max_radii2D || !grad_accum || !denom) return CUT3R_ERR_ARG;
+extern "C" int cut3r_gs_densify_stats(int P, const int* radii, const float* d_means2D, float* max_radii2D, float* grad_accum,
+                                      float* grad_accum_abs, float* denom, void* stream) {
+    if (P <= 0 || !radii || !d_means2D || !max_radii2D || !grad_accum || !grad_accum_abs || !denom) return CUT3R_ERR_ARG;
     hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, radii, d_means2D, max_radii2D, grad_accum,
-                       denom);
+                       grad_accum_abs, denom);
     return cut3r_check_launch();
 }
 

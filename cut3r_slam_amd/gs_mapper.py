@@ -64,7 +64,7 @@ class GaussianMap:
         self._steps_dev_stale = False                                     # the fused trainer advanced `steps` without touching the device scalar
         self.kf_id = torch.zeros(0, dtype=torch.int32, device=self.device)
         self.max_radii2D = z(0)
-        self.grad_accum, self.denom = z(0, 1), z(0, 1)
+        self.grad_accum, self.grad_accum_abs, self.denom = z(0, 1), z(0, 1), z(0, 1)
 
     @property
     def p(self):
@@ -104,6 +104,7 @@ class GaussianMap:
         self.kf_id = torch.cat([self.kf_id, kf_id.to(self.device, torch.int32)], 0)
         self.max_radii2D = torch.cat([self.max_radii2D, z(n)], 0)
         self.grad_accum, self.denom = torch.cat([self.grad_accum, z(n, 1)], 0), torch.cat([self.denom, z(n, 1)], 0)
+        self.grad_accum_abs = torch.cat([self.grad_accum_abs, z(n, 1)], 0)
 
     def extend_from_pcd_seq(self, submap_idx=-1, rgb=None, pointmap=None, conf=None, point_size=1.0):
         """gaussian_model.py:150-216,363-372: one Gaussian per pointmap pixel with conf > 0; scale = sqrt of the mean squared 3-NN distance,
@@ -129,7 +130,7 @@ class GaussianMap:
         self.theta = self.theta.detach()[keep].requires_grad_(True)
         self.m, self.v = self.m[keep], self.v[keep]
         self.kf_id, self.max_radii2D = self.kf_id[keep], self.max_radii2D[keep]
-        self.grad_accum, self.denom = self.grad_accum[keep], self.denom[keep]
+        self.grad_accum, self.grad_accum_abs, self.denom = self.grad_accum[keep], self.grad_accum_abs[keep], self.denom[keep]
 
     def reset_opacity(self):
         """gaussian_model.py:483-486: every opacity back to 0.15, its optimiser state cleared"""
@@ -145,17 +146,41 @@ class GaussianMap:
         self.v[rows] = 0
 
     def add_densification_stats(self, viewspace_grad, update_filter):
-        """gaussian_model.py:779-790: norm of the screen-space gradient (x, y) per visible Gaussian"""
-        self.grad_accum += torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True) * update_filter[:, None]
-        self.denom += update_filter[:, None].float()
+        """gaussian_model.py:779-783: per visible Gaussian the norm of the screen-space gradient (x, y) and -- the RaDe-GS / AbsGS flavour the
+        reference vendors -- the absolute-gradient statistic the rasteriser's backward leaves in the third channel of means2D.grad"""
+        f = update_filter[:, None]
+        self.grad_accum += torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True) * f
+        if viewspace_grad.shape[1] > 2:
+            self.grad_accum_abs += torch.norm(viewspace_grad[:, 2:], dim=-1, keepdim=True) * f
+        self.denom += f.float()
+
+    def _split_noise(self, n):
+        """standard-normal draws of densify_and_split (gaussian_model.py:652-654 torch.normal(0, stds) = stds * these); its own method so
+        that a test can replay the reference's draws"""
+        return torch.randn(n, 3, device=self.device)
+
+    def reset_densification_stats(self):
+        self.grad_accum.zero_()
+        self.grad_accum_abs.zero_()
+        self.denom.zero_()
+        self.max_radii2D.zero_()
 
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
-        """gaussian_model.py:639-777: clone small Gaussians with a large mean screen gradient, split large ones in two, then prune the
-        transparent and the oversized"""
-        grads = self.grad_accum / self.denom.clamp_min(1)
+        """gaussian_model.py:639-777.  A Gaussian is selected when its mean screen gradient reaches `max_grad` OR its mean absolute-gradient
+        statistic reaches the (1 - ratio) quantile of that statistic, ratio = the share selected by the first rule (:751-756); the small ones
+        (largest scale <= percent_dense * extent) are cloned, the large ones replaced by two samples of themselves with scales / 1.6; then the
+        transparent (opacity < min_opacity), the oversized in the world (> 0.1 extent, only with `max_screen_size`) and the degenerate
+        (largest scale < 5e-4, :767-768) are pruned.  densification_postfix (:629-633) zeroes the statistics INCLUDING max_radii2D before the
+        prune mask is formed, so the reference's screen-size rule never fires after a densification: reproduced."""
+        grads = self.grad_accum / self.denom
         grads[grads.isnan()] = 0.0
-        big = self.get_scaling.detach().max(dim=1).values > self.percent_dense * extent
+        grads_abs = self.grad_accum_abs / self.denom
+        grads_abs[grads_abs.isnan()] = 0.0
         hot = grads[:, 0] >= max_grad
+        ratio = hot.float().mean()
+        Q = torch.quantile(grads_abs.reshape(-1), 1 - ratio)
+        hot = hot | (grads_abs[:, 0] >= Q)
+        big = self.get_scaling.detach().max(dim=1).values > self.percent_dense * extent
         clone, split = hot & ~big, hot & big
         th = self.theta.detach()
         new = []
@@ -166,21 +191,21 @@ class GaussianMap:
             std = self.get_scaling.detach()[split].repeat(2, 1)
             R = SO3_matrix(self.get_rotation.detach()[split]).repeat(2, 1, 1)
             rows = th[split].repeat(2, 1)
-            rows[:, 0:3] = (R @ (torch.randn(2 * n, 3, device=self.device) * std)[:, :, None])[:, :, 0] + rows[:, 0:3]
+            rows[:, 0:3] = (R @ (self._split_noise(2 * n) * std)[:, :, None])[:, :, 0] + rows[:, 0:3]
             rows[:, 7:10] = torch.log(std / (0.8 * 2))
             new.append((rows, self.kf_id[split].repeat(2)))
         n_before = len(self)
         for rows, ids in new:
             self._append({k: rows[:, a:b] for k, (a, b) in self.COLS.items()}, ids)
+        self.reset_densification_stats()
         drop = torch.zeros(len(self), dtype=torch.bool, device=self.device)
         drop[:n_before] = split
+        smax = self.get_scaling.detach().max(dim=1).values
         drop |= (self.get_opacity.detach() < min_opacity)[:, 0]
         if max_screen_size:
-            drop |= (self.max_radii2D > max_screen_size) | (self.get_scaling.detach().max(dim=1).values > 0.1 * extent)
+            drop |= (self.max_radii2D > max_screen_size) | (smax > 0.1 * extent)
+        drop |= smax < 5e-4
         self.prune_points(drop)
-        self.grad_accum.zero_()
-        self.denom.zero_()
-        self.max_radii2D.zero_()
 
     # ---- Adam (torch.optim.Adam(lr per group, eps=1e-15) of gaussian_model.py:374-417; one step count for the block, see the class
     #      docstring)
@@ -835,9 +860,7 @@ class GSMapper:
                 gm.theta.data[gi, 0:3] = xyz
                 gm.theta.data[gi, 10:14] = new_rot
                 gm.reset_moments(gi)
-                gm.grad_accum.zero_()
-                gm.denom.zero_()
-                gm.max_radii2D.zero_()
+                gm.reset_densification_stats()
         for k in update_idx:
             if refine_iters > 0:
                 self.pose_refine([k], iters=refine_iters, return_args=False, alpha_th=0.0)
@@ -881,7 +904,7 @@ class GSMapper:
             g._steps_dev_stale = False
         save_file({"theta": g.theta.detach().contiguous(), "m": g.m.contiguous(), "v": g.v.contiguous(), "step_count": g.step_count.contiguous(),
                    "kf_id": g.kf_id.contiguous(), "max_radii2D": g.max_radii2D.contiguous(), "grad_accum": g.grad_accum.contiguous(),
-                   "denom": g.denom.contiguous()}, path)
+                   "grad_accum_abs": g.grad_accum_abs.contiguous(), "denom": g.denom.contiguous()}, path)
 
     def load(self, path):
         from safetensors.torch import load_file
@@ -891,6 +914,7 @@ class GSMapper:
         g.m, g.v, g.step_count, g.kf_id = t["m"], t["v"], t["step_count"], t["kf_id"]
         g.steps, g._steps_dev_stale = int(g.step_count.reshape(-1)[0]), False
         g.max_radii2D, g.grad_accum, g.denom = t["max_radii2D"], t["grad_accum"], t["denom"]
+        g.grad_accum_abs = t["grad_accum_abs"] if "grad_accum_abs" in t else torch.zeros_like(g.grad_accum)
 
     @torch.no_grad()
     def eval_rendering_kf(self):

@@ -371,7 +371,7 @@ class FusedTrainer:
                                                   _p(self.g_depth), _s()), "normal_agree_backward")
             self._backward(v, ps[k], self.g_img, self.g_depth, 0.0, self.gtheta, sums[k], g_normal=g_nrm)
             if iteration < 10000 and densify:
-                check(lib.cut3r_gs_densify_stats(P, _p(self.radii), _p(self.d_means2D), _p(gm.max_radii2D), _p(gm.grad_accum), _p(gm.denom), _s()),
+                check(lib.cut3r_gs_densify_stats(P, _p(self.radii), _p(self.d_means2D), _p(gm.max_radii2D), _p(gm.grad_accum), _p(gm.grad_accum_abs), _p(gm.denom), _s()),
                       "gs_densify_stats")
             gm.steps += 1
             gm._steps_dev_stale = True
@@ -437,7 +437,7 @@ class FusedTrainer:
                 last = self.loss_acc[0] + 0.2 * (1.0 - self.smap.mean())
             self._backward(v, ps[k], self.g_img, self.g_depth, 0.0, self.gtheta, None)
             if iteration > 1000:
-                check(lib.cut3r_gs_densify_stats(P, _p(self.radii), _p(self.d_means2D), _p(gm.max_radii2D), _p(gm.grad_accum), _p(gm.denom), _s()),
+                check(lib.cut3r_gs_densify_stats(P, _p(self.radii), _p(self.d_means2D), _p(gm.max_radii2D), _p(gm.grad_accum), _p(gm.grad_accum_abs), _p(gm.denom), _s()),
                       "gs_densify_stats")
             gm.steps += 1
             gm._steps_dev_stale = True

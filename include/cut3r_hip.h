@@ -439,8 +439,9 @@ int cut3r_normal_agree_backward(const float* normal, const float* depth, int H, 
                                 float* grad_normal, float* grad_depth, void* stream);
 /* densification statistics of one rendered view (hislam2/gaussian/scene/gaussian_model.py:779-790 add_densification_stats and the
  * max_radii2D update of gs_backend_per_frame.py:1021-1027): for visible Gaussians (radii > 0) max_radii2D = max(., radius),
- * grad_accum += |d_means2D.xy|, denom += 1. */
-int cut3r_gs_densify_stats(int P, const int* radii, const float* d_means2D, float* max_radii2D, float* grad_accum, float* denom, void* stream);
+ * grad_accum += |d_means2D.xy|, grad_accum_abs += |d_means2D.z| (the absolute-gradient statistic of the rasteriser's backward, :781), denom += 1. */
+int cut3r_gs_densify_stats(int P, const int* radii, const float* d_means2D, float* max_radii2D, float* grad_accum, float* grad_accum_abs,
+                           float* denom, void* stream);
 /* the pose-refinement loss terms (hislam2/gs_backend_per_frame.py:240-262) in one pass: a = alpha > alpha_th, m = a and both depths >
  * 0.001.  forward: sums[5] = {sum_a |gt - img|, |a|, sum_m diff, sum_m diff^2, |m|}, diff = log d - log gt_d.  backward: coef[3] (device)
  * = {c_rgb, c_var, mean diff} -> grad_img = c_rgb sign(img - gt) on a, grad_depth = 2 c_var (diff - mean) / d on m. */

@@ -630,6 +630,131 @@ def gen_gs_utils_fixture():
     print("wrote gs_utils: ssim", float(val), "| proj[0]", fx["proj"][0].round(4).tolist())
 
 
+class _CudaIsCpu(torch.overrides.TorchFunctionMode):
+    """harness-side device alias for reference code that writes device="cuda" into its tensor factories: inside this mode every `device`
+    argument naming cuda becomes the CPU.  Nothing of the reference's arithmetic is replaced."""
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = dict(kwargs or {})
+        d = kwargs.get("device")
+        if d is not None and "cuda" in str(d):
+            kwargs["device"] = "cpu"
+        return func(*args, **kwargs)
+
+
+def gen_gaussian_model_fixture():
+    """The optimiser and densification book-keeping of the reference's GaussianModel (hislam2/gaussian/scene/gaussian_model.py) ITSELF on
+    the CPU: training_setup (torch.optim.Adam, one group per attribute, eps 1e-15), Adam steps on seeded gradients, update_learning_rate,
+    add_densification_stats (incl. the absolute-gradient statistic), densify_and_prune (clone / split by the gradient OR quantile rule,
+    pruning incl. the < 5e-4 rule) and reset_opacity with their optimiser-state surgery (cat / prune / replace), then more steps.
+    Recorded after every phase: all parameters, both Adam moments and the step count; the standard-normal draws of densify_and_split.
+    Adapters: stub modules for open3d / plyfile / simple_knn / cv2 / matplotlib (import lines only), device="cuda" aliased to the CPU by
+    the TorchFunctionMode above, `.cuda()` as a no-op."""
+    for m in ("open3d", "plyfile", "simple_knn", "simple_knn._C", "cv2", "matplotlib", "matplotlib.cm"):
+        if m not in sys.modules:
+            sys.modules[m] = types.ModuleType(m)
+    sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
+    sys.modules["simple_knn._C"].distCUDA2 = None
+    sys.modules["matplotlib"].cm = sys.modules["matplotlib.cm"]
+    sys.path[:0] = [os.path.join(REF, "hislam2")]
+    from gaussian.scene.gaussian_model import GaussianModel
+    g = torch.Generator().manual_seed(41)
+    P = 240
+    opt = types.SimpleNamespace(position_lr_init=0.0005, position_lr_final=0.000005, position_lr_max_steps=2000, feature_lr=0.005, opacity_lr=0.05,
+                                scaling_lr=0.001, rotation_lr=0.001, percent_dense=0.01)
+    extent, max_grad, min_opacity, size_threshold = 1.0, 0.0005, 0.05, 20
+    init = {"xyz": torch.randn(P, 3, generator=g), "f_dc": torch.randn(P, 1, 3, generator=g) * 0.5, "f_rest": torch.zeros(P, 0, 3),
+            "opacity": torch.randn(P, 1, generator=g) * 1.5 - 0.5,
+            # log scales: a third above percent_dense * extent = 0.01 (split candidates), a few below 5e-4 (pruned as degenerate)
+            "scaling": torch.log(torch.cat([torch.rand(P // 3, 3, generator=g) * 0.03 + 0.012, torch.rand(P - P // 3 - 6, 3, generator=g) * 0.006 + 0.001,
+                                            torch.rand(6, 3, generator=g) * 3e-4 + 1e-4], 0)),
+            "rotation": torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=-1)}
+    fx = {f"init_{k}": v.numpy().copy() for k, v in init.items() if k != "f_rest"}
+    fx.update(opt=np.asarray([opt.position_lr_init, opt.position_lr_final, opt.position_lr_max_steps, opt.feature_lr, opt.opacity_lr, opt.scaling_lr,
+                              opt.rotation_lr, opt.percent_dense, extent, max_grad, min_opacity, size_threshold], np.float64))
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    real_normal = torch.normal
+    draws = []
+
+    def normal_spy(*a, **k):
+        out = real_normal(*a, **k)
+        std = k.get("std", a[1] if len(a) > 1 else None)
+        draws.append((out / std).detach().clone())
+        return out
+    names = ("xyz", "f_dc", "opacity", "scaling", "rotation")
+
+    def snapshot(gm, tag):
+        for grp in gm.optimizer.param_groups:
+            if grp["name"] not in names:
+                continue
+            prm = grp["params"][0]
+            st = gm.optimizer.state.get(prm, {})
+            fx[f"{tag}_{grp['name']}"] = prm.detach().reshape(prm.shape[0], -1).numpy().copy()
+            if st:
+                fx[f"{tag}_{grp['name']}_m"] = st["exp_avg"].reshape(prm.shape[0], -1).numpy().copy()
+                fx[f"{tag}_{grp['name']}_v"] = st["exp_avg_sq"].reshape(prm.shape[0], -1).numpy().copy()
+                fx[f"{tag}_step"] = np.float64(float(st["step"]))
+        fx[f"{tag}_lr_xyz"] = np.float64([grp["lr"] for grp in gm.optimizer.param_groups if grp["name"] == "xyz"][0])
+
+    def step(gm, it, gseed):
+        gg = torch.Generator().manual_seed(gseed)
+        n = gm._xyz.shape[0]
+        grads = {"xyz": torch.randn(n, 3, generator=gg) * 1e-3, "f_dc": torch.randn(n, 1, 3, generator=gg) * 1e-2, "opacity": torch.randn(n, 1, generator=gg) * 1e-2,
+                 "scaling": torch.randn(n, 3, generator=gg) * 1e-3, "rotation": torch.randn(n, 4, generator=gg) * 1e-3}
+        for grp in gm.optimizer.param_groups:
+            prm = grp["params"][0]
+            prm.grad = grads[grp["name"]].clone() if grp["name"] in grads else torch.zeros_like(prm)
+        fx[f"grad_{it}"] = torch.cat([grads[k].reshape(n, -1) for k in names], 1).numpy().copy()
+        # screen-space gradient of one rendered view: (x, y, absolute statistic), visible subset
+        vs = types.SimpleNamespace(grad=torch.cat([torch.randn(n, 2, generator=gg) * 3.2e-4, torch.rand(n, 1, generator=gg) * 2e-3], 1))
+        vis = torch.rand(n, generator=gg) < 0.8
+        fx[f"vs_{it}"], fx[f"vis_{it}"] = vs.grad.numpy().copy(), vis.numpy().copy()
+        gm.max_radii2D[vis] = torch.max(gm.max_radii2D[vis], torch.randint(1, 30, (int(vis.sum()),), generator=gg).float())
+        fx[f"radii_{it}"] = gm.max_radii2D.numpy().copy()
+        gm.add_densification_stats(vs, vis)
+        gm.optimizer.step()
+        gm.optimizer.zero_grad(set_to_none=True)
+        gm.update_learning_rate(it)
+    torch.normal = normal_spy
+    try:
+        with _CudaIsCpu():
+            gm = GaussianModel(sh_degree=0, config=None)
+            gm.init_lr(1.0)
+            # (extend_from_pcd appends through the optimiser, which training_setup creates from existing tensors: set them directly)
+            gm._xyz = torch.nn.Parameter(init["xyz"].clone())
+            gm._features_dc = torch.nn.Parameter(init["f_dc"].clone())
+            gm._features_rest = torch.nn.Parameter(init["f_rest"].clone())
+            gm._opacity = torch.nn.Parameter(init["opacity"].clone())
+            gm._scaling = torch.nn.Parameter(init["scaling"].clone())
+            gm._rotation = torch.nn.Parameter(init["rotation"].clone())
+            gm.max_radii2D = torch.zeros(P)
+            gm.unique_kfIDs, gm.n_obs = torch.zeros(P).int(), torch.zeros(P).int()
+            gm.training_setup(opt)
+            for it in range(4):
+                step(gm, it, 100 + it)
+            snapshot(gm, "a")                                             # after 4 steps
+            gm.densify_and_prune(max_grad, min_opacity, extent, size_threshold)
+            snapshot(gm, "b")                                             # after clone / split / prune
+            fx["n_after_densify"] = np.int64(gm._xyz.shape[0])
+            for it in range(4, 7):
+                step(gm, it, 100 + it)
+            snapshot(gm, "c")
+            gm.reset_opacity()
+            snapshot(gm, "d")
+            step(gm, 7, 107)
+            gm.densify_and_prune(max_grad, min_opacity, extent, None)     # second round without the screen-size rule
+            step(gm, 8, 108)
+            snapshot(gm, "e")
+    finally:
+        torch.Tensor.cuda, torch.normal = real_cuda, real_normal
+    for i, d in enumerate(draws):
+        fx[f"split_draws_{i}"] = d.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "gaussian_model.npz"), **fx)
+    print("wrote gaussian_model: P", P, "->", int(fx["n_after_densify"]), "->", fx["e_xyz"].shape[0], "| split draws", [d.shape[0] for d in draws],
+          "| steps", [float(fx[f"{t}_step"]) for t in "abcde"], "| lr_xyz", [float(fx[f"{t}_lr_xyz"]) for t in "abcde"])
+
+
 def gen_motion_filter_fixture():
     """MotionFilter.kfFilter (hislam2/motion_filter.py:70-135) ITSELF on the CPU over two seeded streams: overlap mode (kf_every = -1,
     skip = 2, thresh = 0.9: a slideshow whose content changes every 4 frames) and fixed cadence (kf_every = 3), both with the
@@ -693,7 +818,7 @@ def gen_motion_filter_fixture():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop", "backend", "chol", "gs_utils"]
+    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop", "backend", "chol", "gs_utils", "gaussian_model"]
     if "motion_filter" in what:
         gen_motion_filter_fixture()
     if "loop" in what:
@@ -704,6 +829,8 @@ if __name__ == "__main__":
         gen_chol_fixture()
     if "gs_utils" in what:
         gen_gs_utils_fixture()
+    if "gaussian_model" in what:
+        gen_gaussian_model_fixture()
     if "frontend" in what:
         gen_frontend_fixture()
     if "nms" in what:

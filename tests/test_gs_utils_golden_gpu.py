@@ -69,3 +69,62 @@ def test_lie_kernels_and_pose_update_equal_the_reference_slam_utils():
     assert float(ps[7:13].abs().max()) == 0.0
     pw = GM.project2world(torch.from_numpy(f["p2w_c2w"]).to(DEV), torch.from_numpy(f["p2w_depth"]).to(DEV), 20.0, 21.0, 7.5, 5.5)
     assert float(np.abs(pw.cpu().numpy() - f["p2w"]).max()) < 5e-6
+
+
+def test_gaussian_map_equals_the_reference_gaussian_model_through_adam_densify_prune_reset():
+    """GaussianMap (one [P,14] block, one fused Adam, row operations) against the reference's GaussianModel + torch.optim.Adam run on the CPU
+    (tests/golden/gaussian_model.npz): 4 Adam steps on seeded gradients with the densification statistics of a rendered view each ->
+    densify_and_prune (gradient OR absolute-gradient-quantile rule, clone / split with the reference's own normal draws replayed, prune incl.
+    the degenerate-scale rule; the screen-size rule is dead after densification_postfix zeroes max_radii2D, as in the reference) -> 3 steps ->
+    reset_opacity -> step -> second densification -> step.  After every phase: every parameter, both Adam moments (zero-padded for new rows,
+    cut for pruned ones, zeroed for the reset opacities), the shared step count and the decayed position learning rate."""
+    from cut3r_slam_amd import gs_mapper as GM
+    f = np.load(os.path.join(GOLD, "gaussian_model.npz"))
+    o = f["opt"]
+    op = {"position_lr_init": o[0], "position_lr_final": o[1], "position_lr_max_steps": int(o[2]), "feature_lr": o[3], "opacity_lr": o[4], "scaling_lr": o[5],
+          "rotation_lr": o[6], "percent_dense": o[7]}
+    extent, max_grad, min_opacity, size_threshold = float(o[8]), float(o[9]), float(o[10]), float(o[11])
+    gm = GM.GaussianMap(op, DEV)
+    t = lambda k: torch.from_numpy(f[k]).to(DEV)
+    P = f["init_xyz"].shape[0]
+    gm._append({"xyz": t("init_xyz"), "f_dc": t("init_f_dc").reshape(P, 3), "opacity": t("init_opacity"), "scaling": t("init_scaling"), "rotation": t("init_rotation")},
+               torch.zeros(P))
+    draws = [t(k) for k in sorted(k for k in f.files if k.startswith("split_draws_"))]
+    gm._split_noise = lambda n: draws.pop(0)
+    worst = {}
+
+    def step(it):
+        gm.theta.grad = t(f"grad_{it}").clone()
+        gm.add_densification_stats(t(f"vs_{it}"), t(f"vis_{it}"))
+        gm.max_radii2D = t(f"radii_{it}").clone()
+        gm.step()
+        gm.zero_grad()
+        gm.lr[0, 0:3] = GM.position_lr(op, it)
+
+    def check(tag):
+        torch.cuda.synchronize()
+        th, m, v = gm.theta.detach().cpu().numpy(), gm.m.cpu().numpy(), gm.v.cpu().numpy()
+        assert th.shape[0] == f[f"{tag}_xyz"].shape[0], (tag, th.shape[0], f[f"{tag}_xyz"].shape[0])
+        for name, (a, b) in GM.GaussianMap.COLS.items():
+            for what, got, key in (("value", th[:, a:b], f"{tag}_{name}"), ("m", m[:, a:b], f"{tag}_{name}_m"), ("v", v[:, a:b], f"{tag}_{name}_v")):
+                ref = f[key]
+                err = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+                worst[what] = max(worst.get(what, 0.0), err)
+                assert err < 5e-6, (tag, name, what, err)
+        assert gm.steps == int(f[f"{tag}_step"]) and abs(float(gm.lr[0, 0]) - float(f[f"{tag}_lr_xyz"])) < 1e-10, (tag, gm.steps, float(gm.lr[0, 0]))
+    for it in range(4):
+        step(it)
+    check("a")
+    gm.densify_and_prune(max_grad, min_opacity, extent, size_threshold)
+    check("b")
+    for it in range(4, 7):
+        step(it)
+    check("c")
+    gm.reset_opacity()
+    check("d")
+    step(7)
+    gm.densify_and_prune(max_grad, min_opacity, extent, None)
+    step(8)
+    check("e")
+    assert not draws
+    print(f"[GaussianMap vs reference GaussianModel] {P} -> {int(f['n_after_densify'])} -> {len(gm)} Gaussians, worst relative errors", {k: f"{v:.1e}" for k, v in worst.items()})
