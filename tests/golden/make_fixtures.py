@@ -279,6 +279,15 @@ def gen_camera_fixture():
     fx = {"enc": enc, "c2w": c2w.numpy(), "R": quaternion_to_matrix(torch.from_numpy(enc[:, 3:])).numpy(),
           "pts": pts.numpy(), "geotrf": geotrf(c2w, pts).numpy(), "pose_vec": vec,
           "pose_vec_c2w": pose_vec_to_matrix(torch.from_numpy(vec)).numpy()}
+    # util.utils.umeyama_alignment (:738-763): a similarity between two point sets, once a proper one and once through a reflection
+    from util.utils import umeyama_alignment
+    src = g.standard_normal((40, 3))
+    from scipy.spatial.transform import Rotation
+    Rt = Rotation.from_euler("xyz", [0.4, -0.7, 1.1]).as_matrix()
+    for name, M in (("proper", Rt), ("reflected", Rt @ np.diag([1.0, 1.0, -1.0]))):
+        dst = 1.7 * src @ M.T + np.array([0.3, -1.2, 2.0]) + 0.01 * g.standard_normal((40, 3))
+        sc, R, t = umeyama_alignment(src, dst)
+        fx.update({f"um_{name}_src": src, f"um_{name}_dst": dst, f"um_{name}_scale": np.float64(sc), f"um_{name}_R": R, f"um_{name}_t": t})
     np.savez_compressed(os.path.join(HERE, "camera.npz"), **fx)
     print("wrote camera", {k: v.shape for k, v in fx.items()})
 

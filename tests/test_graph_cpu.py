@@ -91,3 +91,18 @@ def test_host_pose_helpers_equal_the_reference_fixture():
     np.testing.assert_allclose(gh.pose_vec_to_matrix(f["pose_vec"]), f["pose_vec_c2w"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(SO.pose_encoding_to_camera(torch.from_numpy(f["enc"])).numpy(), f["c2w"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(SO.pose_vec_to_matrix(torch.from_numpy(f["pose_vec"])).numpy(), f["pose_vec_c2w"], rtol=0, atol=1e-6)
+
+
+def test_ate_alignment_equals_the_reference_umeyama():
+    """the Sim(3) alignment behind every ATE number of the bench and the e2e tests (cut3r_slam_amd/eval_ate.umeyama) against the
+    reference's util.utils.umeyama_alignment (:738-763, in camera.npz): a proper similarity and one through a reflection (the det rule)"""
+    import os
+    import numpy as np
+    from cut3r_slam_amd.eval_ate import umeyama
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "camera.npz"))
+    for name in ("proper", "reflected"):
+        s, R, t = umeyama(f[f"um_{name}_src"], f[f"um_{name}_dst"], True)
+        assert abs(s - float(f[f"um_{name}_scale"])) < 1e-12
+        np.testing.assert_allclose(R, f[f"um_{name}_R"], atol=1e-12)
+        np.testing.assert_allclose(t, f[f"um_{name}_t"], atol=1e-12)
+        assert np.linalg.det(R) > 0.999
