@@ -345,6 +345,10 @@ def gen_frontend_fixture():
                 fx[f"submap_ds_{w}"] = kf.submap_ds[t0 // 5].numpy().copy()
                 fx[f"conf_ds_{w}"] = kf.conf_ds[t0 // 5].numpy().copy()
                 fx[f"ii_{w}"], fx[f"jj_{w}"], fx[f"age_{w}"] = graph.ii.numpy().copy(), graph.jj.numpy().copy(), graph.age.numpy().copy()
+            # TrackFrontend.predict (:102-162): a non-keyframe (here: frame 13 of the pan) relocalised against keyframe 9 of the tracked map
+            p_pose, p_depth, p_pm, p_conf = tr.predict(frames[13], kf.image[9], kf.pose[9], kf.depth[9], kf.submap_ds[1, 4])
+            fx.update(predict_pose=p_pose.numpy().copy(), predict_depth=p_depth.numpy().copy(), predict_pointmap=p_pm.numpy().copy(),
+                      predict_conf=p_conf.numpy().copy(), predict_args=np.asarray([13, 9], np.int64))
     finally:
         torch.Tensor.to = real_to
     np.savez_compressed(os.path.join(HERE, "frontend.npz"), **fx)

@@ -49,6 +49,16 @@ def test_oracle_tracker_equals_the_reference_trackfrontend():
         np.testing.assert_array_equal(jj, f[f"jj_{w}"], err_msg=f"jj after window {w}")
     print("[oracle tracker vs reference TrackFrontend.track] worst relative errors:", {k: f"{v:.1e}" for k, v in worst.items()},
           "| edges", [len(f[f"ii_{w}"]) for w in range(3)])
+    # TrackFrontend.predict (:102-162) of the reference on the tracked map: frame 13 against keyframe 9
+    from oracle import cut3r_oracle as O
+    from oracle import slam_oracle as SO
+    new, kfi = f["predict_args"].tolist()
+    preds = O.forward_views(cfg, sd, O.normalize(torch.stack([so.image[kfi], frames[new]], 0)), minimal=True)
+    pose, depth, pm, cf = SO.predict(torch.cat([p["pts3d_in_self_view"] for p in preds], 0), torch.cat([p["conf_self"] for p in preds], 0),
+                                     torch.cat([p["camera_pose"] for p in preds], 0), so.state["pose"][kfi], so.state["depth"][kfi])
+    for name, got in (("pose", pose), ("depth", depth), ("pointmap", pm), ("conf", cf)):
+        ref = f[f"predict_{name}"]
+        assert float(np.abs(got.numpy() - ref).max() / np.abs(ref).max()) < 2e-5, name
     # the fixture exercises the chain: the second and third window start from a non-trivial scale and pose
     assert abs(float(np.log(f["depth_1"][0]).mean())) > 0.1 and float(np.abs(f["pose_2"][0, :3]).max()) > 1e-3
 
