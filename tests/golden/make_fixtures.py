@@ -768,6 +768,105 @@ def gen_gaussian_model_fixture():
           "| steps", [float(fx[f"{t}_step"]) for t in "abcde"], "| lr_xyz", [float(fx[f"{t}_lr_xyz"]) for t in "abcde"])
 
 
+def handover_mapper_update(data):
+    """the deterministic 'mapper' of the hand-over fixture (a test double for the GS backend's interface, shared with the tests): refined
+    poses, depths with a hole, full-resolution pointmaps -- simple functions of the packet it was given"""
+    poses = data["poses"].double().clone()
+    poses[:, :3] += 0.01 * torch.arange(1, poses.shape[0] + 1, dtype=torch.float64, device=poses.device)[:, None]
+    depths = data["depths"].clone() * 1.02
+    depths[:, :8, :8] = 0
+    pm = data["depths"][..., None] * torch.tensor([0.5, -0.25, 1.0], device=depths.device)
+    return {"poses": poses, "depths": depths, "pointmaps": pm}, list(data["viz_idx"])
+
+
+def gen_handover_fixture():
+    """Hi2.run and Hi2.call_gs (hislam2/hi2.py:56-133) THEMSELVES on the CPU with a recording test double in place of the Gaussian mapper:
+    the packet the tracker hands to `mapper.run` after every window (viz_idx, submap_idx, tstamp, poses, images, pointmaps[:n], confs[:n],
+    depths, intrinsics) and what call_gs writes back (poses; the masked depth assignment on an advanced-indexing copy, i.e. nothing;
+    stride-2 pointmaps; the overlap row of the previous submaps).  hi2.py cannot be imported here (its import chain pulls the CUDA
+    rasteriser, the GUI, ...): the two method definitions are compiled from the file's AST into a bare class; KeyFrame / MotionFilter /
+    TrackFrontend are the reference's objects as in the fixtures above."""
+    import ast
+    AR, ARCfg, inference = import_reference_model()
+    import_reference_graph()
+    import motion_filter as MF
+    from keyframe import KeyFrame
+    from track_frontend import TrackFrontend
+    from factor_graph import FactorGraph
+    from torch.multiprocessing import Value
+    from cut3r_slam_amd import synth
+    tree = ast.parse(open(os.path.join(REF, "hislam2", "hi2.py")).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Hi2"][0]
+    fns = {n.name: n for n in cls.body if isinstance(n, ast.FunctionDef)}
+    ns = {"torch": torch, "np": np, "os": os, "viz_pcd": lambda *a, **k: None}
+    exec(compile(ast.Module(body=[fns["call_gs"], fns["run"]], type_ignores=[]), os.path.join(REF, "hislam2", "hi2.py"), "exec"), ns)
+    Hi2 = type("Hi2", (), {"call_gs": ns["call_gs"], "run": ns["run"]})
+    cfg = synth.medium_config()
+    seed = 11
+    sd = synth.tracking_state_dict(cfg, seed)
+    torch.manual_seed(0)
+    model = AR(ref_config(ARCfg, cfg)).eval()
+    torch.nn.Module.load_state_dict(model, sd, strict=True)
+    H, W = cfg.img_size
+    n, buffer, ds = 45, 32, 2
+    frames = synth.pan_stream(n, H, W, pool=5, num=3, den=1, seed=2)
+    kf = object.__new__(KeyFrame)
+    kf.counter, kf.ready, kf.is_initialized, kf.downsample_ratio = Value("i", 0), Value("i", 0), False, ds
+    kf.tstamp = torch.zeros(buffer)
+    kf.image = torch.zeros(buffer, 3, H, W, dtype=torch.uint8)
+    kf.intrinsic, kf.pose, kf.depth = torch.zeros(buffer, 4), torch.zeros(buffer, 7), torch.ones(buffer, H, W)
+    kf.pose[:] = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0])
+    kf.submap_ds = torch.ones(buffer // 5, 6, H // ds, W // ds, 3)
+    kf.conf_ds = torch.zeros(buffer // 5, 6, H // ds, W // ds)
+    kf.featI = torch.zeros(buffer, (H // 16) * (W // 16), cfg.enc_embed_dim)
+    kf.pos = torch.zeros(buffer, (H // 16) * (W // 16), 2, dtype=torch.int64)
+    graph = FactorGraph(kf, device="cpu", max_factors=48)
+    tr = object.__new__(TrackFrontend)
+    tr.device, tr.keyframes, tr.model, tr.graph = "cpu", kf, model, graph
+    tr.verbose, tr.output_dir, tr.use_gt, tr.conf_th, tr.downsample_ratio, tr.t1, tr.warmup = False, None, False, 0.5, ds, 0, 6
+    packets = []
+
+    class Recorder:
+        def run(self, data, iterations):
+            packets.append({k: (v.clone() if torch.is_tensor(v) else (list(v) if isinstance(v, range) else v)) for k, v in data.items()})
+            packets[-1]["iterations"] = iterations
+            return handover_mapper_update(data)
+    slam = Hi2()
+    slam.images, slam.keyframes, slam.tracker, slam.backend, slam.do_lc, slam.freeze_counter = {}, kf, tr, None, False, 0
+    slam.filterx = MF.MotionFilter(model, kf, {"thresh": 0.9, "skip": 1, "kf_every": 2, "skip_blur": False}, device="cpu")
+    slam.mapper, slam.gs_iter_num, slam.verbose, slam.downsample_ratio, slam.output_dir = Recorder(), 7, False, ds, None
+    real_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
+        return real_to(self, *a, **k)
+    intr = torch.tensor([[80.0, 80.0, 47.5, 31.5]])
+    fx = {"seed": np.int64(seed), "frames_sum": np.int64(int(frames.long().sum())), "intrinsic": intr[0].numpy()}
+    torch.Tensor.to = to_cpu
+    try:
+        for t in range(n):
+            before = len(packets)
+            slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr[0], second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+            if len(packets) != before:
+                k = len(packets) - 1
+                pk = packets[-1]
+                viz, sub = list(pk["viz_idx"]), int(pk["submap_idx"])
+                fx.update({f"pk{k}_frame": np.int64(t), f"pk{k}_viz_idx": np.asarray(viz, np.int64), f"pk{k}_submap_idx": np.int64(sub), f"pk{k}_iterations": np.int64(pk["iterations"]),
+                           f"pk{k}_tstamp": pk["tstamp"].numpy(), f"pk{k}_poses": pk["poses"].numpy(), f"pk{k}_pointmaps_mean": pk["pointmaps"].double().mean(dim=(1, 2)).numpy(),
+                           f"pk{k}_confs_mean": pk["confs"].double().mean(dim=(1, 2)).numpy(), f"pk{k}_depths_mean": pk["depths"].mean(dim=(1, 2)).numpy(), f"pk{k}_intrinsics": pk["intrinsics"].numpy(),
+                           f"pk{k}_images_shape": np.asarray(pk["images"].shape, np.int64), f"pk{k}_images_sum": np.int64(int(pk["images"].long().sum())),
+                           f"pk{k}_pose_after": kf.pose[viz].numpy().copy(), f"pk{k}_depth_after_mean": kf.depth[viz].mean(dim=(1, 2)).numpy().copy(),
+                           f"pk{k}_depth_after_corner": kf.depth[viz][:, :8, :8].mean(dim=(1, 2)).numpy().copy(),
+                           f"pk{k}_submaps_after_mean": kf.submap_ds[max(0, sub - 1):sub + 2].double().mean(dim=(2, 3)).numpy().copy()})        # the rows call_gs can touch: this submap, the overlap row of the one before, the next
+    finally:
+        torch.Tensor.to = real_to
+    fx["n_packets"] = np.int64(len(packets))
+    fx["keys"] = np.frombuffer(",".join(sorted(k for k in packets[0] if k != "iterations")).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "handover.npz"), **fx)
+    print("wrote handover:", len(packets), "packets at frames", [int(fx[f"pk{k}_frame"]) for k in range(len(packets))], "| viz_idx", [fx[f"pk{k}_viz_idx"].tolist() for k in range(len(packets))],
+          "| packet keys", bytes(fx["keys"]).decode(), "| depth corner after write-back (0 would mean the masked write took effect)", fx["pk0_depth_after_corner"].round(3).tolist())
+
+
 def gen_motion_filter_fixture():
     """MotionFilter.kfFilter (hislam2/motion_filter.py:70-135) ITSELF on the CPU over two seeded streams: overlap mode (kf_every = -1,
     skip = 2, thresh = 0.9: a slideshow whose content changes every 4 frames) and fixed cadence (kf_every = 3), both with the
@@ -831,7 +930,7 @@ def gen_motion_filter_fixture():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop", "backend", "chol", "gs_utils", "gaussian_model"]
+    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop", "backend", "chol", "gs_utils", "gaussian_model", "handover"]
     if "motion_filter" in what:
         gen_motion_filter_fixture()
     if "loop" in what:
@@ -844,6 +943,8 @@ if __name__ == "__main__":
         gen_gs_utils_fixture()
     if "gaussian_model" in what:
         gen_gaussian_model_fixture()
+    if "handover" in what:
+        gen_handover_fixture()
     if "frontend" in what:
         gen_frontend_fixture()
     if "nms" in what:
