@@ -672,6 +672,7 @@ def gen_gaussian_model_fixture():
     sys.path[:0] = [os.path.join(REF, "hislam2")]
     from gaussian.scene.gaussian_model import GaussianModel
     g = torch.Generator().manual_seed(41)
+    torch.manual_seed(43)                      # the global generator feeds densify_and_split's torch.normal
     P = 240
     opt = types.SimpleNamespace(position_lr_init=0.0005, position_lr_final=0.000005, position_lr_max_steps=2000, feature_lr=0.005, opacity_lr=0.05,
                                 scaling_lr=0.001, rotation_lr=0.001, percent_dense=0.01)
