@@ -868,6 +868,94 @@ def gen_handover_fixture():
           "| packet keys", bytes(fx["keys"]).decode(), "| depth corner after write-back (0 would mean the masked write took effect)", fx["pk0_depth_after_corner"].round(3).tolist())
 
 
+def gen_terminate_fixture():
+    """Hi2.terminate(add_kf=True) (hislam2/hi2.py:152-229) ITSELF on the CPU after the reference loop ran over a stream whose keyframes lie
+    32 frames apart: which in-between frames it relocalises (interval rule :186-196), the TrackFrontend.predict call on each, what it
+    hands to `mapper.add_new_view`, and the write-back of `mapper.finalize()`'s poses.  `mapper` is a recording test double; hi2.py's
+    methods are compiled from its AST as in gen_handover_fixture; `F` of its namespace is torch.nn.functional."""
+    import ast
+    AR, ARCfg, inference = import_reference_model()
+    import_reference_graph()
+    import motion_filter as MF
+    from keyframe import KeyFrame
+    from track_frontend import TrackFrontend
+    from factor_graph import FactorGraph
+    from torch.multiprocessing import Value
+    from cut3r_slam_amd import synth
+    tree = ast.parse(open(os.path.join(REF, "hislam2", "hi2.py")).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Hi2"][0]
+    fns = {n.name: n for n in cls.body if isinstance(n, ast.FunctionDef)}
+    ns = {"torch": torch, "np": np, "os": os, "F": torch.nn.functional, "viz_pcd": lambda *a, **k: None}
+    exec(compile(ast.Module(body=[fns["call_gs"], fns["run"], fns["terminate"]], type_ignores=[]), os.path.join(REF, "hislam2", "hi2.py"), "exec"), ns)
+    Hi2 = type("Hi2", (), {"call_gs": ns["call_gs"], "run": ns["run"], "terminate": ns["terminate"]})
+    cfg = synth.medium_config()
+    seed = 11
+    sd = synth.tracking_state_dict(cfg, seed)
+    torch.manual_seed(0)
+    model = AR(ref_config(ARCfg, cfg)).eval()
+    torch.nn.Module.load_state_dict(model, sd, strict=True)
+    H, W = cfg.img_size
+    n, buffer, ds = 262, 16, 2
+    frames = synth.pan_stream(n, H, W, pool=5, num=1, den=2, seed=6)
+    kf = object.__new__(KeyFrame)
+    kf.counter, kf.ready, kf.is_initialized, kf.downsample_ratio = Value("i", 0), Value("i", 0), False, ds
+    kf.tstamp = torch.zeros(buffer)
+    kf.image = torch.zeros(buffer, 3, H, W, dtype=torch.uint8)
+    kf.intrinsic, kf.pose, kf.depth = torch.zeros(buffer, 4), torch.zeros(buffer, 7), torch.ones(buffer, H, W)
+    kf.pose[:] = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0])
+    kf.submap_ds = torch.ones(buffer // 5, 6, H // ds, W // ds, 3)
+    kf.conf_ds = torch.zeros(buffer // 5, 6, H // ds, W // ds)
+    kf.featI = torch.zeros(buffer, (H // 16) * (W // 16), cfg.enc_embed_dim)
+    kf.pos = torch.zeros(buffer, (H // 16) * (W // 16), 2, dtype=torch.int64)
+    graph = FactorGraph(kf, device="cpu", max_factors=48)
+    tr = object.__new__(TrackFrontend)
+    tr.device, tr.keyframes, tr.model, tr.graph = "cpu", kf, model, graph
+    tr.verbose, tr.output_dir, tr.use_gt, tr.conf_th, tr.downsample_ratio, tr.t1, tr.warmup = False, None, False, 0.5, ds, 0, 6
+    added = []
+
+    class Recorder:
+        def run(self, data, iterations):
+            return {"poses": data["poses"].double(), "depths": data["depths"], "pointmaps": torch.zeros(len(list(data["viz_idx"])), H, W, 3)
+                    + data["depths"][..., None] * torch.tensor([0.5, -0.25, 1.0])}, list(data["viz_idx"])
+
+        def add_new_view(self, new_img, new_pose, new_depth, new_pointmap, new_conf, new_kf_tstamp, kf_sub_idx):
+            added.append({"img_shape": tuple(new_img.shape), "img_sum": int(new_img.long().sum()), "pose": new_pose.clone(), "depth": new_depth.clone(),
+                          "pointmap": new_pointmap.clone(), "conf": new_conf.clone(), "tstamp": int(new_kf_tstamp), "sub": int(kf_sub_idx)})
+
+        def finalize(self):
+            p = kf.pose[:kf.counter.value].double().numpy().copy()
+            p[:, :3] += 0.005 * np.arange(1, p.shape[0] + 1)[:, None]
+            return p
+    slam = Hi2()
+    slam.images, slam.keyframes, slam.tracker, slam.backend, slam.do_lc, slam.freeze_counter = {}, kf, tr, None, False, 0
+    slam.filterx = MF.MotionFilter(model, kf, {"thresh": 0.9, "skip": 1, "kf_every": 32, "skip_blur": False}, device="cpu")
+    slam.mapper, slam.gs_iter_num, slam.verbose, slam.downsample_ratio, slam.output_dir = Recorder(), 1, False, ds, None
+    real_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
+        return real_to(self, *a, **k)
+    intr = torch.tensor([[80.0, 80.0, 47.5, 31.5]])
+    torch.Tensor.to = to_cpu
+    try:
+        for t in range(n):
+            slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr[0], second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+        with torch.no_grad():
+            traj = slam.terminate(n - 1, fill=False, eval_render=False, gaussian_retrain=False, add_kf=True)
+    finally:
+        torch.Tensor.to = real_to
+    k = kf.counter.value
+    fx = {"seed": np.int64(seed), "frames_sum": np.int64(int(frames.long().sum())), "intrinsic": intr[0].numpy(), "keyframes": kf.tstamp[:k].numpy().astype(np.int64),
+          "tracked": np.int64(tr.t1), "added_tstamp": np.asarray([a["tstamp"] for a in added], np.int64), "added_sub": np.asarray([a["sub"] for a in added], np.int64),
+          "added_img_sum": np.asarray([a["img_sum"] for a in added], np.int64), "added_img_shape": np.asarray([a["img_shape"] for a in added], np.int64),
+          "added_pose": torch.cat([a["pose"] for a in added]).numpy(), "added_depth_mean": np.asarray([float(a["depth"].mean()) for a in added]),
+          "added_pointmap_mean": torch.stack([a["pointmap"][0].double().mean(dim=(0, 1)) for a in added]).numpy(),
+          "added_conf_mean": np.asarray([float(a["conf"].mean()) for a in added]), "traj": np.asarray(traj, np.float64)[:k]}
+    np.savez_compressed(os.path.join(HERE, "terminate.npz"), **fx)
+    print("wrote terminate: keyframes", fx["keyframes"].tolist(), "tracked", int(tr.t1), "| extra views at", fx["added_tstamp"].tolist(), "submaps", fx["added_sub"].tolist(),
+          "| image handed over", fx["added_img_shape"][0].tolist())
+
+
 def gen_motion_filter_fixture():
     """MotionFilter.kfFilter (hislam2/motion_filter.py:70-135) ITSELF on the CPU over two seeded streams: overlap mode (kf_every = -1,
     skip = 2, thresh = 0.9: a slideshow whose content changes every 4 frames) and fixed cadence (kf_every = 3), both with the
@@ -931,7 +1019,7 @@ def gen_motion_filter_fixture():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop", "backend", "chol", "gs_utils", "gaussian_model", "handover"]
+    what = sys.argv[1:] or ["rope", "graph", "dpt", "linear", "medium", "nms", "camera", "frontend", "motion_filter", "loop", "backend", "chol", "gs_utils", "gaussian_model", "handover", "terminate"]
     if "motion_filter" in what:
         gen_motion_filter_fixture()
     if "loop" in what:
@@ -946,6 +1034,8 @@ if __name__ == "__main__":
         gen_gaussian_model_fixture()
     if "handover" in what:
         gen_handover_fixture()
+    if "terminate" in what:
+        gen_terminate_fixture()
     if "frontend" in what:
         gen_frontend_fixture()
     if "nms" in what:
