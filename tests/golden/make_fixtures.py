@@ -14,7 +14,20 @@ What is pinned here:
   * graph.npz    : reference FactorGraph.add / add_neighborhood_factors / cal_overlap_batch / cal_overlap_bi and
     util.utils.compute_patch_overlap_ratio / pose_vec_to_matrix on seeded synthetic poses + pointmaps.
 
+  * motion_filter.npz / frontend.npz / loop.npz / backend.npz / handover.npz / terminate.npz : the reference's OWN MotionFilter.kfFilter,
+    TrackFrontend.track / run / predict, TrackBackend.run (up to its optimiser call, which needs the absent lietorch), Hi2.run / call_gs /
+    terminate (with a recording test double as Gaussian mapper) on seeded streams with the medium network: keyframe decisions, window
+    schedule, stores, edge lists, loop candidates / NMS choice / re-tracked submap, hand-over packets and write-backs.
+  * chol.npz : geom/chol.py block_solve / schur_solve / schur_solve_mono_prior.
+  * gs_utils.npz / gaussian_model.npz : the pure-torch pieces of the GS backend (SSIM + gradient, projection matrix, se(3) exp, pose update,
+    lr schedule) and GaussianModel + torch.optim.Adam through Adam steps, densify_and_prune, reset_opacity.
+  * camera.npz also holds util.utils.umeyama_alignment (the ATE alignment).
+
 Harness-side adapters (nothing in the reference is modified):
+  * reference objects whose constructors allocate on "cuda" (KeyFrame, TrackFrontend, TrackBackend) are created without __init__ and given
+    the attributes their methods read; `.to('cuda')` / `.cuda()` are redirected to the CPU for the duration of the calls; for GaussianModel,
+    whose tensor factories name device="cuda", a TorchFunctionMode aliases that device to the CPU; hi2.py's methods are compiled from its
+    AST (importing the file would pull the CUDA rasteriser and the GUI).  Stub modules serve import lines only -- none of them is called.
   * `curope` is pre-registered in sys.modules as the reference's own CPU op (oracle/_ref/curope.so) so the
     reference never tries its bundled CUDA binaries; half tensors (encoder q,k, croco/models/blocks.py:125-126)
     go through that fp32 CPU op via an up/down cast, which is exactly the CUDA kernel's contract
