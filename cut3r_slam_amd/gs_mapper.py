@@ -172,13 +172,23 @@ class GaussianMap:
         transparent (opacity < min_opacity), the oversized in the world (> 0.1 extent, only with `max_screen_size`) and the degenerate
         (largest scale < 5e-4, :767-768) are pruned.  densification_postfix (:629-633) zeroes the statistics INCLUDING max_radii2D before the
         prune mask is formed, so the reference's screen-size rule never fires after a densification: reproduced."""
+        if len(self) == 0:
+            return
         grads = self.grad_accum / self.denom
         grads[grads.isnan()] = 0.0
         grads_abs = self.grad_accum_abs / self.denom
         grads_abs[grads_abs.isnan()] = 0.0
         hot = grads[:, 0] >= max_grad
         ratio = hot.float().mean()
-        Q = torch.quantile(grads_abs.reshape(-1), 1 - ratio)
+        flat = grads_abs.reshape(-1)
+        if flat.numel() <= (1 << 24):
+            Q = torch.quantile(flat, 1 - ratio)
+        else:                                   # torch.quantile refuses more than 2^24 elements: the same linear interpolation on a sort
+            srt = torch.sort(flat).values
+            pos = (1 - ratio) * (flat.numel() - 1)
+            lo = pos.floor().long().clamp(0, flat.numel() - 1)
+            hi = pos.ceil().long().clamp(0, flat.numel() - 1)
+            Q = srt[lo] + (srt[hi] - srt[lo]) * (pos - lo.float())
         hot = hot | (grads_abs[:, 0] >= Q)
         big = self.get_scaling.detach().max(dim=1).values > self.percent_dense * extent
         clone, split = hot & ~big, hot & big
