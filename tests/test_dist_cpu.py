@@ -1,9 +1,10 @@
-"""CPU, world_size 2, gloo: the window-sharded tracking driver (cut3r_slam_amd/dist.py) -- window assignment, the
+"""CPU, world_size 2 and 4, gloo: the window-sharded tracking driver (cut3r_slam_amd/dist.py) -- window assignment, the
 all-gather exchange and the replicated in-order replay.  The network and the HIP chaining are replaced by fakes here
 (this file runs without a GPU); the GPU path uses the same driver with backend "nccl" (RCCL)."""
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -150,3 +151,33 @@ def test_memory_plan_of_the_drivers_8_gpu_job_fits_one_mi355x():
     per_kf = (memory_plan(8, 26, 28)["total"] - memory_plan(8, 25, 28)["total"]) / (5 * 28 * 8)
     assert 2.2e6 < per_kf < 2.5e6, per_kf                      # image 0.59 + depth 0.79 + 6/5 x (stride-2 pointmap 0.59 + confidence 0.20) MB
     assert not memory_plan(world=8, steps=120, wb=28, workspace_bytes=60 * 10**9)["fits"]      # (the bound is real: ~95 steps at N = 8)
+
+
+def test_sharded_tracker_world4_window_batch2():
+    """four gloo ranks (the driver's scaling bench launches N = 2, 4, 8): every rank replays ALL windows in sequence order with the owning
+    rank's network outputs, rank r owns the r-th block of wb consecutive windows of every step, every keyframe is registered on every rank
+    and its pixels are kept by its owner(s) only, the count exchange returns every owner's rows."""
+    world, wb, port = 4, 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, wb)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    trk = res[0][2]
+    nwin = 2 * world * wb                                            # two steps
+    want = [(5 + 5 * j, 11 + 5 * j) for j in range(nwin)]
+    owners = [float((j // wb) % world) for j in range(nwin)]
+    for r, app, tracked, t, t1, lag, nb in res:
+        assert tracked == trk and t == 61 + 2 * world * wb * 50 and t1 == want[-1][1]
+        assert [(k, ts) for k, ts, _ in app] == [(7 + i, 70 + 10 * i) for i in range(5 * nwin)]
+        assert lag == [0, 0] and nb == world * wb
+    assert [(a, b) for a, b, _, _ in trk] == want and [o for *_, o in trk] == owners
+    assert [v for _, _, v, _ in trk] == [a + 100 * o for (a, _), o in zip(want, owners)]
+    # every keyframe's pixels live on one rank, the shared keyframes of neighbouring blocks on two
+    mine = np.asarray([[m for _, _, m in app] for _, app, *_ in res])
+    per_kf = mine.sum(0)
+    assert per_kf.min() >= 1 and per_kf.max() <= 2 and int((per_kf == 2).sum()) == 2 * world
