@@ -59,6 +59,28 @@ def test_two_ranks_on_one_gpu_match_each_other_and_a_single_rank(tmp_path):
         np.testing.assert_array_equal(r0[key], c[key], err_msg="scan, one rank: " + key)
 
 
+def test_four_ranks_on_one_gpu_match_each_other_and_a_single_rank(tmp_path):
+    """the driver's scaling bench also launches N = 4 and 8: four gloo ranks sharing GPU 0 (window batch 1 each) against one rank with
+    window batch 4 -- the same windows per step; replicated state bit-identical across the four ranks, equal to the single-rank run"""
+    common = ["--small", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--sequence-windows", "6"]
+    four = str(tmp_path / "four")
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "4", "--window-batch", "1"] + common,
+               {"CUT3R_DIST_BACKEND": "gloo", "CUT3R_DUMP_STATE": four, "CUT3R_REPLICATE_DEPTH": "1"})
+    assert '"n_gpus": 4' in out
+    one = str(tmp_path / "one")
+    _run([sys.executable, "bench.py", "--window-batch", "4"] + common, {"CUT3R_DUMP_STATE": one})
+    rs, s = [np.load(f"{four}.rank{r}.npz") for r in range(4)], np.load(one + ".rank0.npz")
+    assert all(int(r["k"]) == int(s["k"]) == 6 + 5 * 4 * 3 for r in rs)
+    for r in rs[1:]:
+        for key in ("pose", "w2c", "depth_sum", "submap_sum", "ii", "jj"):
+            np.testing.assert_array_equal(rs[0][key], r[key], err_msg=key)
+    np.testing.assert_array_equal(rs[0]["ii"], s["ii"])
+    np.testing.assert_array_equal(rs[0]["jj"], s["jj"])
+    np.testing.assert_allclose(rs[0]["pose"], s["pose"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rs[0]["depth_sum"], s["depth_sum"], rtol=1e-4)
+
+
 def test_edge_sharded_ba_two_ranks_gloo():
     """BASELINE north_star: per-edge BA sharded over GPUs with an all-reduce of the normal-equation blocks -- two ranks (sharing
     GPU 0, gloo) each assemble the source frames they own; the summed reduced system gives the single-rank step."""
