@@ -153,11 +153,15 @@ def test_memory_plan_of_the_drivers_8_gpu_job_fits_one_mi355x():
     assert not memory_plan(world=8, steps=120, wb=28, workspace_bytes=60 * 10**9)["fits"]      # (the bound is real: ~95 steps at N = 8)
 
 
-def test_sharded_tracker_world4_window_batch2():
-    """four gloo ranks (the driver's scaling bench launches N = 2, 4, 8): every rank replays ALL windows in sequence order with the owning
-    rank's network outputs, rank r owns the r-th block of wb consecutive windows of every step, every keyframe is registered on every rank
-    and its pixels are kept by its owner(s) only, the count exchange returns every owner's rows."""
-    world, wb, port = 4, 2, _free_port()
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_sharded_tracker_more_ranks_window_batch2(world):
+    """four and eight gloo ranks (the driver's scaling bench launches N = 2, 4, 8): every rank replays ALL windows in sequence order with
+    the owning rank's network outputs, rank r owns the r-th block of wb consecutive windows of every step, every keyframe is registered on
+    every rank and its pixels are kept by its owner(s) only, the count exchange returns every owner's rows."""
+    wb, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, wb)) for r in range(world)]
