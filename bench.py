@@ -701,6 +701,10 @@ def main():
                     roofline["sustained_mfma"] = dict(mp, note="bare MFMA loop of this device (no LDS, no memory traffic), N(0,1) vs all-zero fp16 operands: "
                                                                 "the 2.5 PFLOP/s `peak` assumes 2.4 GHz, which the chip does not hold while its operands toggle",
                                                       frac_of_sustained=round(ach / sus, 4) if sus > 0 else None)
+                    if sus > 0:
+                        for e in others:                        # the same ratio for the other MFMA kernels of the table
+                            if e.get("bound") == "mfma" and e.get("achieved") is not None:
+                                e["frac_of_sustained"] = round(e["achieved"] / sus, 4)
                 except Exception as ex:      # a measurement aid: never fails the bench line
                     roofline["sustained_mfma"] = {"error": str(ex)}
     if single and not args.small and not args.no_operating_points:
