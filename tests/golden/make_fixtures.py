@@ -969,6 +969,74 @@ def gen_terminate_fixture():
           "| image handed over", fx["added_img_shape"][0].tolist())
 
 
+def gen_loop_production_fixture():
+    """The same per-frame loop (kfFilter + TrackFrontend.run of the reference, hi2.py:101-111) AT PRODUCTION SHAPE: the reference's own
+    ViT-L / 768-d dual decoder / DPT model (cut3r_slam_amd.config.production_config, seeded weights) on 384x512 frames, 33 frames at
+    kf_every = 2 -> 18 keyframes, three six-view windows and the closing window -- the stream of tests/test_e2e_production_gpu.py.
+    Takes a few minutes of CPU: NOT in the default list, run `python tests/golden/make_fixtures.py loop_production`.  Stored: keyframes, window calls, final poses, edge list, and strided samples of the depths and submaps."""
+    AR, ARCfg, inference = import_reference_model()
+    import_reference_graph()
+    import motion_filter as MF
+    from keyframe import KeyFrame
+    from track_frontend import TrackFrontend
+    from factor_graph import FactorGraph
+    from torch.multiprocessing import Value
+    from cut3r_slam_amd import synth
+    from cut3r_slam_amd.config import production_config
+    cfg = production_config()
+    sd = synth.tracking_state_dict(cfg, 0, enc_residual_gain=0.1)
+    torch.manual_seed(0)
+    model = AR(ref_config(ARCfg, cfg)).eval()
+    print("production: load_state_dict:", torch.nn.Module.load_state_dict(model, sd, strict=True))
+    H, W = 384, 512
+    n, buffer, ds = 33, 40, 2
+    frames = synth.pan_stream(n, H, W, pool=9, num=6, den=1, seed=0)
+    intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])
+    kf = object.__new__(KeyFrame)
+    kf.counter, kf.ready, kf.is_initialized, kf.downsample_ratio = Value("i", 0), Value("i", 0), False, ds
+    kf.tstamp = torch.zeros(buffer)
+    kf.image = torch.zeros(buffer, 3, H, W, dtype=torch.uint8)
+    kf.intrinsic, kf.pose, kf.depth = torch.zeros(buffer, 4), torch.zeros(buffer, 7), torch.ones(buffer, H, W)
+    kf.pose[:] = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0])
+    kf.submap_ds = torch.ones(buffer // 5, 6, H // ds, W // ds, 3)
+    kf.conf_ds = torch.zeros(buffer // 5, 6, H // ds, W // ds)
+    kf.featI = torch.zeros(buffer, (H // 16) * (W // 16), cfg.enc_embed_dim)
+    kf.pos = torch.zeros(buffer, (H // 16) * (W // 16), 2, dtype=torch.int64)
+    filt = MF.MotionFilter(model, kf, {"thresh": 0.9, "skip": 1, "kf_every": 2, "skip_blur": False}, device="cpu")
+    graph = FactorGraph(kf, device="cpu", max_factors=48)
+    tr = object.__new__(TrackFrontend)
+    tr.device, tr.keyframes, tr.model, tr.graph = "cpu", kf, model, graph
+    tr.verbose, tr.output_dir, tr.use_gt, tr.conf_th, tr.downsample_ratio, tr.t1, tr.warmup = False, None, False, 0.5, ds, 0, 6
+    real_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
+        return real_to(self, *a, **k)
+    calls = []
+    torch.Tensor.to = to_cpu
+    import time
+    t_start = time.time()
+    try:
+        with torch.no_grad():
+            for t in range(n):
+                filt.kfFilter(t, frames[t:t + 1], intrinsics=intr, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+                flag, rng, sub = tr.run(t, last_frame=(t == n - 1))
+                if rng is not None:
+                    calls.append([t, int(bool(flag)), rng.start, rng.stop, int(sub)])
+                    print(f"  window {calls[-1]} after {time.time() - t_start:.0f} s", flush=True)
+    finally:
+        torch.Tensor.to = real_to
+    k, t1 = kf.counter.value, tr.t1
+    nsub = (t1 - 1) // 5 + 1
+    fx = {"frames_sum": np.int64(int(frames.long().sum())), "intrinsic": intr.numpy(), "calls": np.asarray(calls, np.int64),
+          "keyframes": kf.tstamp[:k].numpy().astype(np.int64), "t1": np.int64(t1), "pose": kf.pose[:t1].numpy().copy(),
+          "depth_samples": kf.depth[:t1, 8::24, 8::32].numpy().copy(), "depth_mean": kf.depth[:t1].double().mean(dim=(1, 2)).numpy(),
+          "submap_samples": kf.submap_ds[:nsub, :, 4::12, 4::16].numpy().copy(), "conf_mean": kf.conf_ds[:nsub].double().mean(dim=(2, 3)).numpy(),
+          "ii": graph.ii.numpy().copy(), "jj": graph.jj.numpy().copy()}
+    np.savez_compressed(os.path.join(HERE, "loop_production.npz"), **fx)
+    print("wrote loop_production: keyframes", k, "tracked", t1, "calls", calls, "| edges", len(fx["ii"]), f"| {time.time() - t_start:.0f} s")
+
+
 def gen_motion_filter_fixture():
     """MotionFilter.kfFilter (hislam2/motion_filter.py:70-135) ITSELF on the CPU over two seeded streams: overlap mode (kf_every = -1,
     skip = 2, thresh = 0.9: a slideshow whose content changes every 4 frames) and fixed cadence (kf_every = 3), both with the
@@ -1049,6 +1117,8 @@ if __name__ == "__main__":
         gen_handover_fixture()
     if "terminate" in what:
         gen_terminate_fixture()
+    if "loop_production" in what:
+        gen_loop_production_fixture()
     if "frontend" in what:
         gen_frontend_fixture()
     if "nms" in what:
