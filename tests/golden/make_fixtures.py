@@ -435,7 +435,7 @@ def gen_loop_fixture():
     print("wrote loop: keyframes", k, "tracked", t1, "calls (frame, run_backend, t0, t1, submap):", calls, "| edges", len(fx["ii"]))
 
 
-def gen_backend_fixture():
+def gen_backend_fixture(production=False):
     """TrackBackend.run (hislam2/track_backend.py:527-586) ITSELF on the CPU up to its optimiser call: the per-frame loop of Hi2.run
     (hi2.py:101-121: kfFilter, TrackFrontend.run, every other eligible window the backend) over a seeded stream with weights for which
     the loop detector fires (synth.loop_state_dict); at the first backend call the reference's own detect_loop scan, FactorGraph.NMS
@@ -460,13 +460,16 @@ def gen_backend_fixture():
     from cut3r_slam_amd import synth
     cfg = synth.medium_config()
     seed = 11
-    sd = synth.loop_state_dict(cfg, seed)
+    n, buffer, ds = 90, 64, 2
+    if production:                       # (`backend_production`: the same at 384x512 with the ViT-L / DPT network; minutes of CPU, on request)
+        from cut3r_slam_amd.config import production_config
+        cfg, seed, n, buffer = production_config(), 0, 40, 24
+    sd = synth.loop_state_dict(cfg, seed, enc_residual_gain=0.1) if production else synth.loop_state_dict(cfg, seed)
     torch.manual_seed(0)
     model = AR(ref_config(ARCfg, cfg)).eval()
     torch.nn.Module.load_state_dict(model, sd, strict=True)
-    H, W = cfg.img_size
-    n, buffer, ds = 90, 64, 2
-    frames = synth.pan_stream(n, H, W, pool=5, num=2, den=1, seed=0)
+    H, W = (384, 512) if production else cfg.img_size
+    frames = synth.pan_stream(n, H, W, pool=9, num=6, den=1, seed=0) if production else synth.pan_stream(n, H, W, pool=5, num=2, den=1, seed=0)
     kf = object.__new__(KeyFrame)
     kf.counter, kf.ready, kf.is_initialized, kf.downsample_ratio = Value("i", 0), Value("i", 0), False, ds
     kf.tstamp = torch.zeros(buffer)
@@ -514,7 +517,7 @@ def gen_backend_fixture():
     def to_cpu(self, *a, **k):
         a = tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
         return real_to(self, *a, **k)
-    intr = torch.tensor([80.0, 80.0, 47.5, 31.5])
+    intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0]) if production else torch.tensor([80.0, 80.0, 47.5, 31.5])
     torch.Tensor.to, torch.Tensor.cuda = to_cpu, (lambda self, *a, **k: self)
     fired_at, freeze, windows = None, 0, []
     try:
@@ -546,7 +549,10 @@ def gen_backend_fixture():
           "anchor_sub_num": np.int64(rec["anchor_sub_num"]), "pointmaps_lc": rec["pointmaps_lc"].numpy(), "confs_lc": rec["confs_lc"].numpy(),
           "poses_lc": rec["poses_lc"].numpy(), "pointmap_current_lc": rec["pointmap_current_lc"].numpy(),
           "pose_before": kf.pose[:t1].numpy().copy(), "ii": graph.ii.numpy().copy(), "jj": graph.jj.numpy().copy()}
-    np.savez_compressed(os.path.join(HERE, "backend.npz"), **fx)
+    if production:                       # strided samples instead of the full re-tracked submap
+        fx["pointmaps_lc"], fx["confs_lc"] = fx["pointmaps_lc"][:, 4::12, 4::16].copy(), fx["confs_lc"][:, 4::12, 4::16].copy()
+        fx["pointmap_current_lc"] = fx["pointmap_current_lc"][:, 4::12, 4::16].copy()
+    np.savez_compressed(os.path.join(HERE, "backend_production.npz" if production else "backend.npz"), **fx)
     print("wrote backend: fired at frame", fired_at, "keyframes", k, "| scan", fx["scan_idx"].tolist(), "candidates", fx["candidates"].tolist(), "k_th", int(fx["k_th"]),
           "-> matched", int(fx["idx_matched"]), "current", int(fx["idx_current"]), "| selected", fx["selected_idx"].tolist())
 
@@ -1119,6 +1125,8 @@ if __name__ == "__main__":
         gen_terminate_fixture()
     if "loop_production" in what:
         gen_loop_production_fixture()
+    if "backend_production" in what:
+        gen_backend_fixture(production=True)
     if "frontend" in what:
         gen_frontend_fixture()
     if "nms" in what:

@@ -135,7 +135,15 @@ def test_oracle_loop_equals_the_reference_kffilter_plus_trackfrontend_run():
     np.testing.assert_array_equal(jj, f["jj"])
 
 
-def load_backend_fixture():
+def load_backend_fixture(production=False):
+    if production:
+        from cut3r_slam_amd.config import production_config
+        f = np.load(os.path.join(GOLD, "backend_production.npz"))
+        cfg = production_config()
+        sd = synth.loop_state_dict(cfg, int(f["seed"]), enc_residual_gain=0.1)
+        frames = synth.pan_stream(40, 384, 512, pool=9, num=6, den=1, seed=0)
+        assert int(frames.long().sum()) == int(f["frames_sum"]), "the regenerated frames are not the fixture's"
+        return f, cfg, sd, frames
     f = np.load(os.path.join(GOLD, "backend.npz"))
     cfg = synth.medium_config()
     sd = synth.loop_state_dict(cfg, int(f["seed"]))
