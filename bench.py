@@ -500,6 +500,36 @@ def trajectory_parity_leg(dev, production_model=None, production_sd=None):
                     "differing_edges": [[int(i), int(j), so.graph.ratios.get((max(i, j), min(i, j)))] for i, j in diff[:8]],
                     "cpu_oracle_s": round(t_oracle, 1)}
         del slam
+    if production_model is not None:
+        # fourth entry: against the REFERENCE'S OWN loop at production shape -- tests/golden/loop_production.npz holds the keyframe trajectory
+        # that the reference's kfFilter + TrackFrontend.run produced on the CPU with its ViT-L / DPT model for these weights and this stream
+        # (generated in the build container by tests/golden/make_fixtures.py; the reference itself does not travel)
+        fpath = os.path.join(ROOT, "tests", "golden", "loop_production.npz")
+        if os.path.exists(fpath):
+            f = np.load(fpath)
+            frames = synth.pan_stream(33, H, W, 9, 6, 1, 0)
+            if int(frames.long().sum()) == int(f["frames_sum"]):
+                conf = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 1, "kf_every": 2}, "frontend": {"iteration": 0}}}
+                # (the fixture's weights, not the bench's: synth.tracking_state_dict(production_config(), 0, enc_residual_gain=0.1))
+                model_f = Cut3rModel(production_model.cfg, synth.tracking_state_dict(production_model.cfg, 0, enc_residual_gain=0.1), dev, minimal=True)
+                slam = Cut3rSlam(model_f, conf, (H, W), buffer=41, device=dev)
+                fr, it, n = frames.to(dev), torch.from_numpy(f["intrinsic"]), frames.shape[0]
+                for t in range(n):
+                    slam.run(t, fr[t:t + 1], it, fr[t:t + 1], it, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+                torch.cuda.synchronize()
+                ts, poses = slam.trajectory()
+                tg = np.concatenate([ts.reshape(-1, 1).astype(np.float64), poses.astype(np.float64)], 1)
+                k = int(f["t1"])
+                tr = np.concatenate([f["keyframes"][:k].reshape(-1, 1).astype(np.float64), f["pose"].astype(np.float64)], 1)
+                a = ate_rmse(tg, tr, 0.01, True)
+                ii, jj, _ = slam.graph.edges_numpy()
+                path = float(np.linalg.norm(np.diff(tr[:, 1:4], axis=0), axis=1).sum())
+                res["production_384x512_vs_reference_loop"] = {
+                    "reference": "hislam2 MotionFilter.kfFilter + TrackFrontend.run with the reference's ARCroco3DStereo on the CPU (tests/golden/loop_production.npz)",
+                    "keyframes": len(tr), "keyframe_agreement": float(np.array_equal(tg[:, 0], tr[:, 0])), "path_length_m": round(path, 4),
+                    "ate_rmse_m": a["rmse"], "ate_max_m": a["max"], "sim3_scale": a["scale"], "ate_rmse_mm_per_m": 1e3 * a["rmse"] / max(path, 1e-9),
+                    "edge_lists_equal": bool(np.array_equal(ii, f["ii"]) and np.array_equal(jj, f["jj"])), "edges_gpu": int(len(ii)), "edges_reference": int(len(f["ii"]))}
+                del slam, model_f
     return res
 
 
@@ -783,6 +813,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_base, "operating_points": op_points, "trajectory_parity": traj,
             "ate_rmse_m": (traj or {}).get("fixed_cadence_kf_every_2", {}).get("ate_rmse_m"),
             "ate_rmse_m_production_384x512": (traj or {}).get("production_384x512_kf_every_2", {}).get("ate_rmse_m"),
+            "ate_rmse_m_production_384x512_vs_reference_loop": (traj or {}).get("production_384x512_vs_reference_loop", {}).get("ate_rmse_m"),
             "hbm_peak_gb": round(hbm_peak / 1e9, 2),
             "memory_plan_8_gpus_25_steps_gb": {k: (round(v / 1e9, 2) if k != "keyframes" else v) for k, v in
                                                cdist.memory_plan(8, 25, WB, H, W, workspace_bytes=max(0, hbm_peak - cdist.memory_plan(1, args.steps + args.warmup + (probe_steps or 0), WB, H, W, weights_bytes=0)["total"])).items()
