@@ -585,6 +585,35 @@ def cpu_baseline(cfg, sd, imgs_u8, frames_per_window=50):
                       "6 decoder/head views + 1 alignment + 5 graph updates"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) the way the driver's own multi-GPU command does
+    -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>` --
+    as a CHILD process (this process has made no GPU call and makes none), relay rank 0's JSON line on stdout, everything else on stderr,
+    and return the children's exit code."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    log(f"starting {n} ranks: {' '.join(cmd)}")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for line in proc.stdout:
+        (lines.append if line.lstrip().startswith("{") else sys.stderr.write)(line)
+    rc = proc.wait()
+    if rc == 0 and not lines:
+        log("the ranks exited without a result line")
+        return 1
+    for line in lines[-1:]:
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -603,6 +632,25 @@ def main():
     ap.add_argument("--window-batch", type=int, default=28, help="tracking windows pushed through the decoder together "
                     "(buffered-stream throughput mode; 1 = the reference's one-window-at-a-time schedule)")
     args = ap.parse_args()
+
+    # ---- `--gpus N` starts the N ranks itself (one process per GPU) when no launcher has done so: fresh child processes through
+    #      torch.distributed.run, started BEFORE anything in this process touches the GPU; this process only relays rank 0's JSON line and
+    #      the exit code.  Under a launcher (WORLD_SIZE set) --gpus must agree with it: a mislabelled run is refused, never reported.
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    backend_env = os.environ.get("CUT3R_DIST_BACKEND", "nccl")
+    emu_env = int(os.environ.get("CUT3R_EMULATE_WORLD", "0"))
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            if backend_env == "nccl" and torch.cuda.device_count() < args.gpus:       # device_count() does not initialise the GPU
+                raise SystemExit(f"bench: --gpus {args.gpus} over RCCL needs {args.gpus} visible GPUs, found {torch.cuda.device_count()} "
+                                 "(CUT3R_DIST_BACKEND=gloo runs a functional multi-rank job on one GPU)")
+            raise SystemExit(launch_ranks(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus and emu_env <= 1:
+        raise SystemExit(f"bench: --gpus {args.gpus} disagrees with WORLD_SIZE={os.environ['WORLD_SIZE']} of the launcher: pass the same number "
+                         "(`python bench.py --gpus N` starts the N ranks itself)")
+    elif backend_env == "nccl" and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])):
+        raise SystemExit(f"bench: {os.environ['WORLD_SIZE']} RCCL ranks need one GPU each, found {torch.cuda.device_count()}")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     emu = int(os.environ.get("CUT3R_EMULATE_WORLD", "0"))     # debug: rank 0 of an `emu`-GPU job on ONE GPU (replay load only)

@@ -35,10 +35,12 @@ def test_two_ranks_on_one_gpu_match_each_other_and_a_single_rank(tmp_path):
     # as the first window of a rank's batch, one inside it
     common = ["--small", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
     two = str(tmp_path / "two")
-    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--window-batch", "2", "--sequence-windows", "6"] + common,
+    # `python bench.py --gpus 2` starts its two ranks ITSELF (bench.launch_ranks: fresh children through torch.distributed.run, the parent
+    # makes no GPU call and relays rank 0's line) -- the form the driver's scaling bench uses; the four-rank test below keeps the
+    # explicit launcher form
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--window-batch", "2", "--sequence-windows", "6"] + common,
                {"CUT3R_DIST_BACKEND": "gloo", "CUT3R_DUMP_STATE": two, "CUT3R_REPLICATE_DEPTH": "1"})
-    assert '"n_gpus": 2' in out
+    assert '"n_gpus": 2' in out and out.count('"metric"') == 1
     one = str(tmp_path / "one")
     _run([sys.executable, "bench.py", "--window-batch", "4", "--sequence-windows", "6"] + common, {"CUT3R_DUMP_STATE": one})
     r0, r1, s = np.load(two + ".rank0.npz"), np.load(two + ".rank1.npz"), np.load(one + ".rank0.npz")

