@@ -292,6 +292,13 @@ def gen_camera_fixture():
     fx = {"enc": enc, "c2w": c2w.numpy(), "R": quaternion_to_matrix(torch.from_numpy(enc[:, 3:])).numpy(),
           "pts": pts.numpy(), "geotrf": geotrf(c2w, pts).numpy(), "pose_vec": vec,
           "pose_vec_c2w": pose_vec_to_matrix(torch.from_numpy(vec)).numpy()}
+    # the other branches of geotrf (geometry.py:85-115): one matrix on a point list, a batch of matrices on a batch of point lists, 3x3
+    # matrices, the z = norm projection, numpy inputs  (round 4: pins cut3r_slam_amd/dust3r_utils.geotrf, the zero-edit model boundary)
+    pl = torch.from_numpy(g.standard_normal((9, 11, 3)).astype(np.float32))
+    pl[..., 2] = pl[..., 2].abs() + 0.5
+    fx.update({"pts_list": pl.numpy(), "geotrf_single": geotrf(c2w[2], pl[0]).numpy(), "geotrf_batch": geotrf(c2w, pl).numpy(),
+               "geotrf_rot3": geotrf(c2w[:, :3, :3].contiguous(), pl).numpy(), "geotrf_norm": geotrf(c2w[:, :3, :3].contiguous(), pl, norm=2.0, ncol=2).numpy(),
+               "geotrf_numpy": geotrf(c2w[3].numpy(), pl[1].numpy()), "inv": __import__("src.dust3r.utils.geometry", fromlist=["inv"]).inv(c2w).numpy()})
     # util.utils.umeyama_alignment (:738-763): a similarity between two point sets, once a proper one and once through a reflection
     from util.utils import umeyama_alignment
     src = g.standard_normal((40, 3))
