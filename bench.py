@@ -304,7 +304,7 @@ def traffic_from_profile(tile, launches_in_run):
 
 # ------------------------------------------------------------------------------------------------------------------ legs
 def fixed_cadence_leg(model, slam_cls, cdist, dev, wb, steps, warmup, world=1, rank=0, dist_on=False, emu=0, probe_steps=0, barrier=None,
-                      seq_windows=0):
+                      seq_windows=0, frame_source="host"):
     """buffered fixed-cadence schedule (kf_every=10) through the pipelined ShardedTracker; returns dict of results.  seq_windows > 0:
     the stream is a succession of sequences of that many windows (TrackFrontend.sequence_windows), 0: one endless sequence"""
     total_steps = warmup + steps
@@ -319,7 +319,18 @@ def fixed_cadence_leg(model, slam_cls, cdist, dev, wb, steps, warmup, world=1, r
     need = runner.frames_needed(total_steps + probe_steps, KF_EVERY, WIN)
     # one synthetic 640x480 recording of a Replica-shaped sequence (2000 frames), resident in HBM as RAW camera frames and read
     # cyclically; every keyframe is resized to the tracking resolution INSIDE the timed region (ShardedTracker._append)
-    frames = FrameLoop(synth_camera_frames((seq_windows if seq_windows > 0 else 40) * WIN * KF_EVERY, dev, seed=0), need)
+    # frame_source "host" (default): the recording sits in PINNED HOST memory and every keyframe the step reads crosses the link inside
+    # the timed region (asynchronous copy + resize on an upload stream, cut3r_slam_amd.dist.PinnedFrames) -- the reference uploads
+    # every frame it touches (hislam2/motion_filter.py:78,91); "host-all": ALL frames cross the link (also the 9 of 10 that a
+    # fixed-cadence stream never reads); "resident": the recording is in HBM before the timer starts (rounds 1-3)
+    rec = synth_camera_frames((seq_windows if seq_windows > 0 else 40) * WIN * KF_EVERY, dev, seed=0)
+    if frame_source in ("host", "host-all"):
+        host = rec.cpu()
+        del rec
+        torch.cuda.empty_cache()
+        frames = cdist.PinnedFrames(host, need, dev, upload_every_frame=(frame_source == "host-all"))
+    else:
+        frames = FrameLoop(rec, need)
     t = 0
     while not slam.keyframes.is_initialized:          # prologue (untimed): the 6-keyframe initialisation window
         f = to_tracking(frames[t:t + 1])
@@ -332,6 +343,7 @@ def fixed_cadence_leg(model, slam_cls, cdist, dev, wb, steps, warmup, world=1, r
     barrier()
     for k in runner.stats:
         runner.stats[k] = 0
+    up0 = getattr(frames, "bytes_uploaded", 0)
     tic = time.perf_counter()
     for _ in range(steps):
         t = runner.step(frames, t, KF_EVERY, WIN, intr)
@@ -339,7 +351,8 @@ def fixed_cadence_leg(model, slam_cls, cdist, dev, wb, steps, warmup, world=1, r
     barrier()
     elapsed = time.perf_counter() - tic
     return {"elapsed": elapsed, "slam": slam, "runner": runner, "frames": frames, "t": t, "intr": intr,
-            "frames_per_step": KF_EVERY * WIN * wb, "health": tracking_health(slam)}
+            "frames_per_step": KF_EVERY * WIN * wb, "health": tracking_health(slam),
+            "h2d_bytes_per_step": (getattr(frames, "bytes_uploaded", 0) - up0) / max(1, steps)}
 
 
 def tracking_health(slam):
@@ -629,6 +642,8 @@ def main():
                     "kf_every=10, whatever the number of GPUs: a bigger job runs through more sequences per step); 0 = one endless stream")
     ap.add_argument("--sequence-per-gpu", action="store_true", help="multiply --sequence-windows by the number of GPUs (sequences that grow "
                     "with the job: the covisibility test of a keyframe then grows with it too)")
+    ap.add_argument("--frames", choices=("host", "host-all", "resident"), default="host", help="where the camera recording lives: pinned host "
+                    "memory with every keyframe uploaded inside the timed region (default), every FRAME uploaded, or resident in HBM")
     ap.add_argument("--window-batch", type=int, default=28, help="tracking windows pushed through the decoder together "
                     "(buffered-stream throughput mode; 1 = the reference's one-window-at-a-time schedule)")
     args = ap.parse_args()
@@ -708,9 +723,10 @@ def main():
     SEQ = max(0, args.sequence_windows) * (world if args.sequence_per_gpu else 1)
     emu_rank = int(os.environ.get("CUT3R_EMULATE_RANK", "0")) % max(1, world) if emu > 1 else rank    # debug: rehearse another rank's load
     leg = fixed_cadence_leg(model, Cut3rSlam, cdist, dev, WB, args.steps, args.warmup, world, emu_rank, dist_on, emu, probe_steps, barrier,
-                            seq_windows=SEQ)
+                            seq_windows=SEQ, frame_source=args.frames)
     elapsed, slam, runner, frames, t, intr = (leg[k] for k in ("elapsed", "slam", "runner", "frames", "t", "intr"))
     frames_per_step = leg["frames_per_step"]
+    leg_h2d = leg["h2d_bytes_per_step"]
     health = leg["health"]
     if not health["poses_finite"] or health["nonfinite_windows"]:
         raise SystemExit(f"bench: the headline leg produced non-finite poses: {health}")      # never report a throughput for it
@@ -825,6 +841,17 @@ def main():
                 "keyframes_at_end": int(le["slam"].tracker.t1), "valid": bool(le["health"]["poses_finite"] and not le["health"]["nonfinite_windows"]),
                 "health": le["health"]}
             del le
+        log("operating points: the headline schedule with EVERY frame uploaded from pinned host memory")
+        la = fixed_cadence_leg(model, Cut3rSlam, cdist, dev, WB, max(2, args.steps // 2), args.warmup, barrier=barrier, seq_windows=SEQ, frame_source="host-all")
+        ns = max(2, args.steps // 2)
+        op_points["every_frame_uploaded"] = {
+            "config": f"the headline schedule (kf_every=10, window_batch={WB}) with ALL {la['frames_per_step']} frames of a step crossing the host link (pinned memory, "
+                      "asynchronous copies on the upload stream), as the reference's motion filter uploads every frame it is handed (hislam2/motion_filter.py:78); "
+                      "the 9 of 10 frames a fixed-cadence stream never reads are dropped on arrival",
+            "frames_per_s": round(ns * la["frames_per_step"] / la["elapsed"], 1), "ms_per_step": round(1e3 * la["elapsed"] / ns, 3),
+            "h2d_mb_per_step": round(la["h2d_bytes_per_step"] / 1e6, 1), "h2d_gb_per_s": round(la["h2d_bytes_per_step"] * ns / la["elapsed"] / 1e9, 2),
+            "health": la["health"]}
+        del la
         log("operating points: overlap mode (kf_every=-1, skip=5, thresh=0.9)")
         op_points["overlap_mode"] = guarded("overlap mode leg", overlap_mode_leg, model, Cut3rSlam, dev)
         log("operating points: loop closure on (BASELINE configs[2])")
@@ -846,8 +873,11 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "keyframes_per_s": round(value / KF_EVERY, 2),
             "nonfinite_windows": health["nonfinite_windows"], "health": health, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"BUFFERED FIXED-CADENCE mode: Replica-shaped 640x480 sequences (raw u8 frames resident in HBM; every keyframe resized to the 384x512 "
-                                   "tracking resolution inside the timed region, cv2.resize INTER_LINEAR semantics); kf_every=10; "
+            "config": {"workload": "BUFFERED FIXED-CADENCE mode: Replica-shaped 640x480 sequences ("
+                                   + {"host": "raw u8 frames streamed from pinned host memory: every keyframe the step reads is uploaded (async H2D on an upload stream) ",
+                                      "host-all": "raw u8 frames streamed from pinned host memory: EVERY frame is uploaded (async H2D on an upload stream), keyframes ",
+                                      "resident": "raw u8 frames resident in HBM; every keyframe "}[args.frames]
+                                   + "and resized to the 384x512 tracking resolution inside the timed region, cv2.resize INTER_LINEAR semantics); kf_every=10; "
                                    + (f"a sequence = {SEQ} windows = {SEQ * 50} frames (Replica room0: 2000 frames, x{world} GPUs), sequences follow each other without "
                                       "a gap (the last keyframe of one is keyframe 0 of the next: initialisation window, empty graph); " if SEQ > 0 else "ONE endless stream; ")
                                    + f"step = {WB} window(s) "
@@ -857,7 +887,8 @@ def main():
                                    "ViT-L/24 enc, 768/12 dual decoder, DPT head, random init; GS backend off; the reference's own "
                                    "schedules (one window at a time; overlap mode) are in `operating_points`"
                                    + (" [DEBUG --small]" if args.small else ""),
-                       "frames_per_step": frames_per_step, "window_views": 6, "window_batch": WB, "sequence_windows": SEQ, "parallelism": f"window-sharded x{world}"},
+                       "frames_per_step": frames_per_step, "window_views": 6, "window_batch": WB, "sequence_windows": SEQ, "parallelism": f"window-sharded x{world}",
+                       "frame_source": args.frames, "h2d_mb_per_step": round(leg_h2d / 1e6, 2)},
             "roofline": roofline, "cpu_baseline": cpu_base, "operating_points": op_points, "trajectory_parity": traj,
             "ate_rmse_m": (traj or {}).get("fixed_cadence_kf_every_2", {}).get("ate_rmse_m"),
             "ate_rmse_m_production_384x512": (traj or {}).get("production_384x512_kf_every_2", {}).get("ate_rmse_m"),

@@ -29,6 +29,8 @@ class GemmDesc(C.Structure):
         ("tile", c_int), ("stages", c_int),
         ("rope_pos", c_void_p), ("rope_table", c_void_p), ("rope_cols", c_int), ("rope_pmin", c_int), ("rope_npos", c_int),
         ("rope_d", c_int),
+        ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nslab", c_int), ("ln_eps", c_float),
+        ("stats_out", c_void_p), ("out16", c_void_p), ("ld16", c_int),
     ]
 
 

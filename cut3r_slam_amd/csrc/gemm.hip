@@ -38,6 +38,9 @@ struct GemmArgs {
     int prio;         // 1: s_setprio(1) around the MFMA cluster
     // fused 2-D RoPE (head dimension rope_d = 64 or 48) on output columns < rope_cols
     const long long* rope_pos; const float* rope_table; int rope_cols, rope_pmin, rope_npos, rope_d;
+    // LayerNorm folded into the GEMMs (see "LayerNorm fold" below): consumer side (ln_stats != null) and producer side (stats_out != null)
+    const float* ln_stats; const float* ln_c; int ln_nslab; float ln_eps;
+    float* stats_out; h16* out16; int ld16;
 };
 
 DEVINL half8_t relu8(half8_t v) {
@@ -108,11 +111,86 @@ DEVINL void fused_store4(const GemmArgs& g, int z, const float* bias, int gm, in
     store_out4(g, z, orow_off, fused_finish4(g, v, b4, bias != nullptr, r1, r2));
 }
 
+// ---- LayerNorm fold (round 4).  y = LN(x) W^T + b  =  rstd (x (gamma . W)^T - mu c) + d   with  c_n = sum_k gamma_k W_nk,
+// d = W beta + b  (croco/models/blocks.py:187-190: x = x + attn(norm1(x)); x = x + mlp(norm2(x)); dust3r/blocks.py:292-297).
+// PRODUCER (the fp32 + residual GEMM that writes the residual stream x): besides x it stores an fp16 copy of x (the consumer's A
+// operand) and, per row and 64-column slab, (sum, m2) with m2 = sum (x - sum/64)^2 -- in a FIXED order (in-lane pairs, then a
+// 16-lane butterfly: quad xor 1, xor 2, half mirror, row mirror), the same in every tile kernel, so the statistics of a row are
+// the same bits whatever tile or batch computed it.  CONSUMER (qkv / projq / projkv / fc1 with gamma folded into the fp16 weight
+// panel, d passed as the bias): combines a row's slabs in slab order (Chan's parallel variance: no E[x^2] - mu^2 cancellation),
+// rstd = 1 / sqrt(m2 / K + eps), and applies  acc * rstd - (rstd mu) c_n  to the raw accumulator before the usual epilogue.
+template <int CTRL>
+DEVINL float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+DEVINL float row16_sum(float v) {       // total over the 16 lanes of a DPP row, in every lane; all 64 lanes must be active
+    v += dpp_mov<0xB1>(v);               // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);               // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);              // row_half_mirror
+    v += dpp_mov<0x140>(v);              // row_mirror
+    return v;
+}
+// (sum, m2) of one row's 64-column slab; `v` = this lane's 4 consecutive columns, lane & 15 = column group.  Every lane gets both.
+DEVINL void slab_stats4(const f32x4& v, float& sum, float& m2) {
+    sum = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
+    const float mean = sum * (1.0f / 64.0f);
+    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+    m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+}
+// the same statistics from EIGHT consecutive columns per lane (lane & 7 = column group of 8: the 16-byte-store layout of the 256 x 256
+// producer epilogue).  Bit-identical to slab_stats4: the in-lane pair sums are step 1 of the 16-group butterfly (a + b == b + a), the
+// three DPP steps pair the same partial sums as its steps 2-4.
+DEVINL float row8_sum(float v) {
+    v += dpp_mov<0xB1>(v);               // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);               // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);              // row_half_mirror
+    return v;
+}
+DEVINL void slab_stats8(const f32x4& a, const f32x4& b, float& sum, float& m2) {
+    sum = row8_sum(((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3])));
+    const float mean = sum * (1.0f / 64.0f);
+    const float d0 = a[0] - mean, d1 = a[1] - mean, d2 = a[2] - mean, d3 = a[3] - mean;
+    const float e0 = b[0] - mean, e1 = b[1] - mean, e2 = b[2] - mean, e3 = b[3] - mean;
+    m2 = row8_sum(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)));
+}
+// row parameters (rstd, rstd * mu) from the row's slab statistics (8-B aligned), combined in slab order, in two steps so
+// that a kernel can REQUEST the statistics before it issues its DMA prologue and USE them after it: vmcnt retires in order, so a load
+// issued behind the prologue's LDS-DMA could only be waited for by draining the whole prologue.  All of a row's slabs are requested
+// together (clamped index: every load is unconditional, so the compiler keeps them in flight; a loop over the run-time slab count had
+// ONE 8-byte load outstanding at a time: 12-16 L2 round trips per tile, measured as -10 % end to end); slabs beyond nslab contribute an
+// exact + 0.0f.
+constexpr int LN_MAXS = 16;                        // K <= 1024 (the widths the network normalises: 768, 1024 and the test configs)
+struct LnRow { float2 t[LN_MAXS]; };
+// (statistics are stored SLAB-MAJOR, [nslab][M][2]: consecutive threads own consecutive rows, so each of these loads is one coalesced
+//  512-byte access per wave; row-major, a wave's load touched 64 different lines)
+DEVINL void ln_row_load(const float* __restrict__ st, int row, int M, int nslab, LnRow& r) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXS; i++) r.t[i] = reinterpret_cast<const float2*>(st)[(size_t)min(i, nslab - 1) * M + row];
+}
+DEVINL void ln_row_finish(const LnRow& r, int nslab, int K, float eps, float& rs, float& rm) {
+    float S = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXS; i++) S += (i < nslab) ? r.t[i].x : 0.f;
+    const float mu = S / (float)K;
+    float M2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXS; i++) {
+        const float e = r.t[i].x * (1.0f / 64.0f) - mu;
+        M2 += (i < nslab) ? r.t[i].y + 64.0f * (e * e) : 0.f;
+    }
+    rs = 1.0f / sqrtf(M2 / (float)K + eps);
+    rm = rs * mu;
+}
+DEVINL float ln_pre(float acc, float rs, float rm, float c) { return fmaf(acc, rs, -(rm * c)); }
+DEVINL f32x4 ln_pre4(const f32x4& a, float rs, float rm, const f32x4& c) {
+    return f32x4{ln_pre(a[0], rs, rm, c[0]), ln_pre(a[1], rs, rm, c[1]), ln_pre(a[2], rs, rm, c[2]), ln_pre(a[3], rs, rm, c[3])};
+}
+
 // Fused 2-D RoPE of 4 consecutive output columns gn..gn+3 (< rope_cols) of row gm, head dimension D = 64 or 48 (quarter
 // Q = D/4): a head is [y-block | x-block] of D/2 columns, inside a block column j < Q pairs with column j + Q.  `cs_row` is
 // this row of the epilogue's LDS staging (raw accumulators), c4 the tile-local column of gn; the partner values come from
 // c4 +- Q (tiles start on head boundaries).  Same arithmetic as rope2d_kernel on the fp16-rounded projection.
-DEVINL void rope_store4(const GemmArgs& g, int z, const float* bias, int gm, int gn, const float* cs_row, int c4) {
+DEVINL void rope_store4(const GemmArgs& g, int z, const float* bias, int gm, int gn, const float* cs_row, int c4, float ln_rs = 1.f, float ln_rm = 0.f) {
     const int D = g.rope_d, Q = D >> 2, half = D >> 1;
     const int hl = gn % D, X = hl / half, within = hl - X * half;
     const bool lower = within < Q;
@@ -120,6 +198,10 @@ DEVINL void rope_store4(const GemmArgs& g, int z, const float* bias, int gm, int
     const int po = lower ? Q : -Q;
     f32x4 own = *reinterpret_cast<const f32x4*>(cs_row + c4);
     f32x4 partner = *reinterpret_cast<const f32x4*>(cs_row + c4 + po);
+    if (g.ln_stats) {              // LayerNorm fold: the raw accumulators become the projection of the normalised row first
+        own = ln_pre4(own, ln_rs, ln_rm, *reinterpret_cast<const f32x4*>(g.ln_c + gn));
+        partner = ln_pre4(partner, ln_rs, ln_rm, *reinterpret_cast<const f32x4*>(g.ln_c + gn + po));
+    }
     if (bias) {
         own += *reinterpret_cast<const f32x4*>(bias + gn);
         partner += *reinterpret_cast<const f32x4*>(bias + gn + po);
@@ -183,6 +265,9 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
     constexpr int EPI_ROWS = BM / EPI_PASSES;
     constexpr int EPI_BYTES = EPI_ROWS * CPAD * 4;
     constexpr int LDS_BYTES = (NSTAGE * STAGE_BYTES > EPI_BYTES) ? NSTAGE * STAGE_BYTES : EPI_BYTES;
+    // LayerNorm fold, consumer side: (rstd, rstd * mu) of the tile's BM rows live behind the epilogue's staging band (the ring is dead by then)
+    constexpr int LNP_OFF = LDS_BYTES - BM * 8;
+    static_assert(EPI_BYTES <= LNP_OFF, "no room for the LayerNorm row parameters behind the staging band");
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -319,9 +404,18 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
         for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nt = (K + BK - 1) / BK;
+    // LayerNorm fold, consumer side: thread t < BM requests row t's slab statistics BEFORE the DMA prologue (vmcnt retires in order) and
+    // turns them into (rstd, rstd * mu) while the first K-tiles are in flight; the pair waits in two registers until the ring is dead
+    // and then moves behind the staging band
+    float ln_rs = 1.f, ln_rm = 0.f;
+    LnRow ln_raw;
+    const bool ln_mine = g.ln_stats && tid < BM;
+    if (ln_mine) ln_row_load(g.ln_stats, min(m0 + tid, M - 1), M, g.ln_nslab, ln_raw);
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; s++)
         if (s < nt) issue_tile(s, s);
+    if (ln_mine) ln_row_finish(ln_raw, g.ln_nslab, K, g.ln_eps, ln_rs, ln_rm);
+    asm volatile("" : "+v"(ln_rs), "+v"(ln_rm));          // computed HERE, in the prologue's shadow (not sunk behind the main loop)
 
     const int fr = lane & 15, fq = lane >> 4;   // fragment row, k-chunk
     int stage = 0;
@@ -369,6 +463,11 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
     // ---- epilogue: accumulators -> LDS (fp32) -> coalesced fused store, one row band per pass.  The residual rows a thread
     // will add are loaded BEFORE the band is staged (their latency overlaps the staging and the barrier).
     float* cs = reinterpret_cast<float*>(smem);
+    const float* lnp = reinterpret_cast<const float*>(smem + LNP_OFF);       // [BM][2], valid after the staging barrier
+    if (g.ln_stats && tid < BM) {
+        float* w = reinterpret_cast<float*>(smem + LNP_OFF) + 2 * tid;
+        w[0] = ln_rs; w[1] = ln_rm;
+    }
     const float* bias = g.bias ? g.bias + (size_t)z * g.sBias : nullptr;
     constexpr int TPR = BN / 4;               // threads per output row (4 columns each)
     constexpr int RPP = NTHR / TPR;           // rows per pass
@@ -423,8 +522,16 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
             for (int i = 0; i < ITER; i++) {
                 const int r = r0 + i * RPP;
                 const int gm = m0 + p * EPI_ROWS + r;
-                if (col_ok && r < EPI_ROWS && gm < M) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4) + bb;
+                // (every lane runs the arithmetic -- the slab statistics are 16-lane butterflies --, only the stores are bounded)
+                const bool ok = col_ok && r < EPI_ROWS && gm < M;
+                {
+                    const int rc = min(r, EPI_ROWS - 1);
+                    f32x4 v = *reinterpret_cast<const f32x4*>(cs + rc * CPAD + c4);
+                    if (g.ln_stats) {
+                        const int lr = p * EPI_ROWS + rc;
+                        v = ln_pre4(v, lnp[2 * lr], lnp[2 * lr + 1], *reinterpret_cast<const f32x4*>(g.ln_c + gnc));
+                    }
+                    v += bb;
                     if (EPI == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = gelu_fast(v[e]);
@@ -440,9 +547,18 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
                     const size_t off = (size_t)z * g.sC + (size_t)gm * g.ldc + gn;
                     if (F16OUT) {
                         const half4_t o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
-                        *reinterpret_cast<half4_t*>((h16*)g.C + off) = o;
+                        if (ok) *reinterpret_cast<half4_t*>((h16*)g.C + off) = o;
                     } else {
-                        *reinterpret_cast<f32x4*>((float*)g.C + off) = v;
+                        if (ok) *reinterpret_cast<f32x4*>((float*)g.C + off) = v;
+                        if (EPI == 3 && g.stats_out) {            // producer side of the LayerNorm fold: fp16 copy + slab statistics
+                            float ssum, sm2;
+                            slab_stats4(v, ssum, sm2);
+                            if (ok) {
+                                const half4_t o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                                *reinterpret_cast<half4_t*>(g.out16 + (size_t)gm * g.ld16 + gn) = o;
+                                if ((tid & 15) == 0) *reinterpret_cast<float2*>(g.stats_out + ((size_t)(gn >> 6) * M + gm) * 2) = float2{ssum, sm2};
+                            }
+                        }
                     }
                 }
             }
@@ -486,7 +602,8 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
                     }
                     if (r < EPI_ROWS && gm < M) {
                         const f32x4 r2 = g.res2 ? load_res4(g.res2, g.res2_f16, (size_t)z * g.sR2 + (size_t)gm * g.ldr2 + gn) : zero4;
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
+                        f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
+                        if (g.ln_stats) v = ln_pre4(v, lnp[2 * (p * EPI_ROWS + r)], lnp[2 * (p * EPI_ROWS + r) + 1], *reinterpret_cast<const f32x4*>(g.ln_c + gn));
                         store_out4(g, z, (size_t)gm * g.ldc + gn, fused_finish4(g, v, b4, bias != nullptr, r1, r2));
                     }
                 }
@@ -494,9 +611,13 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
                 for (int r = r0; r < EPI_ROWS; r += RPP) {
                     const int gm = m0 + p * EPI_ROWS + r;
                     if (gm >= M) break;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
-                    if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, cs + r * CPAD, c4);
-                    else fused_store4(g, z, bias, gm, gn, v);
+                    f32x4 v = *reinterpret_cast<const f32x4*>(cs + r * CPAD + c4);
+                    const float rs = g.ln_stats ? lnp[2 * (p * EPI_ROWS + r)] : 1.f, rm = g.ln_stats ? lnp[2 * (p * EPI_ROWS + r) + 1] : 0.f;
+                    if (gn < g.rope_cols) rope_store4(g, z, bias, gm, gn, cs + r * CPAD, c4, rs, rm);
+                    else {
+                        if (g.ln_stats) v = ln_pre4(v, rs, rm, *reinterpret_cast<const f32x4*>(g.ln_c + gn));
+                        fused_store4(g, z, bias, gm, gn, v);
+                    }
                 }
             }
         }
@@ -560,11 +681,17 @@ __global__ CUT3R_TILE_BOUNDS void gemm_pair_kernel(const GemmPairArgs a) {
 // convolutions; 6 = fp16 out + bias + 2-D RoPE of the 64-wide heads in columns < rope_cols (a wave's 64-column slab is one head: the
 // rotation partner of a lane's 8 columns is 16 columns away in the wave's own staging row).  Straight-line; same per-element
 // arithmetic, same order (bias, activation, residuals; RoPE on the fp16-rounded projection, as the stand-alone kernel sees it).
-template <bool CONV3, bool RELU_IN, bool FAST_DMA = false, int EPI = 0>
+// LN (round 4): consumer side of the LayerNorm fold for the fp16-output epilogues 1 / 2 / 6 -- thread t < 256 turns the slab statistics of
+// the tile's row t into (rstd, rstd * mu) while the prologue's DMA is in flight and parks them in 2 KiB behind the ring (published by the
+// prologue's barrier); the epilogue applies acc * rstd - (rstd mu) c_n before the bias.  The
+// producer side (EPI 3 with g.stats_out: fp16 copy + slab statistics of the fp32 residual stream it writes) needs no LDS and is decided
+// at run time.
+template <bool CONV3, bool RELU_IN, bool FAST_DMA = false, int EPI = 0, bool LN = false>
 DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     constexpr int UNIT = 128 * BK * 2;      // 16 KiB: 128 rows x 64 halfs
     constexpr int BUF = 4 * UNIT;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+    static_assert(!LN || EPI == 1 || EPI == 2 || EPI == 6, "the LayerNorm fold feeds the fp16-output epilogues");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + (LN ? 2 * 1024 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
@@ -751,18 +878,34 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
 #ifndef CUT3R_G256_PHASES
 #define CUT3R_G256_PHASES 2
 #endif
+    static_assert(!LN || CUT3R_G256_PHASES == 2, "the LayerNorm fold is wired into the two-phase schedule");
 #if CUT3R_G256_PHASES == 2
     // ---- TWO phases per K-tile (one per 64-row half of the wave's 128 rows): phase A reads A-half 0 (U0) and both B halves (U1, U2)
     // and runs 32 MFMAs, phase B reads A-half 1 (U3) and runs the other 32 -- four barriers per K-tile, 32 MFMAs per barrier pair.
     // A slot is refilled as soon as both wave groups have read it: U0..U2 of K-tile t+2 go into the CURRENT buffer during phase B
     // (they were last read in phase A, by the lagging group one barrier later), U3 of K-tile t+1 into the other buffer during
     // phase A.  In flight behind the unit a phase needs: 4 units = 8 DMA instructions per wave (one counted wait per phase).
+    LnRow ln_raw;
+    if constexpr (LN) {          // thread t < 256 owns row t of the tile: requested BEFORE the DMA prologue (vmcnt retires in order), used after it
+        if (tid < 256) ln_row_load(g.ln_stats, min(m0 + tid, M - 1), M, g.ln_nslab, ln_raw);
+    }
     issue_a(0, 0, 0); issue_b(0, 0, 1); issue_b(1, 0, 2); issue_a(1, 0, 3);
     issue_a(0, 1, 0); issue_b(0, 1, 1); issue_b(1, 1, 2);
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LN) {
+        // (rstd, rstd * mu) of the tile's 256 rows go to 2 KiB behind the ring, published by the prologue's barrier.  The store pins the
+        // arithmetic HERE (left alone, the compiler sinks it to its first use behind the main loop and carries the raw registers there
+        // through scratch)
+        if (tid < 256) {
+            float rs_, rm_;
+            ln_row_finish(ln_raw, g.ln_nslab, K, g.ln_eps, rs_, rm_);
+            *reinterpret_cast<float2*>(smem + 2 * BUF + tid * 8) = float2{rs_, rm_};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     if (nt > 1) wait_vmcnt<6>(); else wait_vmcnt<0>();
     CUT3R_BARRIER();
     if (wr == 1) CUT3R_BARRIER();          // stagger: the second wave group runs one barrier behind the first
@@ -845,12 +988,15 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
     const float* bias = g.bias ? g.bias + (size_t)z * g.sBias : nullptr;
     const bool plain = !g.shuf && g.rope_cols == 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float* lnp = reinterpret_cast<const float*>(smem + 2 * BUF) + wr * 256;      // LN: (rstd, rstd * mu) of this wave's 128 rows
     if constexpr (EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5 || EPI == 6) {
         const int er = lane >> 3, ec = (lane & 7) * 8;
         const int gn = n0 + wc * 64 + ec;
         const bool col_ok = gn + 8 <= N;               // (every lane stages its accumulators; only the readers are column-bounded)
         const int gnc = col_ok ? gn : 0;
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + gnc), b1 = *reinterpret_cast<const f32x4*>(bias + gnc + 4);
+        f32x4 lc0 = zero4, lc1 = zero4, lpc0 = zero4, lpc1 = zero4;      // LN: c_n of this lane's 8 columns (and of its RoPE partner's)
+        if constexpr (LN) { lc0 = *reinterpret_cast<const f32x4*>(g.ln_c + gnc); lc1 = *reinterpret_cast<const f32x4*>(g.ln_c + gnc + 4); }
         // EPI 6: the slab n0 + wc*64 .. +63 is one head; rotated when it lies below rope_cols (wave-uniform); partner's bias
         const bool rope_here = EPI == 6 && (n0 + wc * 64) < g.rope_cols && col_ok;
         f32x4 pb0 = zero4, pb1 = zero4;
@@ -858,6 +1004,7 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
             const int pc = gnc + ((ec & 16) ? -16 : 16);
             pb0 = *reinterpret_cast<const f32x4*>(bias + pc);
             pb1 = *reinterpret_cast<const f32x4*>(bias + pc + 4);
+            if constexpr (LN) { lpc0 = *reinterpret_cast<const f32x4*>(g.ln_c + pc); lpc1 = *reinterpret_cast<const f32x4*>(g.ln_c + pc + 4); }
         }
         // EPI 6: the wave keeps the first ROPE_LDS rows of the cos|sin table (row = 16 cos | 16 sin) and the clamped table rows of its
         // 128 output rows behind its staging band, in its own 16 KiB: the rotation of a row then costs LDS reads instead of a dependent
@@ -916,8 +1063,17 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
 #pragma unroll
             for (int it = 0; it < 4; it++) {
                 const int rr = it * 8 + er;
-                f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec) + b0;
-                f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + 4) + b1;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + 4);
+                float rs = 1.f, rm = 0.f;
+                if constexpr (LN) {
+                    const float2 pr = *reinterpret_cast<const float2*>(lnp + 2 * (mp * 32 + rr));
+                    rs = pr.x; rm = pr.y;
+                    v0 = ln_pre4(v0, rs, rm, lc0);
+                    v1 = ln_pre4(v1, rs, rm, lc1);
+                }
+                v0 += b0;
+                v1 += b1;
                 if (EPI == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) { v0[e] = gelu_fast(v0[e]); v1[e] = gelu_fast(v1[e]); }
@@ -933,8 +1089,11 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
                 if (EPI == 6 && rope_here) {
                     // head-local column ec: half X = ec / 32 (y or x position), pair offset +-16 inside the half, frequency index ec % 16 ..
                     const int po = (ec & 16) ? -16 : 16;
-                    f32x4 p0 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + po) + pb0;
-                    f32x4 p1 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + po + 4) + pb1;
+                    f32x4 p0 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + po);
+                    f32x4 p1 = *reinterpret_cast<const f32x4*>(cs + rr * CP + ec + po + 4);
+                    if constexpr (LN) { p0 = ln_pre4(p0, rs, rm, lpc0); p1 = ln_pre4(p1, rs, rm, lpc1); }
+                    p0 += pb0;
+                    p1 += pb1;
                     const int pv = psl[(mp * 32 + rr) * 2 + (ec >> 5)];
                     f32x4 c0, c1, s0, s1;
                     if (__builtin_amdgcn_ballot_w64(pv >= ROPE_LDS) == 0) {
@@ -958,6 +1117,50 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
                 }
                 const half8_t o = {(h16)v0[0], (h16)v0[1], (h16)v0[2], (h16)v0[3], (h16)v1[0], (h16)v1[1], (h16)v1[2], (h16)v1[3]};
                 if (col_ok && m0 + wr * 128 + mp * 32 + rr < M) *reinterpret_cast<half8_t*>(crow + (size_t)(mp * 4 + it) * step8) = o;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else if (EPI == 3 && g.stats_out) {
+        // producer side of the LayerNorm fold: the same sums in the same order with EIGHT columns per lane, so that the fp16 copy leaves
+        // as 16-byte stores (stores are issue-bound: one per lane and row instead of two)
+        const int er = lane >> 3, ec = (lane & 7) * 8;
+        const int gn = n0 + wc * 64 + ec;
+        const bool col_ok = gn + 8 <= N;
+        const int gnc = col_ok ? gn : 0;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + gnc), b1 = *reinterpret_cast<const f32x4*>(bias + gnc + 4);
+        const float* rrow = (const float*)g.res1 + (size_t)z * g.sR1 + gnc;
+        float* crow = (float*)g.C + (size_t)z * g.sC + gnc;
+#pragma unroll
+        for (int mp = 0; mp < 4; mp++) {
+            f32x4 ra[4], rb[4];
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int gm = min(m0 + wr * 128 + mp * 32 + it * 8 + er, M - 1);
+                ra[it] = *reinterpret_cast<const f32x4*>(rrow + (size_t)gm * g.ldr1);
+                rb[it] = *reinterpret_cast<const f32x4*>(rrow + (size_t)gm * g.ldr1 + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) cs[(i * 16 + fq * 4 + e) * CP + j * 16 + fr] = acc[mp * 2 + i][j][e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int rr = it * 8 + er;
+                const int gm = m0 + wr * 128 + mp * 32 + rr;
+                const f32x4 v0 = (*reinterpret_cast<const f32x4*>(cs + rr * CP + ec) + b0) + ra[it];
+                const f32x4 v1 = (*reinterpret_cast<const f32x4*>(cs + rr * CP + ec + 4) + b1) + rb[it];
+                float ssum, sm2;
+                slab_stats8(v0, v1, ssum, sm2);
+                if (col_ok && gm < M) {
+                    *reinterpret_cast<f32x4*>(crow + (size_t)gm * g.ldc) = v0;
+                    *reinterpret_cast<f32x4*>(crow + (size_t)gm * g.ldc + 4) = v1;
+                    const half8_t o = {(h16)v0[0], (h16)v0[1], (h16)v0[2], (h16)v0[3], (h16)v1[0], (h16)v1[1], (h16)v1[2], (h16)v1[3]};
+                    *reinterpret_cast<half8_t*>(g.out16 + (size_t)gm * g.ld16 + gnc) = o;
+                    if ((lane & 7) == 0) *reinterpret_cast<float2*>(g.stats_out + ((size_t)(gnc >> 6) * M + gm) * 2) = float2{ssum, sm2};
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -1084,8 +1287,8 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
 #undef CUT3R_BARRIER
 }
 
-template <bool CONV3, bool RELU_IN, bool FAST_DMA = false, int EPI = 0>
-__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) { gemm256_body<CONV3, RELU_IN, FAST_DMA, EPI>(g, blockIdx.x, blockIdx.z); }
+template <bool CONV3, bool RELU_IN, bool FAST_DMA = false, int EPI = 0, bool LN = false>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmArgs g) { gemm256_body<CONV3, RELU_IN, FAST_DMA, EPI, LN>(g, blockIdx.x, blockIdx.z); }
 
 // which compile-time epilogue of gemm256_body a plain Linear qualifies for (0: the run-time one)
 static int gemm256_epi_mode(const GemmArgs& g) {
@@ -1292,6 +1495,20 @@ static int fill_args(const cut3r_gemm_desc* d, GemmArgs& g) {
     g.rope_pos = (const long long*)d->rope_pos; g.rope_table = d->rope_table;
     g.rope_cols = d->rope_pos ? d->rope_cols : 0; g.rope_pmin = d->rope_pmin; g.rope_npos = d->rope_npos;
     g.rope_d = d->rope_d ? d->rope_d : 64;
+    // LayerNorm fold: consumer (ln_stats + ln_colsum) and producer (stats_out + out16) sides
+    g.ln_stats = d->ln_stats; g.ln_c = d->ln_colsum; g.ln_nslab = d->ln_nslab; g.ln_eps = d->ln_eps;
+    g.stats_out = d->stats_out; g.out16 = (h16*)d->out16; g.ld16 = d->ld16;
+    if ((d->ln_stats != nullptr) != (d->ln_colsum != nullptr) || (d->stats_out != nullptr) != (d->out16 != nullptr)) return CUT3R_ERR_ARG;
+    if (d->ln_stats) {
+        if (!d->bias || d->conv_k == 3 || d->shuf || d->relu_in || batch_of(d) != 1 || d->ln_nslab * 64 != d->K || !(d->ln_eps > 0.f) ||
+            ((uintptr_t)d->ln_stats & 7) || ((uintptr_t)d->ln_colsum & 15))
+            return CUT3R_ERR_ARG;
+    }
+    if (d->stats_out) {
+        if (d->out_f16 || !d->res1 || d->res1_f16 || d->res2 || d->act || d->conv_k == 3 || d->shuf || batch_of(d) != 1 || (d->N & 63) ||
+            (d->ld16 & 7) || ((uintptr_t)d->out16 & 15) || ((uintptr_t)d->stats_out & 7))
+            return CUT3R_ERR_ARG;
+    }
     if (g.rope_cols) {
         // whole heads inside the N range and inside every tile (tile widths 64/128/256 hold 64-wide heads, 192 holds both
         // 64- and 48-wide heads), fp16 output only
@@ -1312,7 +1529,7 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int tile = cut3r_gemm_tile_for(d);
     if (tile == 16) {
-        if (d->M > 64 || d->conv_k == 3 || d->shuf || d->relu_in || g.rope_cols) return CUT3R_ERR_ARG;
+        if (d->M > 64 || d->conv_k == 3 || d->shuf || d->relu_in || g.rope_cols || g.ln_stats || g.stats_out) return CUT3R_ERR_ARG;
         dim3 grid((d->N + 15) / 16, 1, batch);
         const int mb = (d->M + 15) / 16;            // 1..4 row blocks; K >= 2048 splits over 8 waves, else 4
 #define CUT3R_SKINNY(NWV, MBV) hipLaunchKernelGGL((gemm_skinny_kernel<NWV, MBV>), grid, dim3(64 * NWV), 0, s, g)
@@ -1323,6 +1540,9 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         dim3 grid(((d->N + 255) / 256) * ((d->M + 255) / 256), 1, batch);
         const bool fast = gemm256_fast_ok(g);
         const int epi = fast ? gemm256_epi_mode(g) : 0;
+        // the LayerNorm fold lives in the compile-time epilogues: consumer 1 / 2 / 6, producer 3
+        if (g.ln_stats && !(fast && d->conv_k != 3 && !d->relu_in && (epi == 1 || epi == 2 || epi == 6))) return CUT3R_ERR_ARG;
+        if (g.stats_out && !(fast && d->conv_k != 3 && !d->relu_in && epi == 3)) return CUT3R_ERR_ARG;
         if (d->conv_k == 3 && d->relu_in && fast && epi == 4) hipLaunchKernelGGL((gemm256_kernel<true, true, true, 4>), grid, dim3(512), 0, s, g);
         else if (d->conv_k == 3 && !d->relu_in && fast && epi == 5) hipLaunchKernelGGL((gemm256_kernel<true, false, true, 5>), grid, dim3(512), 0, s, g);
         else if (d->conv_k == 3 && !d->relu_in && fast && epi == 1) hipLaunchKernelGGL((gemm256_kernel<true, false, true, 1>), grid, dim3(512), 0, s, g);
@@ -1332,6 +1552,13 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         else if (d->conv_k == 3 && d->relu_in) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, dim3(512), 0, s, g);
         else if (d->conv_k == 3) hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, dim3(512), 0, s, g);
         else if (d->relu_in) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, dim3(512), 0, s, g);
+        else if (fast && g.ln_stats) {
+            switch (epi) {
+                case 1: hipLaunchKernelGGL((gemm256_kernel<false, false, true, 1, true>), grid, dim3(512), 0, s, g); break;
+                case 2: hipLaunchKernelGGL((gemm256_kernel<false, false, true, 2, true>), grid, dim3(512), 0, s, g); break;
+                default: hipLaunchKernelGGL((gemm256_kernel<false, false, true, 6, true>), grid, dim3(512), 0, s, g);
+            }
+        }
         else if (fast) {
             switch (epi) {
                 case 1: hipLaunchKernelGGL((gemm256_kernel<false, false, true, 1>), grid, dim3(512), 0, s, g); break;
@@ -1349,6 +1576,7 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
             g.swz = 1;
             grid = dim3(grid.x * grid.y, 1, batch);
         }
+        if (g.stats_out && d->stages != 0) return CUT3R_ERR_ARG;
         if (d->stages == 3) hipLaunchKernelGGL((gemm_kernel<128, 128, 3>), grid, dim3(256), 0, s, g);
         else if (d->stages == 8) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 4>), grid, dim3(512), 0, s, g);   // 8 waves
         else if (d->stages == 9) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);   // 8 waves
@@ -1357,6 +1585,7 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<128, 128, 2>), grid, dim3(256), 0, s, g);
         else {
             const int am = tile_addr_mode(g), ep = gemm256_epi_mode(g);
+            if (g.stats_out && !(am == 1 && ep == 3)) return CUT3R_ERR_ARG;      // the producer side lives in the compile-time epilogue 3
             if (am == 1 && ep == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 1, 1>), grid, dim3(512), 0, s, g);
             else if (am == 1 && ep == 2) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 1, 2>), grid, dim3(512), 0, s, g);
             else if (am == 1 && ep == 3) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 1, 3>), grid, dim3(512), 0, s, g);
@@ -1364,6 +1593,8 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
             else if (am == 2) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2, 2>), grid, dim3(512), 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, g);
         }
+    } else if (g.stats_out && tile != 64) {
+        return CUT3R_ERR_ARG;              // producer side of the LayerNorm fold: tiles 256, 128 and 64 only
     } else if (tile == 128192) {       // 128 x 192 (four 48-wide or three 64-wide heads per tile), 8 waves (32 x 96 per wave), 80 KB LDS
         dim3 grid(((d->N + 191) / 192) * ((d->M + 127) / 128), 1, batch);
         g.swz = 1;
@@ -1390,17 +1621,27 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
         else hipLaunchKernelGGL((gemm_kernel<128, 64, 2>), grid, dim3(256), 0, s, g);
     } else if (tile == 64) {
         dim3 grid((d->N + 63) / 64, (d->M + 63) / 64, batch);
+        if (g.stats_out && d->stages != 0) return CUT3R_ERR_ARG;
         if (d->stages == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 2>), grid, dim3(256), 0, s, g);
         else if (d->stages == 8 || (d->stages == 0 && d->K >= 2048)) {   // long K: 8 waves
             const int am = d->stages == 0 ? tile_addr_mode(g) : 0;
-            if (am == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4, 1>), grid, dim3(512), 0, s, g);
+            const int ep = am == 1 ? gemm256_epi_mode(g) : 0;
+            if (g.stats_out && ep != 3) return CUT3R_ERR_ARG;
+            if (ep == 3) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4, 1, 3>), grid, dim3(512), 0, s, g);     // fc2 + residual at one window
+            else if (am == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4, 1>), grid, dim3(512), 0, s, g);
             else if (am == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4, 2>), grid, dim3(512), 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4>), grid, dim3(512), 0, s, g);
         }
         else if (d->stages == 4) hipLaunchKernelGGL((gemm_kernel<64, 64, 4>), grid, dim3(256), 0, s, g);
         else {
             const int am = d->stages == 0 ? tile_addr_mode(g) : 0;
-            if (am == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 1>), grid, dim3(256), 0, s, g);
+            // compile-time epilogues for the one-window (M = 769) Linear layers: fp16 + bias, + GELU, fp32 + bias + fp32 residual
+            const int ep = am == 1 ? gemm256_epi_mode(g) : 0;
+            if (g.stats_out && ep != 3) return CUT3R_ERR_ARG;
+            if (ep == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 1, 1>), grid, dim3(256), 0, s, g);
+            else if (ep == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 1, 2>), grid, dim3(256), 0, s, g);
+            else if (ep == 3) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 1, 3>), grid, dim3(256), 0, s, g);
+            else if (am == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 1>), grid, dim3(256), 0, s, g);
             else if (am == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 2>), grid, dim3(256), 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<64, 64, 3>), grid, dim3(256), 0, s, g);
         }
@@ -1419,7 +1660,7 @@ extern "C" int cut3r_gemm_f16_pair(const cut3r_gemm_desc* d0, const cut3r_gemm_d
     if (rc != CUT3R_OK) return rc;
     // plain linears only, one problem each (no batch), same N and K so both take the same tile kernel
     for (const cut3r_gemm_desc* d : {d0, d1})
-        if (d->conv_k == 3 || d->shuf || d->relu_in || (d->rope_pos && d->rope_cols) || (d->batch > 1)) return CUT3R_ERR_ARG;
+        if (d->conv_k == 3 || d->shuf || d->relu_in || (d->rope_pos && d->rope_cols) || (d->batch > 1) || d->ln_stats || d->stats_out) return CUT3R_ERR_ARG;
     if (d0->N != d1->N || d0->K != d1->K) return CUT3R_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     // tile choice on the COMBINED grid (the two problems fill the chip together)

@@ -87,6 +87,63 @@ def memory_plan(world: int, steps: int, wb: int = 28, H: int = 384, W: int = 512
     return plan
 
 
+class PinnedFrames:
+    """A camera recording in PINNED HOST memory, delivered to the GPU the way a live system receives it: the reference uploads every
+    frame it touches (/root/reference/hislam2/motion_filter.py:78,91 `.to('cuda')`, track_frontend.py:48).  `fetch(f)` issues an
+    asynchronous host-to-device copy of frame `f % period` on this object's own HIP stream into a device staging ring and returns the
+    staged [1,H0,W0,3] u8 tensor; whatever consumes it must run on `stream` (ShardedTracker does the keyframe's resize there: copy and consumer are then
+    in stream order, which is also what makes a small ring safe) or wait for `event()`.  `upload_every_frame=True` also pushes the frames nobody reads (non-keyframes of a fixed-cadence stream) over the
+    link: the reference's motion filter uploads every tested frame."""
+
+    def __init__(self, host_frames: torch.Tensor, virtual_len: int, device, ring: int = 16, upload_every_frame: bool = False):
+        assert not host_frames.is_cuda and host_frames.dtype == torch.uint8 and host_frames.dim() == 4
+        self.base = host_frames if host_frames.is_pinned() else host_frames.pin_memory()
+        self.period = self.base.shape[0]
+        self.shape = (int(virtual_len),) + tuple(self.base.shape[1:])
+        self.device, self.dtype, self.is_cuda = torch.device(device), torch.uint8, False
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.ring = torch.empty((int(ring),) + tuple(self.base.shape[1:]), dtype=torch.uint8, device=self.device)
+        self._slot = 0
+        self.upload_every_frame = bool(upload_every_frame)
+        self._uploaded_upto = 0
+        self.bytes_uploaded = 0
+
+    def fetch(self, f: int) -> torch.Tensor:
+        """frame f -> its staging slot, copied on `self.stream` (call inside `torch.cuda.stream(self.stream)` or wait for event())"""
+        slot = self._slot
+        self._slot = (slot + 1) % self.ring.shape[0]
+        dst = self.ring[slot:slot + 1]
+        with torch.cuda.stream(self.stream):
+            dst.copy_(self.base[int(f) % self.period][None], non_blocking=True)
+        self.bytes_uploaded += dst.numel()
+        return dst
+
+    def upload_range(self, a: int, b: int, keep: Callable[[int], bool]):
+        """the every-frame operating point: frames a..b-1 that `keep` does not claim (they are fetched by their consumer) cross the link
+        too, into a scratch slot, and are dropped -- nothing reads a non-keyframe of a fixed-cadence stream"""
+        if not self.upload_every_frame:
+            return
+        scratch = self.ring[-1:]
+        with torch.cuda.stream(self.stream):
+            for f in range(max(a, self._uploaded_upto), b):
+                if not keep(f):
+                    scratch.copy_(self.base[f % self.period][None], non_blocking=True)
+                    self.bytes_uploaded += scratch.numel()
+        self._uploaded_upto = max(self._uploaded_upto, b)
+
+    def event(self) -> torch.cuda.Event:
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    def __getitem__(self, key):           # untimed paths (prologue): a synchronous slice on the device
+        if isinstance(key, slice):
+            a = 0 if key.start is None else key.start
+            b = self.shape[0] if key.stop is None else key.stop
+            return torch.stack([self.base[f % self.period] for f in range(a, b)], 0).to(self.device)
+        return self.base[int(key) % self.period].to(self.device)
+
+
 class ShardedTracker:
     """Drives a replicated `Cut3rSlam` with window-sharded, batched, pipelined network inference."""
 
@@ -116,6 +173,7 @@ class ShardedTracker:
         self.replicate_depth = os.environ.get("CUT3R_REPLICATE_DEPTH", "0") == "1"
         self._chain = None
         self._f0 = 0
+        self._upload_ev = None            # frames from pinned host memory (PinnedFrames): the event behind the last upload + resize
         slam.tracked_only = True          # trajectory writers stop at the last TRACKED keyframe (the look-ahead registers more)
         self.stats = {"append_s": 0.0, "issue_s": 0.0, "issue_enc_s": 0.0, "replay_s": 0.0, "replay_wait_s": 0.0, "exchange_s": 0.0, "steps": 0}     # host wall-clock per phase
 
@@ -282,6 +340,20 @@ class ShardedTracker:
     def _append_range(self, frames, t, n_frames, kf_every, win, intr, first_t0):
         """register the keyframes among frames t..t+n_frames-1 (once: a look-ahead may already have done it)"""
         slam, world, rank, wb = self.slam, self.world, self.rank, self.wb
+        host = isinstance(frames, PinnedFrames)
+        if host:
+            # the recording lives in pinned host memory: a keyframe's pixels cross the link by an asynchronous copy on the upload stream
+            # and are resized there, straight into the keyframe store; the encoder pass that reads them waits for `_upload_ev`
+            frames.upload_range(max(t, self._appended_upto), t + n_frames, lambda f: f % kf_every == 0)
+        ctx = torch.cuda.stream(frames.stream) if host else contextlib.nullcontext()
+        with ctx:
+            self._append_frames(frames, t, n_frames, kf_every, win, intr, host)
+        if host:
+            self._upload_ev = frames.event()
+        self._appended_upto = max(self._appended_upto, t + n_frames)
+
+    def _append_frames(self, frames, t, n_frames, kf_every, win, intr, host):
+        slam, world, rank, wb = self.slam, self.world, self.rank, self.wb
         for f in range(max(t, self._appended_upto), t + n_frames):
             if f % kf_every == 0:
                 k = slam.keyframes.counter.value
@@ -292,8 +364,7 @@ class ShardedTracker:
                 o = k - self._f0
                 blk = (o - 1) // (win * wb) if o >= 1 else 0
                 mine = blk % world == rank or (o >= 1 and o % (win * wb) == 0 and (blk + 1) % world == rank)
-                self.append_fn(k, frames[f:f + 1] if mine else None, f, intr, mine)
-        self._appended_upto = max(self._appended_upto, t + n_frames)
+                self.append_fn(k, (frames.fetch(f) if host else frames[f:f + 1]) if mine else None, f, intr, mine)
 
     def step(self, frames, t, kf_every, win, intr):
         """Advance world*wb windows (= world*wb*win*kf_every frames).  Returns the new frame counter."""
@@ -328,6 +399,8 @@ class ShardedTracker:
             else:
                 if self._ahead is not None:      # a look-ahead pass for other windows may still be writing the feature store
                     torch.cuda.current_stream().wait_event(self._ahead[2])
+                if self._upload_ev is not None:  # host frames: this step's keyframes were uploaded + resized on the upload stream
+                    torch.cuda.current_stream().wait_event(self._upload_ev)
                 feats = self._encode(mine)
             self._ahead = None
             self.stats["issue_s"] += time.perf_counter() - tic
@@ -343,6 +416,8 @@ class ShardedTracker:
                 if self._enc_stream is None:
                     self._enc_stream = torch.cuda.Stream()      # default priority: raising either side's priority measured 15-20 % slower
                 self._enc_stream.wait_stream(torch.cuda.current_stream())      # the keyframe images were copied on this stream
+                if self._upload_ev is not None:                                # ... or, from pinned host memory, on the upload stream
+                    self._enc_stream.wait_event(self._upload_ev)
                 with torch.cuda.stream(self._enc_stream):
                     nf = self._encode(nxt_mine)
                     ev_enc = torch.cuda.Event()

@@ -223,6 +223,23 @@ class GaussianMap:
         self.theta.grad = None
 
     @torch.no_grad()
+    def step_like_reference(self, densified=False, reset=False, **kw):
+        """One optimiser step in the reference's order (gs_backend_per_frame.py:425-438, 564-577, 920-935, 1025-1041): densify_and_prune /
+        reset_opacity run BEFORE `optimizer.step()`, and both re-create `nn.Parameter`s (cat_tensors_to_optimizer, _prune_optimizer,
+        replace_tensor_to_optimizer: gaussian_model.py:488-560) whose `.grad` is then None -- so after a densification Adam skips EVERY group
+        (no update, no moment update, no step increment) and after an opacity reset it skips the opacity group."""
+        if densified:
+            return
+        if reset:
+            keep = self.theta.detach()[:, 6:7].clone()
+            self.step(**kw)
+            with torch.no_grad():
+                self.theta[:, 6:7] = keep
+                self.m[:, 6:7] = 0
+                self.v[:, 6:7] = 0
+            return
+        self.step(**kw)
+
     def step(self, b1=0.9, b2=0.999, eps=1e-15):
         g = self.theta.grad
         if g is None:
@@ -646,10 +663,11 @@ class GSMapper:
                     for vs, vis, radii in stats:
                         self.gaussians.max_radii2D = torch.max(self.gaussians.max_radii2D, radii.float() * vis)
                         self.gaussians.add_densification_stats(vs.grad, vis)
-                self.gaussians.step()
-                if densify and eager and it in (iters // 4, iters // 2):
+                dens = bool(densify and eager and it in (iters // 4, iters // 2))
+                if dens:
                     self.gaussians.densify_and_prune(self.config["opt_params"]["densify_grad_threshold"], self.gaussian_th, self.gaussian_extent,
                                                      self.size_threshold)
+                self.gaussians.step_like_reference(densified=dens)
             if opt is not None:
                 opt.step()
                 for v in views:
@@ -701,13 +719,15 @@ class GSMapper:
                     vis = pkg["visibility_filter"]
                     self.gaussians.max_radii2D = torch.max(self.gaussians.max_radii2D, pkg["radii"].float() * vis)
                     self.gaussians.add_densification_stats(pkg["viewspace_points"].grad, vis)
-                self.gaussians.step()
+                do_densify = do_reset = False
                 if iteration < 10000 and densify:
                     do_densify = (iteration == iteration_total // 2) if densify_every is not None else ((self.iteration_count + 1) % update_every == 0)
                     if do_densify:
                         self.gaussians.densify_and_prune(op["densify_grad_threshold"], self.gaussian_th, self.gaussian_extent, self.size_threshold)
-                    if (self.iteration_count + 1) % reset_every == 0 and opacity_reset:
+                    do_reset = bool((self.iteration_count + 1) % reset_every == 0 and opacity_reset)
+                    if do_reset:
                         self.gaussians.reset_opacity()
+                self.gaussians.step_like_reference(densified=do_densify, reset=do_reset)
                 if densify and "position_lr_final" in op:
                     # gs_backend_per_frame.py:1043-1044 calls update_learning_rate(iteration) on EVERY iteration of a densifying run (only
                     # the statistics / densify / reset above stop at 10000); gaussian_model.py:419-431, general_utils.py:41-56
@@ -761,10 +781,11 @@ class GSMapper:
                     vis = pkg["visibility_filter"]
                     self.gaussians.max_radii2D = torch.max(self.gaussians.max_radii2D, pkg["radii"].float() * vis)
                     self.gaussians.add_densification_stats(pkg["viewspace_points"].grad, vis)
-                self.gaussians.step()
-                if iteration > 1000 and (iteration + 1) % update_every == 0:
+                dens = iteration > 1000 and (iteration + 1) % update_every == 0
+                if dens:
                     self.gaussians.densify_and_prune(self.config["opt_params"]["densify_grad_threshold"], self.gaussian_th, self.gaussian_extent,
                                                      self.size_threshold)
+                self.gaussians.step_like_reference(densified=dens)
             last = loss.detach()
         self.gaussians.zero_grad()
         return float(last) if last is not None else None
@@ -921,8 +942,13 @@ class GSMapper:
         t = load_file(path, device=str(self.device))
         g = self.gaussians
         g.theta = t["theta"].requires_grad_(True)
-        g.m, g.v, g.step_count, g.kf_id = t["m"], t["v"], t["step_count"], t["kf_id"]
-        g.steps, g._steps_dev_stale = int(g.step_count.reshape(-1)[0]), False
+        g.m, g.v, g.kf_id = t["m"], t["v"], t["kf_id"]
+        # one Adam step count per block (a device scalar).  Older files carry one count per Gaussian ([P,1]) and an empty map carries none:
+        # take the largest count (0 for an empty map) and keep the one-element form the captured iteration increments in place
+        sc = t["step_count"].reshape(-1)
+        g.steps = int(sc.max()) if sc.numel() > 0 else 0
+        g.step_count = torch.full((1,), float(g.steps), dtype=g.m.dtype if g.m.is_floating_point() else torch.float32, device=g.m.device)
+        g._steps_dev_stale = False
         g.max_radii2D, g.grad_accum, g.denom = t["max_radii2D"], t["grad_accum"], t["denom"]
         g.grad_accum_abs = t["grad_accum_abs"] if "grad_accum_abs" in t else torch.zeros_like(g.grad_accum)
 

@@ -373,17 +373,29 @@ class FusedTrainer:
             if iteration < 10000 and densify:
                 check(lib.cut3r_gs_densify_stats(P, _p(self.radii), _p(self.d_means2D), _p(gm.max_radii2D), _p(gm.grad_accum), _p(gm.grad_accum_abs), _p(gm.denom), _s()),
                       "gs_densify_stats")
-            gm.steps += 1
-            gm._steps_dev_stale = True
-            b1, b2 = 0.9, 0.999
-            check(lib.cut3r_gs_adam(P * 14, _p(gm.theta), _p(gm.m), _p(gm.v), _p(self.gtheta), _p(gm.lr), b1, b2, 1 - b1 ** gm.steps, 1 - b2 ** gm.steps,
-                                    1e-15, _s()), "gs_adam")
+            # the reference's order (gs_backend_per_frame.py:1025-1041): densify_and_prune / reset_opacity come BEFORE optimizer.step() and
+            # re-create the parameters, whose .grad is then None: Adam skips every group after a densification (no update, no moment
+            # update, no step increment) and the opacity group after a reset (GaussianMap.step_like_reference)
+            do_densify = do_reset = False
             if iteration < 10000 and densify:
                 do_densify = (iteration == iteration_total // 2) if densify_every is not None else ((mp.iteration_count + 1) % update_every == 0)
                 if do_densify:
                     gm.densify_and_prune(op["densify_grad_threshold"], mp.gaussian_th, mp.gaussian_extent, mp.size_threshold)
-                if (mp.iteration_count + 1) % reset_every == 0 and opacity_reset:
+                do_reset = bool((mp.iteration_count + 1) % reset_every == 0 and opacity_reset)
+                if do_reset:
                     gm.reset_opacity()
+            if not do_densify:
+                keep = gm.theta.detach()[:, 6:7].clone() if do_reset else None
+                gm.steps += 1
+                gm._steps_dev_stale = True
+                b1, b2 = 0.9, 0.999
+                check(lib.cut3r_gs_adam(P * 14, _p(gm.theta), _p(gm.m), _p(gm.v), _p(self.gtheta), _p(gm.lr), b1, b2, 1 - b1 ** gm.steps, 1 - b2 ** gm.steps,
+                                        1e-15, _s()), "gs_adam")
+                if do_reset:
+                    with torch.no_grad():
+                        gm.theta[:, 6:7] = keep
+                        gm.m[:, 6:7] = 0
+                        gm.v[:, 6:7] = 0
             if densify and "position_lr_final" in op:
                 gm.lr[0, 0:3] = position_lr(op, iteration)
             check(lib.cut3r_gs_pose_step(_p(ps[k]), _p(sums[k]), 0.0, None, lr * 2, lr * 10, 1, _s()), "gs_pose_step")
@@ -439,11 +451,13 @@ class FusedTrainer:
             if iteration > 1000:
                 check(lib.cut3r_gs_densify_stats(P, _p(self.radii), _p(self.d_means2D), _p(gm.max_radii2D), _p(gm.grad_accum), _p(gm.grad_accum_abs), _p(gm.denom), _s()),
                       "gs_densify_stats")
-            gm.steps += 1
-            gm._steps_dev_stale = True
-            b1, b2 = 0.9, 0.999
-            check(lib.cut3r_gs_adam(P * 14, _p(gm.theta), _p(gm.m), _p(gm.v), _p(self.gtheta), _p(gm.lr), b1, b2, 1 - b1 ** gm.steps, 1 - b2 ** gm.steps,
-                                    1e-15, _s()), "gs_adam")
             if iteration > 1000 and (iteration + 1) % update_every == 0:
+                # (gs_backend_per_frame.py:920-935: densification first, then an optimizer.step() that finds no gradients)
                 gm.densify_and_prune(op["densify_grad_threshold"], mp.gaussian_th, mp.gaussian_extent, mp.size_threshold)
+            else:
+                gm.steps += 1
+                gm._steps_dev_stale = True
+                b1, b2 = 0.9, 0.999
+                check(lib.cut3r_gs_adam(P * 14, _p(gm.theta), _p(gm.m), _p(gm.v), _p(self.gtheta), _p(gm.lr), b1, b2, 1 - b1 ** gm.steps, 1 - b2 ** gm.steps,
+                                        1e-15, _s()), "gs_adam")
         return float(last) if last is not None else None

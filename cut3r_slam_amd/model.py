@@ -92,6 +92,11 @@ class Cut3rModel:
         self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "1") != "0"
         # windows per DPT-head pass of a view (the head's convolutions at the coarse pyramid levels have few output tiles)
         self.head_chunk = max(1, int(_os.environ.get("CUT3R_HEAD_CHUNK", "28")))      # measured at 28 windows: 8 -> 4806, 14 -> 4867, 28 -> 4932 frames/s
+        # LayerNorm folded into the GEMMs (round 4): the fp32 + residual projections (attn.proj, cross_attn.proj, mlp.fc2) also write an fp16
+        # copy of the residual stream and its per-row slab statistics; qkv / projq / projk|projv / fc1 read that copy through gamma-folded
+        # weights and normalise in their epilogue (include/cut3r_hip.h, cut3r_gemm_desc).  The LayerNorm launches in front of them
+        # disappear, except where the input has no producer GEMM (first encoder block, first decoder layer of a view, pose memory).
+        self.ln_fold = _os.environ.get("CUT3R_LN_FOLD", "1") != "0"
         self._head_stream = None
         self._side = None
         self._head_side = None
@@ -143,11 +148,25 @@ class Cut3rModel:
         def ln(name):
             self.w[name] = (f32(name + ".weight"), f32(name + ".bias"))
 
+        def fold(name, w, b, norm):
+            """LayerNorm `norm` folded into the Linear (w, b) that consumes it: y = LN(x) W^T + b = rstd (x (gamma.W)^T - mu c) + d with the
+            panel fp16(gamma . W), c_n = the row sums of THAT panel (so the constant part cancels exactly) and d = W beta + b"""
+            if not self.ln_fold or w.shape[1] % 64 or w.shape[0] % 4:
+                return
+            gam, bet = sd[norm + ".weight"].double(), sd[norm + ".bias"].double()
+            wd = w.double()
+            L = _Lin((wd * gam[None, :]).float(), None, dev)
+            L.b = (wd @ bet + b.double()).to(device=dev, dtype=F32).contiguous()
+            L.c = L.w.double().sum(1).to(F32).contiguous()
+            self.w[name + "@ln"] = L
+
         def enc_block(p):
             ln(p + ".norm1"); lin(p + ".attn.qkv"); lin(p + ".attn.proj"); ln(p + ".norm2")
             lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
+            fold(p + ".attn.qkv", sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"], p + ".norm1")
+            fold(p + ".mlp.fc1", sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"], p + ".norm2")
 
-        def dec_block(p):
+        def dec_block(p, folded=True):
             ln(p + ".norm1"); lin(p + ".attn.qkv"); lin(p + ".attn.proj")
             ln(p + ".norm2"); ln(p + ".norm3"); ln(p + ".norm_y")
             lin(p + ".cross_attn.projq"); lin(p + ".cross_attn.proj")
@@ -155,6 +174,11 @@ class Cut3rModel:
             bkv = torch.cat([sd[p + ".cross_attn.projk.bias"], sd[p + ".cross_attn.projv.bias"]], 0)
             self.w[p + ".cross_attn.projkv"] = _Lin(wkv, bkv, dev)
             lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
+            if folded:
+                fold(p + ".attn.qkv", sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"], p + ".norm1")
+                fold(p + ".cross_attn.projq", sd[p + ".cross_attn.projq.weight"], sd[p + ".cross_attn.projq.bias"], p + ".norm2")
+                fold(p + ".cross_attn.projkv", wkv, bkv, p + ".norm_y")
+                fold(p + ".mlp.fc1", sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"], p + ".norm3")
 
         self.w["patch_embed"] = _Lin(sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], dev)
         for i in range(cfg.enc_depth):
@@ -166,7 +190,7 @@ class Cut3rModel:
         ln("dec_norm"); ln("dec_norm_state")
         lin("pose_retriever.proj_q")
         for i in range(2):
-            dec_block(f"pose_retriever.write_blocks.{i}"); dec_block(f"pose_retriever.read_blocks.{i}")
+            dec_block(f"pose_retriever.write_blocks.{i}", False); dec_block(f"pose_retriever.read_blocks.{i}", False)
         self.pose_token = f32("pose_token").reshape(1, -1)
         self.masked_token = f32("pose_retriever.masked_token").reshape(1, -1)
         self.mem0 = f32("pose_retriever.mem").reshape(cfg.local_mem_size, -1)
@@ -240,14 +264,25 @@ class Cut3rModel:
         return t
 
     # ------------------------------------------------------------------ primitives
-    def _linear(self, x16, name, out, act=0, res1=None, res2=None, skinny=False, rope=None):
+    def _linear(self, x16, name, out, act=0, res1=None, res2=None, skinny=False, rope=None, ln=None, emit=None):
         """skinny: the operand has ONE row per independent sequence (pose token of a tracking window): weight-streaming
         kernel whose per-row result does not depend on how many windows are batched.
-        rope = (positions [B,N,2], cols): RoPE of the first `cols` output columns fused into the GEMM epilogue."""
-        L = self.w[name]
+        rope = (positions [B,N,2], cols): RoPE of the first `cols` output columns fused into the GEMM epilogue.
+        ln = slab statistics of the rows of `x16` (then x16 is the fp16 copy of the UN-normalised residual stream and the LayerNorm in front
+        of this Linear runs inside its epilogue through the folded panel `name@ln`); emit = (stats, x16) this GEMM writes for the next one."""
+        L = self.w[name + "@ln"] if ln is not None else self.w[name]
         if rope is not None:
             rope = (rope[0], rope[1], self.cfg.rope_freq, rope[2])
-        return ops.linear(x16, L.w, out, L.b, act, res1, res2, tile=16 if skinny else 0, rope=rope)
+        return ops.linear(x16, L.w, out, L.b, act, res1, res2, tile=16 if skinny else 0, rope=rope,
+                          ln=(ln, L.c, self.cfg.ln_eps) if ln is not None else None, emit=emit)
+
+    def _folded(self, name):
+        return self.ln_fold and (name + "@ln") in self.w
+
+    def _xs(self, tag, x):
+        """the fp16 copy + slab statistics that belong to the fp32 residual buffer `x` ([M,C], C % 64 == 0): (x16, stats [C/64, M, 2])"""
+        M, Cc = x.shape
+        return self.buf(tag + ".x16", (M, Cc), F16), self.buf(tag + ".xst", (Cc // 64, M, 2), F32)
 
     def _linear_pair(self, x0, name0, out0, x1, name1, out1, act=0, res0=None, res1=None):
         """the same projection of the state-side and the image-side decoder block in ONE launch (ops.linear_pair)"""
@@ -266,28 +301,29 @@ class Cut3rModel:
     def _rope(self, t, pos):
         ops.rope_2d_pair(t, pos, None, None, self.cfg.rope_freq, 1.0)
 
-    def _self_attn(self, tag, x_ln16, B, N, heads, pos, p, out, res):
-        """x_ln16 fp16 [B*N,C] -> out(fp32) = res + proj(attn(qkv(x)))"""
+    def _self_attn(self, tag, x_ln16, B, N, heads, pos, p, out, res, ln=None, emit=None):
+        """x_ln16 fp16 [B*N,C] -> out(fp32) = res + proj(attn(qkv(x))).  ln: x_ln16 is the UN-normalised fp16 copy and `ln` its slab
+        statistics (norm1 folded into qkv); emit: the projection also writes (stats, fp16 copy) of `out`."""
         Cc = x_ln16.shape[1]
         D = Cc // heads
         sk = N == 1
         qkv = self.buf(tag + ".qkv", (B * N, 3 * Cc), F16)
         fuse = (not sk) and self._fuse_rope(pos, D, B * N)
-        self._linear(x_ln16, p + ".qkv", qkv, skinny=sk, rope=(pos, 2 * Cc, D) if fuse else None)
+        self._linear(x_ln16, p + ".qkv", qkv, skinny=sk, rope=(pos, 2 * Cc, D) if fuse else None, ln=ln)
         v5 = qkv.view(B, N, 3, heads, D)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
         if pos is not None and not fuse:
             ops.rope_2d_pair(q, pos, k, pos, self.cfg.rope_freq, 1.0)
         a = self.buf(tag + ".attn", (B, N, heads, D), F16)
         ops.attention(q, k, v, a, D ** -0.5)
-        self._linear(a.view(B * N, Cc), p + ".proj", out, res1=res, skinny=sk)
+        self._linear(a.view(B * N, Cc), p + ".proj", out, res1=res, skinny=sk, emit=emit)
 
-    def _mlp(self, tag, x_ln16, p, out, res, skinny=False):
+    def _mlp(self, tag, x_ln16, p, out, res, skinny=False, ln=None, emit=None):
         M = x_ln16.shape[0]
         hdim = self.w[p + ".fc1"].npad
         h = self.buf(tag + ".mlp_h", (M, hdim), F16)
-        self._linear(x_ln16, p + ".fc1", h, act=1, skinny=skinny)
-        self._linear(h, p + ".fc2", out, res1=res, skinny=skinny)
+        self._linear(x_ln16, p + ".fc1", h, act=1, skinny=skinny, ln=ln)
+        self._linear(h, p + ".fc2", out, res1=res, skinny=skinny, emit=emit)
 
     # ------------------------------------------------------------------ encoder
     def _encode(self, img: torch.Tensor):
@@ -306,12 +342,21 @@ class Cut3rModel:
         y, xx = torch.meshgrid(torch.arange(nh, device=self.device), torch.arange(nw, device=self.device), indexing="ij")
         pos = torch.stack([y.reshape(-1), xx.reshape(-1)], -1)[None].expand(B, -1, -1).contiguous()
         ln16 = self.buf(tag + ".ln16", (M, E), F16)
+        fold = self._folded("enc_blocks.0.attn.qkv") and E % 64 == 0
+        x16, xst = self._xs(tag, x) if fold else (None, None)
+        em = (xst, x16) if fold else None
         for i in range(cfg.enc_depth):
             p = f"enc_blocks.{i}"
-            self._ln(x, p + ".norm1", out16=ln16)
-            self._self_attn(tag, ln16, B, N, cfg.enc_num_heads, pos, p + ".attn", x, x)
-            self._ln(x, p + ".norm2", out16=ln16)
-            self._mlp(tag, ln16, p + ".mlp", x, x)
+            if fold and i > 0:           # norm1 runs inside the qkv epilogue, on the copy + statistics the previous block's fc2 wrote
+                self._self_attn(tag, x16, B, N, cfg.enc_num_heads, pos, p + ".attn", x, x, ln=xst, emit=em)
+            else:
+                self._ln(x, p + ".norm1", out16=ln16)
+                self._self_attn(tag, ln16, B, N, cfg.enc_num_heads, pos, p + ".attn", x, x, emit=em)
+            if fold:                     # norm2 inside the fc1 epilogue
+                self._mlp(tag, x16, p + ".mlp", x, x, ln=xst, emit=em if i + 1 < cfg.enc_depth else None)
+            else:
+                self._ln(x, p + ".norm2", out16=ln16)
+                self._mlp(tag, ln16, p + ".mlp", x, x)
         feat = torch.empty((B, N, E), dtype=F32, device=self.device)
         feat16 = torch.empty((B, N, E), dtype=F16, device=self.device)
         self._ln(x, "enc_norm", out16=feat16.view(M, E), out32=feat.view(M, E))
@@ -371,10 +416,13 @@ class Cut3rModel:
         return feat, pos, im_shape
 
     # ------------------------------------------------------------------ decoder block
-    def _dec_block(self, tag, p, x, y, xpos, ypos, heads, out, B=1, pre_ln=False):
+    def _dec_block(self, tag, p, x, y, xpos, ypos, heads, out, B=1, pre_ln=False, xs=None, ys=None, os_=None):
         """x fp32 [B*Nx,C], y fp32 [B*Ny,C] -> out fp32 [B*Nx,C]   (dust3r/blocks.py:292-297).  B = independent
         sequences (tracking windows batched through the decoder).  pre_ln: norm1(x) and norm_y(y) are already in this
-        block's `.ln16` / `.y16` buffers (`_dual_norms`)."""
+        block's `.ln16` / `.y16` buffers (`_dual_norms`).
+        LayerNorm fold: xs / ys = (fp16 copy, slab statistics) of x / y as the GEMMs that produced them wrote them (norm1 and norm_y then run
+        inside the qkv / projk|projv epilogues); os_ = the pair that belongs to `out`: the three residual projections of this block write
+        it (norm2 -> projq and norm3 -> fc1 read it here, the next layer's norm1 / norm_y read what fc2 leaves)."""
         Cc = x.shape[1]
         Nx, Ny = x.shape[0] // B, y.shape[0] // B
         D = Cc // heads
@@ -383,30 +431,49 @@ class Cut3rModel:
         kv = self.buf(tag + ".kv", (B * Ny, 2 * Cc), F16)
         kv4 = kv.view(B, Ny, 2, heads, D)
         k, v = kv4[:, :, 0], kv4[:, :, 1]
+        if os_ is not None and not (Nx > 1 and self._folded(p + ".mlp.fc1")):
+            os_ = None
+        em = (os_[1], os_[0]) if os_ is not None else None          # (stats, fp16 copy) the residual projections write
+        if xs is not None and not (Nx > 1 and self._folded(p + ".attn.qkv")):
+            xs = None
+        if ys is not None and not (Ny > 1 and self._folded(p + ".cross_attn.projkv")):
+            ys = None
 
         def kv_branch():          # depends only on y (the other stream's previous layer): norm_y -> projk|projv -> RoPE(k)
-            if not pre_ln:
-                self._ln(y, p + ".norm_y", out16=y16)
             fuse_k = Ny > 1 and self._fuse_rope(ypos, D, B * Ny)
-            self._linear(y16, p + ".cross_attn.projkv", kv, skinny=(Ny == 1), rope=(ypos, Cc, D) if fuse_k else None)
+            if ys is not None:
+                self._linear(ys[0], p + ".cross_attn.projkv", kv, rope=(ypos, Cc, D) if fuse_k else None, ln=ys[1])
+            else:
+                if not pre_ln:
+                    self._ln(y, p + ".norm_y", out16=y16)
+                self._linear(y16, p + ".cross_attn.projkv", kv, skinny=(Ny == 1), rope=(ypos, Cc, D) if fuse_k else None)
             if ypos is not None and not fuse_k:
                 self._rope(k, ypos)
 
-        if not pre_ln:
-            self._ln(x, p + ".norm1", out16=ln16)
-        self._self_attn(tag, ln16, B, Nx, heads, xpos, p + ".attn", out, x)
-        self._ln(out, p + ".norm2", out16=ln16)
+        if xs is not None:
+            self._self_attn(tag, xs[0], B, Nx, heads, xpos, p + ".attn", out, x, ln=xs[1], emit=em)
+        else:
+            if not pre_ln:
+                self._ln(x, p + ".norm1", out16=ln16)
+            self._self_attn(tag, ln16, B, Nx, heads, xpos, p + ".attn", out, x, emit=em)
         q = self.buf(tag + ".q", (B, Nx, heads, D), F16)
         fuse_q = Nx > 1 and self._fuse_rope(xpos, D, B * Nx)
-        self._linear(ln16, p + ".cross_attn.projq", q.view(B * Nx, Cc), skinny=(Nx == 1), rope=(xpos, Cc, D) if fuse_q else None)
+        if os_ is not None:
+            self._linear(os_[0], p + ".cross_attn.projq", q.view(B * Nx, Cc), rope=(xpos, Cc, D) if fuse_q else None, ln=os_[1])
+        else:
+            self._ln(out, p + ".norm2", out16=ln16)
+            self._linear(ln16, p + ".cross_attn.projq", q.view(B * Nx, Cc), skinny=(Nx == 1), rope=(xpos, Cc, D) if fuse_q else None)
         if xpos is not None and not fuse_q:
             self._rope(q, xpos)
         kv_branch()      # (forking this onto its own capture stream was tried: nested forks crash hipGraph capture_end on ROCm 7.2)
         a = self.buf(tag + ".cattn", (B, Nx, heads, D), F16)
         ops.attention(q, k, v, a, D ** -0.5)
-        self._linear(a.view(B * Nx, Cc), p + ".cross_attn.proj", out, res1=out, skinny=(Nx == 1))
-        self._ln(out, p + ".norm3", out16=ln16)
-        self._mlp(tag, ln16, p + ".mlp", out, out, skinny=(Nx == 1))
+        self._linear(a.view(B * Nx, Cc), p + ".cross_attn.proj", out, res1=out, skinny=(Nx == 1), emit=em)
+        if os_ is not None:
+            self._mlp(tag, os_[0], p + ".mlp", out, out, ln=os_[1], emit=em)
+        else:
+            self._ln(out, p + ".norm3", out16=ln16)
+            self._mlp(tag, ln16, p + ".mlp", out, out, skinny=(Nx == 1))
         return out
 
     def _dec_layer_pair(self, l, a, s_a, b, s_b, pos_img, pos_state, Wn, fork=False):
@@ -658,6 +725,12 @@ class Cut3rModel:
         self._linear(self.register_tokens16, "decoder_embed_state", s0)
         st[0].view(Wn, S, D).copy_(s0[None].expand(Wn, -1, -1))
         im = [self.buf("dec.img0", (Wn * (N + 1), D), F32), self.buf("dec.img1", (Wn * (N + 1), D), F32)]
+        # LayerNorm fold: every residual buffer of the decoder has its fp16 copy + slab statistics, written by the GEMM that fills it
+        fold = self.ln_fold and D % 64 == 0 and self._folded("dec_blocks.0.attn.qkv")
+        xs_of = {}
+        if fold:
+            for t_, nm in ((st[0], "dec.state0"), (st[1], "dec.state1"), (im[0], "dec.img0"), (im[1], "dec.img1")):
+                xs_of[t_.data_ptr()] = self._xs(nm, t_)
         msz = self.mem0.shape[0]
         mem = [self.buf("dec.mem0", (Wn * msz, 2 * D), F32), self.buf("dec.mem1", (Wn * msz, 2 * D), F32)]
         mem[0].view(Wn, msz, 2 * D).copy_(self.mem0[None].expand(Wn, -1, -1))
@@ -702,27 +775,34 @@ class Cut3rModel:
             # re-initialises both, model.py:819-822): their final updates are skipped unless the caller asked for them
             dead_tail = (i == V - 1) and not return_taps
             for l in range(Ld):
+                # LayerNorm fold: from the second layer of a view on, the inputs of a layer were written by the previous layer's fc2 together
+                # with their fp16 copies and slab statistics (the first layer's inputs come from decoder_embed / the state carry: LayerNorm launches)
+                use_fold = fold and not self.pair_gemm
+                xa, xsa = (xs_of[a.data_ptr()], xs_of[s_a.data_ptr()]) if (use_fold and l > 0) else (None, None)
+                xb, xsb = (xs_of[b.data_ptr()], xs_of[s_b.data_ptr()]) if use_fold else (None, None)
                 if dead_tail and l == Ld - 1:
-                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn)
+                    self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, xs=xa, ys=xsa, os_=xb)
                     s_a, s_b = s_b, s_a
                     a, b = b, a
                     continue
                 if self.pair_gemm:
                     self._dec_layer_pair(l, a, s_a, b, s_b, pos_img, pos_state, Wn, fork=fork)
                 else:
-                    pre = self.dual_ln and D in (768, 1024, 1536)
+                    pre = self.dual_ln and D in (768, 1024, 1536) and xa is None
                     if pre:
                         self._dual_norms(l, a, s_a)
                     if fork:
                         cur = torch.cuda.current_stream()
                         self._side.wait_stream(cur)
                         with torch.cuda.stream(self._side):
-                            self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre)
-                        self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre)
+                            self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre,
+                                            xs=xsa, ys=xa, os_=xsb)
+                        self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre, xs=xa, ys=xsa, os_=xb)
                         cur.wait_stream(self._side)
                     else:
-                        self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre)
-                        self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre)
+                        self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre,
+                                        xs=xsa, ys=xa, os_=xsb)
+                        self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre, xs=xa, ys=xsa, os_=xb)
                 s_a, s_b = s_b, s_a
                 a, b = b, a
                 if l + 1 == h1 or l + 1 == h2:

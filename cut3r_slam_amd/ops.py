@@ -197,10 +197,15 @@ def rope_table(device, base, fwd=1.0, head_dim=64):
     return t
 
 
-def linear(A, W, out, bias=None, act=0, res1=None, res2=None, tile=0, rope=None):
+def linear(A, W, out, bias=None, act=0, res1=None, res2=None, tile=0, rope=None, ln=None, emit=None):
     """out[M,N] = act(A[M,K] @ W[N,K]^T + bias) (+res1)(+res2).  A,W fp16; out fp16|fp32 (any row stride).
     rope = (positions int64 [M,2] contiguous, cols, base[, head_dim = 64 | 48]): 2-D RoPE fused on the first `cols` columns
-    (48-wide heads use the 128 x 192 tile)."""
+    (48-wide heads use the 128 x 192 tile).
+    LayerNorm fold (include/cut3r_hip.h, cut3r_gemm_desc):
+      ln = (stats fp32 [K/64, M, 2] (slab-major), colsum fp32 [N], eps): A holds the UN-normalised rows (fp16 copy of the residual stream), W the
+           gamma-folded panel, bias the folded d; the epilogue normalises per row from the slab statistics;
+      emit = (stats_out fp32 [N/64, M, 2], out16 fp16 [M, N]): an fp32 + fp32-residual GEMM also writes the fp16 copy of its
+           output and the slab statistics the next consumer needs."""
     _cuda(A, W, out, bias, res1, res2)
     _req(A.dtype == F16 and W.dtype == F16 and A.dim() == 2 and W.dim() == 2, "A,W must be 2-D fp16")
     M, K = A.shape
@@ -231,6 +236,19 @@ def linear(A, W, out, bias=None, act=0, res1=None, res2=None, tile=0, rope=None)
         tab = rope_table(out.device, base, 1.0, hd)
         d.rope_pos, d.rope_table, d.rope_cols, d.rope_pmin, d.rope_npos = pos.data_ptr(), tab.data_ptr(), int(cols), ROPE_PMIN, ROPE_NPOS
         d.rope_d = hd
+    if ln is not None:
+        st, cs, eps = ln
+        _cuda(st, cs)
+        _req(K % 64 == 0 and st.dtype == F32 and st.is_contiguous() and st.numel() == M * (K // 64) * 2, f"ln stats fp32 [K/64={K // 64}, M={M}, 2]")
+        _req(cs.dtype == F32 and cs.is_contiguous() and cs.numel() == N and bias is not None and tile != 16, "ln colsum fp32 [N], folded bias required")
+        d.ln_stats, d.ln_colsum, d.ln_nslab, d.ln_eps = st.data_ptr(), cs.data_ptr(), K // 64, float(eps)
+    if emit is not None:
+        so, o16 = emit
+        _cuda(so, o16)
+        _req(N % 64 == 0 and so.dtype == F32 and so.is_contiguous() and so.numel() == M * (N // 64) * 2, f"stats_out fp32 [N/64={N // 64}, M={M}, 2]")
+        _req(o16.dtype == F16 and o16.shape == (M, N) and o16.stride(1) == 1, "out16 fp16 [M,N]")
+        _req(out.dtype == F32 and res1 is not None and res1.dtype == F32 and res2 is None and act == 0 and tile != 16, "emit: fp32 output with an fp32 residual")
+        d.stats_out, d.out16, d.ld16 = so.data_ptr(), o16.data_ptr(), o16.stride(0)
     lib = _lib.load()
     check(lib.cut3r_gemm_f16(C.byref(d), _stream()), f"cut3r_gemm_f16 M={M} N={N} K={K}")
     return out

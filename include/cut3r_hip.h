@@ -80,6 +80,22 @@ typedef struct cut3r_gemm_desc {
     const float* rope_table;
     int rope_cols, rope_pmin, rope_npos;
     int rope_d;           /* head dimension of the fused RoPE: 64 (default when 0) or 48 (forces the 128 x 192 tile) */
+    /* LayerNorm folded into the GEMMs (round 4; replaces the nn.LayerNorm in front of qkv / projq / projk|projv / fc1:
+     * croco/models/blocks.py:187-190, dust3r/blocks.py:292-297).  y = LN(x) W^T + b = rstd (x (gamma.W)^T - mu c) + d.
+     * CONSUMER: A = fp16 copy of the UN-normalised rows x, B = fp16(gamma . W), bias = d = W beta + b, ln_colsum = c
+     * (c_n = sum_k B_nk, fp32 [N]), ln_stats = fp32 [K/64][M][2] (slab-major): (sum, m2 = sum (x - sum/64)^2) of every 64-column
+     * slab of every row, ln_nslab = K/64, ln_eps = the LayerNorm's eps.  The row's slabs are combined in slab order (parallel
+     * variance), the raw accumulator becomes acc*rstd - (rstd*mu)*c_n, then the usual epilogue runs (bias, GELU, RoPE, fp16).
+     * PRODUCER: an fp32-output GEMM with an fp32 residual (the one that writes the residual stream) also stores out16 = fp16
+     * copy of its output rows (ld16) and stats_out = their slab statistics, fp32 [N/64][M][2] (N % 64 == 0), computed in one
+     * fixed order in every tile kernel.  Tiles 256 / 128 / 64 (producer), + 128 x 192 (consumer); not the skinny tile. */
+    const float* ln_stats;
+    const float* ln_colsum;
+    int ln_nslab;
+    float ln_eps;
+    float* stats_out;
+    void* out16;
+    int ld16;
 } cut3r_gemm_desc;
 int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream);
 /* table[0][p][q] = cos((pmin+p) * fwd / base^(q/Q)), table[1][p][q] = sin(...), q < Q = head_dim/4, p < npos: the angles

@@ -2,8 +2,9 @@
 against the CPU oracle.
 
 Tolerances (stated): GEMM/attention operands are fp16 with fp32 accumulation (the
-reference runs TF32), so token features agree to <= 1e-2 of their scale after the full stack, poses to <= 5e-3,
-pointmaps to <= 2e-2 relative to the map's scale (expm1 of the regressed norm amplifies relative error by ~|d|).
+reference runs TF32: the same 10-bit mantissa).  Since round 4 the golden test applies the TF32-budget rule of
+tests/test_precision_gpu.py against the reference's own outputs -- e_hip <= 2 e_tf32 + 2e-4 per output -- plus absolute caps of
+3 x the measured errors (CAP below); the u8 / minimal / oracle tests keep absolute bounds of the same size.
 """
 import json
 import os
@@ -37,26 +38,53 @@ def _check(name, got, ref, tol, log, mask=None):
     assert e <= tol, "\n".join(log)
 
 
+# absolute caps of the golden test = 3 x the errors measured on MI355X (round 4, `pytest -s`: profiles/r04/achieved_errors.txt), per output
+# class, next to the TF32-budget rule below.  (Rounds 1-3 allowed 5e-3 / 1e-2 / 2e-2: a regression that tripled the error passed.)
+CAP = {"model_tiny_dpt": {"enc_feat": 1.5e-3, "state": 2.5e-3, "mem": 2.5e-3, "camera_pose": 4e-3, "pts": 6e-3, "conf": 4e-3, "rgb": 4e-3},
+       "model_tiny_linear": {"enc_feat": 1.5e-3, "state": 2.5e-3, "mem": 2.5e-3, "camera_pose": 4e-3, "pts": 6e-3, "conf": 4e-3, "rgb": 4e-3},
+       "model_medium_dpt": {"enc_feat": 2e-3, "state": 2.5e-3, "mem": 2.5e-3, "camera_pose": 6e-3, "pts": 8e-3, "conf": 4e-3, "rgb": 4e-3}}
+
+
+def _cls(k):
+    return "camera_pose" if k == "camera_pose" else "rgb" if k == "rgb" else "conf" if k.startswith("conf") else "pts"
+
+
 @pytest.mark.parametrize("name", ["model_tiny_dpt", "model_tiny_linear", "model_medium_dpt"])
 def test_model_matches_reference_golden(name):
+    """every output of the network against the REFERENCE's own outputs (tests/golden/*.npz), under the TF32-budget rule of
+    tests/test_precision_gpu.py: with e_x = max|x - reference| / max|reference|,  e_hip <= 2 e_tf32 + 2e-4  where e_tf32 is the error of the CPU
+    restatement run with TF32-rounded operands (the reference's own arithmetic on its GPUs: src/croco/models/croco.py:13) against the same
+    reference outputs -- plus the absolute caps above."""
     f = np.load(os.path.join(GOLD, name + ".npz"))
     cfg = Cut3rConfig.from_dict(json.loads(bytes(f["config_json"]).decode()))
     sd = synth_state_dict(cfg, int(f["seed"]))
     model = Cut3rModel(cfg, sd, DEV, minimal=False)
     imgs = torch.from_numpy(f["imgs"])
-    log = []
+    x = O.normalize(imgs)
+    with O.matmul_precision("tf32"):
+        tf_feat, _ = O.encode_image(cfg, sd, x[:1])
+        tf_preds, tf_states = O.forward_views(cfg, sd, x, minimal=False, return_states=True)
+    log, cap = [], CAP[name]
+
+    def check(tag, got, tf, ref, c, mask=None):
+        got, tf, ref = (torch.as_tensor(t).float().cpu() for t in (got, tf, ref))
+        if mask is not None:
+            got, tf, ref = got[mask], tf[mask], ref[mask]
+        e_hip, e_tf = _relerr(got, ref), _relerr(tf, ref)
+        log.append(f"{tag}: hip {e_hip:.2e} tf32 {e_tf:.2e} (cap {cap[c]:.1e})")
+        assert e_hip <= cap[c] and e_hip <= 2.0 * e_tf + 2e-4, "\n".join(log)
+
     feat, pos, _ = model.encode_image({"img": model.normalize(imgs[:1].float()).to(DEV)})
     torch.cuda.synchronize()
     assert torch.equal(pos.cpu(), torch.from_numpy(f["enc_pos0"]))
-    _check("enc_feat", feat, f["enc_feat0"], 5e-3, log)
+    check("enc_feat", feat, tf_feat, f["enc_feat0"], "enc_feat")
     preds, taps = model.forward_window(model.normalize(imgs.float()).to(DEV), return_taps=True)
     torch.cuda.synchronize()
-    for i, (s, m) in enumerate(taps["states"]):
-        _check(f"state{i+1}", s[None], f[f"state{i+1}_feat"], 1e-2, log)
-        _check(f"mem{i+1}", m[None], f[f"state{i+1}_mem"], 1e-2, log)
+    for i, (st, m) in enumerate(taps["states"]):
+        check(f"state{i+1}", st[None], tf_states[i + 1][0], f[f"state{i+1}_feat"], "state")
+        check(f"mem{i+1}", m[None], tf_states[i + 1][1], f[f"state{i+1}_mem"], "mem")
     for i, p in enumerate(preds):
         for k, v in p.items():
-            tol = 5e-3 if k == "camera_pose" else 2e-2
             mask = None
             if cfg.head_type == "linear" and k == "pts3d_in_self_view":
                 # pos_z (linear_head.py:316) multiplies xyz by sign(z): a pixel whose regressed z is ~0 flips sign under
@@ -64,9 +92,9 @@ def test_model_matches_reference_golden(name):
                 r = torch.from_numpy(f[f"pred{i}_{k}"])
                 mask = (r[..., 2] > 0.03 * r.abs().max())
                 assert mask.float().mean() > 0.8
-            _check(f"pred{i}.{k}", v, f[f"pred{i}_{k}"], tol, log, mask)
+            check(f"pred{i}.{k}", v, tf_preds[i][k], f[f"pred{i}_{k}"], _cls(k), mask)
         assert set(p) == {"camera_pose", "pts3d_in_self_view", "conf_self", "rgb", "pts3d_in_other_view", "conf"}
-    print("\n".join(log))
+    print(f"[golden {name}] " + " | ".join(log))
 
 
 def test_u8_input_and_minimal_mode_and_reference_forward_api():
@@ -80,12 +108,12 @@ def test_u8_input_and_minimal_mode_and_reference_forward_api():
     for i, p in enumerate(preds):
         assert set(p) == {"camera_pose", "pts3d_in_self_view", "conf_self"}
         for k, v in p.items():
-            _check(f"u8 pred{i}.{k}", v, f[f"pred{i}_{k}"], 2e-2, log)
+            _check(f"u8 pred{i}.{k}", v, f[f"pred{i}_{k}"], 4e-3 if k == "camera_pose" else 6e-3, log)
     from cut3r_slam_amd.inference import inference
     from cut3r_slam_amd.track_frontend import make_views
     out, _ = inference(make_views(model, imgs), model, DEV)
     for i, p in enumerate(out["pred"]):
-        _check(f"inference() pred{i}", p["pts3d_in_self_view"], f[f"pred{i}_pts3d_in_self_view"], 2e-2, log)
+        _check(f"inference() pred{i}", p["pts3d_in_self_view"], f[f"pred{i}_pts3d_in_self_view"], 6e-3, log)
 
 
 def test_medium_config_head_dims_48_64_vs_oracle():
@@ -102,10 +130,10 @@ def test_medium_config_head_dims_48_64_vs_oracle():
     torch.cuda.synchronize()
     log = []
     for i in range(4):
-        _check(f"state{i+1}", taps["states"][i][0][None], ref_states[i + 1][0], 1e-2, log)
-        _check(f"pose{i}", preds[i]["camera_pose"], ref[i]["camera_pose"], 5e-3, log)
-        _check(f"pts{i}", preds[i]["pts3d_in_self_view"], ref[i]["pts3d_in_self_view"], 2e-2, log)
-        _check(f"conf{i}", preds[i]["conf_self"], ref[i]["conf_self"], 2e-2, log)
+        _check(f"state{i+1}", taps["states"][i][0][None], ref_states[i + 1][0], 2.5e-3, log)      # 3 x measured (7e-4 ... 8e-4)
+        _check(f"pose{i}", preds[i]["camera_pose"], ref[i]["camera_pose"], 6e-3, log)              # measured 2.0e-3
+        _check(f"pts{i}", preds[i]["pts3d_in_self_view"], ref[i]["pts3d_in_self_view"], 8e-3, log)  # measured 2.5e-3
+        _check(f"conf{i}", preds[i]["conf_self"], ref[i]["conf_self"], 4e-3, log)                  # measured 1.3e-3
     print("\n".join(log))
 
 
