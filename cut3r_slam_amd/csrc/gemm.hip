@@ -54,6 +54,18 @@ __device__ __attribute__((aligned(16))) unsigned char g_zero16[16];
 
 template <int N>
 DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until all but the youngest `fl` K-tiles (NL LDS-DMA instructions each) have landed; fl <= MAXF (the ring depth minus two)
+template <int NL, int MAXF>
+DEVINL void wait_tiles_in_flight(int fl) {
+    static_assert(MAXF * NL <= 63, "vmcnt is a 6-bit counter");
+    if constexpr (MAXF >= 6) { if (fl >= 6) { wait_vmcnt<6 * NL>(); return; } }
+    if constexpr (MAXF >= 5) { if (fl == 5) { wait_vmcnt<5 * NL>(); return; } }
+    if constexpr (MAXF >= 4) { if (fl == 4) { wait_vmcnt<4 * NL>(); return; } }
+    if constexpr (MAXF >= 3) { if (fl == 3) { wait_vmcnt<3 * NL>(); return; } }
+    if constexpr (MAXF >= 2) { if (fl == 2) { wait_vmcnt<2 * NL>(); return; } }
+    if constexpr (MAXF >= 1) { if (fl == 1) { wait_vmcnt<NL>(); return; } }
+    wait_vmcnt<0>();
+}
 
 // Fused output of 4 consecutive columns (gn..gn+3) of row gm: bias, GELU|ReLU, up to two residuals, fp16|fp32 store,
 // optional ConvTranspose pixel-shuffle scatter.  Shared by every GEMM kernel of this file.  The residual operands are
@@ -420,11 +432,11 @@ DEVINL void gemm_tile_body(const GemmArgs& g, const int bx, const int by, const 
     const int fr = lane & 15, fq = lane >> 4;   // fragment row, k-chunk
     int stage = 0;
     for (int t = 0; t < nt; t++) {
-        // tiles that may stay in flight behind tile t: min(NSTAGE-2, nt-1-t)
+        // tiles that may stay in flight behind tile t: min(NSTAGE-2, nt-1-t) -- the whole ring depth is used (round 4: at one window the
+        // 64 x 64 launches are bound by the HBM latency of their weight panels with only two K-tiles in flight)
         const int ahead = nt - 1 - t;
-        if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<2 * NL>();
-        else if (NSTAGE >= 3 && ahead >= 1) wait_vmcnt<NL>();
-        else wait_vmcnt<0>();
+        constexpr int MAXF = NSTAGE - 2 > 6 ? 6 : NSTAGE - 2;
+        wait_tiles_in_flight<NL, MAXF>(ahead < MAXF ? ahead : MAXF);
         __builtin_amdgcn_s_barrier();
         if (t + NSTAGE - 1 < nt) {
             int st2 = stage + NSTAGE - 1;
@@ -644,10 +656,10 @@ static int tile_addr_mode(const GemmArgs& g) {
 // (src/dust3r/model.py:669-692: both blocks of a layer read the previous layer's pair, so they are independent).  One launch
 // of 2 x 294 tiles fills the chip where two launches of 294 tiles each leave 43 % of the workgroup slots empty.
 struct GemmPairArgs { GemmArgs p[2]; int nblk0; };
-template <int BM, int BN, int NSTAGE, int WAVES_M = 2, int WAVES_N = 2>
+template <int BM, int BN, int NSTAGE, int WAVES_M = 2, int WAVES_N = 2, int ADDR = 0, int EPI = 0>
 __global__ CUT3R_TILE_BOUNDS void gemm_pair_kernel(const GemmPairArgs a) {
     const int sel = (int)blockIdx.x >= a.nblk0 ? 1 : 0;
-    gemm_tile_body<BM, BN, NSTAGE, WAVES_M, WAVES_N>(a.p[sel], blockIdx.x - sel * a.nblk0, 0, 0);
+    gemm_tile_body<BM, BN, NSTAGE, WAVES_M, WAVES_N, ADDR, EPI>(a.p[sel], blockIdx.x - sel * a.nblk0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1627,7 +1639,11 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
             const int am = d->stages == 0 ? tile_addr_mode(g) : 0;
             const int ep = am == 1 ? gemm256_epi_mode(g) : 0;
             if (g.stats_out && ep != 3) return CUT3R_ERR_ARG;
-            if (ep == 3) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4, 1, 3>), grid, dim3(512), 0, s, g);     // fc2 + residual at one window
+            // ring depth (CUT3R_GEMM64_STAGES): these launches put <= 2 workgroups on a CU and wait on HBM for their weight panels
+            static const int ns8 = [] { const char* e = getenv("CUT3R_GEMM64_STAGES"); return e ? atoi(e) : 3; }();
+            if (ep == 3 && ns8 == 6) hipLaunchKernelGGL((gemm_kernel<64, 64, 6, 2, 4, 1, 3>), grid, dim3(512), 0, s, g);
+            else if (ep == 3 && ns8 == 4) hipLaunchKernelGGL((gemm_kernel<64, 64, 4, 2, 4, 1, 3>), grid, dim3(512), 0, s, g);
+            else if (ep == 3) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4, 1, 3>), grid, dim3(512), 0, s, g);     // fc2 + residual at one window
             else if (am == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4, 1>), grid, dim3(512), 0, s, g);
             else if (am == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4, 2>), grid, dim3(512), 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 4>), grid, dim3(512), 0, s, g);
@@ -1638,10 +1654,18 @@ extern "C" int cut3r_gemm_f16(const cut3r_gemm_desc* d, void* stream) {
             // compile-time epilogues for the one-window (M = 769) Linear layers: fp16 + bias, + GELU, fp32 + bias + fp32 residual
             const int ep = am == 1 ? gemm256_epi_mode(g) : 0;
             if (g.stats_out && ep != 3) return CUT3R_ERR_ARG;
-            if (ep == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 1, 1>), grid, dim3(256), 0, s, g);
-            else if (ep == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 1, 2>), grid, dim3(256), 0, s, g);
-            else if (ep == 3) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 1, 3>), grid, dim3(256), 0, s, g);
-            else if (am == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 1>), grid, dim3(256), 0, s, g);
+            static const int ns4 = [] { const char* e = getenv("CUT3R_GEMM64_STAGES"); return e ? atoi(e) : 3; }();
+#define CUT3R_T64(NS)                                                                                                   \
+    do {                                                                                                                 \
+        if (ep == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, NS, 2, 2, 1, 1>), grid, dim3(256), 0, s, g);                \
+        else if (ep == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, NS, 2, 2, 1, 2>), grid, dim3(256), 0, s, g);           \
+        else if (ep == 3) hipLaunchKernelGGL((gemm_kernel<64, 64, NS, 2, 2, 1, 3>), grid, dim3(256), 0, s, g);           \
+        else hipLaunchKernelGGL((gemm_kernel<64, 64, NS, 2, 2, 1>), grid, dim3(256), 0, s, g);                           \
+    } while (0)
+            if (am == 1 && ns4 == 6) CUT3R_T64(6);
+            else if (am == 1 && ns4 == 4) CUT3R_T64(4);
+            else if (am == 1) CUT3R_T64(3);
+#undef CUT3R_T64
             else if (am == 2) hipLaunchKernelGGL((gemm_kernel<64, 64, 3, 2, 2, 2>), grid, dim3(256), 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<64, 64, 3>), grid, dim3(256), 0, s, g);
         }
@@ -1658,20 +1682,46 @@ extern "C" int cut3r_gemm_f16_pair(const cut3r_gemm_desc* d0, const cut3r_gemm_d
     if (rc != CUT3R_OK) return rc;
     rc = fill_args(d1, a.p[1]);
     if (rc != CUT3R_OK) return rc;
-    // plain linears only, one problem each (no batch), same N and K so both take the same tile kernel
+    // linears only, one problem each (no batch), same N and K so both take the same tile kernel
     for (const cut3r_gemm_desc* d : {d0, d1})
-        if (d->conv_k == 3 || d->shuf || d->relu_in || (d->rope_pos && d->rope_cols) || (d->batch > 1) || d->ln_stats || d->stats_out) return CUT3R_ERR_ARG;
+        if (d->conv_k == 3 || d->shuf || d->relu_in || (d->batch > 1)) return CUT3R_ERR_ARG;
     if (d0->N != d1->N || d0->K != d1->K) return CUT3R_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    const bool special = d0->ln_stats || d1->ln_stats || d0->stats_out || d1->stats_out || a.p[0].rope_cols || a.p[1].rope_cols;
     // tile choice on the COMBINED grid (the two problems fill the chip together)
     int tile = d0->tile;
     if (tile == 0) {
         const long long t256 = (long long)((d0->M + 255) / 256 + (d1->M + 255) / 256) * ((d0->N + 255) / 256);
         const long long rounds = (t256 + 255) / 256;
         const bool fills = rounds == 1 || t256 * 100 >= rounds * 256 * 85;
-        tile = ((d0->N & 255) == 0 && t256 >= 128 && fills) ? 256 : 128;
+        const long long t128 = (long long)((d0->M + 127) / 128 + (d1->M + 127) / 128) * ((d0->N + 127) / 128);
+        tile = ((d0->N & 255) == 0 && t256 >= 128 && fills && !special) ? 256 : ((t128 >= 128 && !special) ? 128 : 64);
     }
-    if (tile == 256) {
+    if (special && tile != 64) return CUT3R_ERR_ARG;          // fused RoPE / LayerNorm fold ride the 64 x 64 pair kernels (the one-window schedule)
+    if (tile == 64) {
+        // the one-window (M = 768 / 769) decoder: state-side + image-side projection of a layer in ONE launch of 2 x 156 tiles.  Compile-time
+        // epilogue when both problems qualify for the same one (fc1: 2, residual projections: 3 -- also the LayerNorm fold's producer), else
+        // the run-time epilogue (fused RoPE of the image side next to the plain state side; LayerNorm fold consumer in either).
+        const int n0 = ((d0->N + 63) / 64) * ((d0->M + 63) / 64), n1 = ((d1->N + 63) / 64) * ((d1->M + 63) / 64);
+        a.nblk0 = n0;
+        a.p[0].swz = a.p[1].swz = 1;             // 1-D grid: tile (pid_m, pid_n) from the XCD-aware rasterisation of each problem
+        const bool am = tile_addr_mode(a.p[0]) == 1 && tile_addr_mode(a.p[1]) == 1;
+        const int e0 = gemm256_epi_mode(a.p[0]), e1 = gemm256_epi_mode(a.p[1]);
+        const int ep = (am && e0 == e1 && (e0 == 1 || e0 == 2 || e0 == 3)) ? e0 : 0;
+        if ((d0->stats_out || d1->stats_out) && ep != 3) return CUT3R_ERR_ARG;
+        const dim3 grid(n0 + n1);
+        if (d0->K >= 2048) {
+            if (ep == 3) hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 3, 2, 4, 1, 3>), grid, dim3(512), 0, s, a);
+            else if (am) hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 3, 2, 4, 1, 0>), grid, dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 3, 2, 4, 0, 0>), grid, dim3(512), 0, s, a);
+        } else {
+            if (ep == 1) hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 3, 2, 2, 1, 1>), grid, dim3(256), 0, s, a);
+            else if (ep == 2) hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 3, 2, 2, 1, 2>), grid, dim3(256), 0, s, a);
+            else if (ep == 3) hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 3, 2, 2, 1, 3>), grid, dim3(256), 0, s, a);
+            else if (am) hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 3, 2, 2, 1, 0>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 3, 2, 2, 0, 0>), grid, dim3(256), 0, s, a);
+        }
+    } else if (tile == 256) {
         const int n0 = ((d0->N + 255) / 256) * ((d0->M + 255) / 256), n1 = ((d1->N + 255) / 256) * ((d1->M + 255) / 256);
         a.nblk0 = n0;
         hipLaunchKernelGGL(gemm256_pair_kernel, dim3(n0 + n1), dim3(512), 0, s, a);

@@ -82,11 +82,17 @@ class Cut3rModel:
         # launches are 30-40 % faster than the two launches they replace, but they join the two blocks at every projection, and
         # the step loses the overlap of one block's MFMA-bound GEMMs with the other block's VALU-bound attention / LayerNorm
         self.pair_gemm = _os.environ.get("CUT3R_PAIR_GEMM", "0") != "0"
+        # The one-window schedule (round 4) was measured with a layer as pair launches on the 64 x 64 pair kernels (`_dec_layer_pair`, with the
+        # LayerNorm fold and the fused RoPE): 24.5 vs 23.6 ms per window -- slower as well.  A one-window launch costs ~6.5 us before its
+        # first K-tile whatever its size (a + b K fit of the kernel trace), so fewer, fuller launches only help if the chain gets shorter,
+        # and the pair form joins the two blocks seven times per layer.  `pair_rows` > 0 turns the pair form on below that many rows.
+        self.pair_rows = int(_os.environ.get("CUT3R_PAIR_ROWS", "0"))
         # RoPE in the q/k projection epilogue: 0 off, 1 heads of 64 (default), 2 also heads of 48.  Bit-identical to the stand-alone
         # kernel.  Through the run-time epilogue of round 1 it lost 2.5 % end to end; as a compile-time epilogue of the 256x256 kernel
         # (a wave's 64-column slab is one head) it gains 1.0 % (5703 -> 5761 frames/s, interleaved runs); 48-wide heads straddle the
         # slabs and keep the stand-alone launch
         self.fused_rope = int(_os.environ.get("CUT3R_FUSED_ROPE", "1"))      # RoPE in the q/k projection epilogue (D = 64)
+        self.rope48_rows = int(_os.environ.get("CUT3R_ROPE48_ROWS", "0"))     # 48-wide heads: fused below this many GEMM rows (0: never -- measured round 4 at one window: 28.4 vs 23.7 ms per window, the 128 x 192 tile puts 72 workgroups on 256 CUs)
         # DPT head of view i (all windows) on a third stream while the recurrent decoder works on view i+1: the decoder's
         # mid-size kernels leave matrix and memory pipes idle that the head's large convolutions can use
         self.head_overlap = _os.environ.get("CUT3R_HEAD_OVERLAP", "1") != "0"
@@ -284,14 +290,26 @@ class Cut3rModel:
         M, Cc = x.shape
         return self.buf(tag + ".x16", (M, Cc), F16), self.buf(tag + ".xst", (Cc // 64, M, 2), F32)
 
-    def _linear_pair(self, x0, name0, out0, x1, name1, out1, act=0, res0=None, res1=None):
-        """the same projection of the state-side and the image-side decoder block in ONE launch (ops.linear_pair)"""
-        L0, L1 = self.w[name0], self.w[name1]
-        ops.linear_pair((x0, L0.w, out0, L0.b, res0), (x1, L1.w, out1, L1.b, res1), act)
+    def _linear_pair(self, x0, name0, out0, x1, name1, out1, act=0, res0=None, res1=None, ex0=None, ex1=None):
+        """the same projection of the state-side and the image-side decoder block in ONE launch (ops.linear_pair); ex = per-problem extras:
+        rope = (pos, cols, D) fused RoPE, ln = slab statistics (the operand is then the un-normalised fp16 copy, folded panel `name@ln`),
+        emit = (stats, fp16 copy) the projection writes"""
+        def prob(x, name, out, res, ex):
+            ex = dict(ex or {})
+            L = self.w[name + "@ln"] if ex.get("ln") is not None else self.w[name]
+            if ex.get("ln") is not None:
+                ex["ln"] = (ex["ln"], L.c, self.cfg.ln_eps)
+            if ex.get("rope") is not None:
+                r = ex["rope"]
+                ex["rope"] = (r[0], r[1], self.cfg.rope_freq, r[2])
+            return (x, L.w, out, L.b, res, {k: v for k, v in ex.items() if v is not None})
+        ops.linear_pair(prob(x0, name0, out0, res0, ex0), prob(x1, name1, out1, res1, ex1), act)
 
     def _fuse_rope(self, pos, D, rows):
-        """the GEMM-fused RoPE covers head dimension 64 with one position row per GEMM row"""
-        dims = (64, 48) if self.fused_rope == 2 else (64,)
+        """the GEMM-fused RoPE covers head dimension 64 with one position row per GEMM row; 48-wide heads (the state side of the decoder)
+        need the 128 x 192 tile, which loses to the 256 x 256 kernel + a RoPE launch on large batches (round 3: -3 % end to end at 28
+        windows) but shortens the launch chain of the one-window schedule, where every launch is latency: fused up to `rope48_rows` rows"""
+        dims = (64, 48) if (self.fused_rope == 2 or (self.fused_rope and rows <= self.rope48_rows)) else (64,)
         return self.fused_rope and pos is not None and D in dims and pos.is_contiguous() and pos.numel() == 2 * rows
 
     def _ln(self, x, name, out16=None, out32=None, mod=None):
@@ -476,12 +494,16 @@ class Cut3rModel:
             self._mlp(tag, ln16, p + ".mlp", out, out, skinny=(Nx == 1))
         return out
 
-    def _dec_layer_pair(self, l, a, s_a, b, s_b, pos_img, pos_state, Wn, fork=False):
+    def _dec_layer_pair(self, l, a, s_a, b, s_b, pos_img, pos_state, Wn, fork=False, xs=None, os_=None):
         """Decoder layer l for BOTH streams: image block (a, s_a) -> b and state block (s_a, a) -> s_b (model.py:669-692, both
         read the previous layer's pair).  The seven projections of a block run as seven PAIR launches (state + image problem in
-        one grid, ops.linear_pair); LayerNorm / RoPE / attention stay per side (different token counts and head widths: 16 x 48
+        one grid, ops.linear_pair); RoPE of the 48-wide state heads / attention stay per side (different token counts and head widths: 16 x 48
         state heads, 12 x 64 image heads) and, under graph capture with `fork`, on two streams.  Same kernels and row arithmetic as
-        `_dec_block`: bit-identical results."""
+        `_dec_block`: bit-identical results.
+        This is the ONE-WINDOW schedule's form of a layer (round 4): at M = 768 / 769 rows every launch is latency, the two capture streams of
+        `_dec_block` overlap poorly (kernel trace: one kernel running 59 % of the time, two 34 %), and one launch of 2 x 156 tiles of 64 x 64
+        fills the 256 CUs where each problem alone leaves 100 idle.  xs = ((a16, a_stats), (s16, s_stats)) | None and os_ likewise for
+        (b, s_b): the LayerNorm fold (norm1 / norm_y / norm2 / norm3 inside the projections' epilogues)."""
         cfg = self.cfg
         Cc = a.shape[1]
         ps, pi = f"dec_blocks_state.{l}", f"dec_blocks.{l}"
@@ -500,6 +522,16 @@ class Cut3rModel:
             sd["kv"] = self.buf(t + ".kv", (Wn * Ny, 2 * Cc), F16)
             sd["catt"] = self.buf(t + ".cattn", (Wn, Nx, h, D), F16)
             sd["h"] = self.buf(t + ".mlp_h", (Wn * Nx, self.w[sd["p"] + ".mlp.fc1"].npad), F16)
+        fold_in = xs is not None and self._folded(pi + ".attn.qkv") and self._folded(ps + ".attn.qkv")
+        fold_out = os_ is not None and self._folded(pi + ".mlp.fc1") and self._folded(ps + ".mlp.fc1")
+        if fold_in:
+            (I["x16"], I["xst"]), (S["x16"], S["xst"]) = xs          # image tokens a, state tokens s_a
+        if fold_out:
+            (I["o16"], I["ost"]), (S["o16"], S["ost"]) = os_
+        em = (lambda sd: {"emit": (sd["ost"], sd["o16"])}) if fold_out else (lambda sd: None)
+        # fused RoPE where the head width is 64 and the tokens have a position row each
+        small = Wn * max(Ni, Ns) <= self.pair_rows          # the 64 x 64 pair kernels carry the fused RoPE / the fold; large batches run plain pairs
+        fr = lambda pos, D, rows: bool(small and self.fused_rope and pos is not None and D == 64 and pos.is_contiguous() and pos.numel() == 2 * rows)
 
         def both(fn):
             """fn(side) for the state and the image side; on two capture streams when forking"""
@@ -514,38 +546,63 @@ class Cut3rModel:
                 fn(S)
                 fn(I)
 
-        if self.dual_ln and Cc in (768, 1024, 1536):
-            self._dual_norms(l, a, s_a)
-        else:
-            both(lambda sd: (self._ln(sd["x"], sd["p"] + ".norm1", out16=sd["ln16"]), self._ln(sd["y"], sd["p"] + ".norm_y", out16=sd["y16"])))
+        if not fold_in:
+            if self.dual_ln and Cc in (768, 1024, 1536):
+                self._dual_norms(l, a, s_a)
+            else:
+                both(lambda sd: (self._ln(sd["x"], sd["p"] + ".norm1", out16=sd["ln16"]), self._ln(sd["y"], sd["p"] + ".norm_y", out16=sd["y16"])))
         # ---- self attention
-        self._linear_pair(S["ln16"], ps + ".attn.qkv", S["qkv"], I["ln16"], pi + ".attn.qkv", I["qkv"])
+        for sd in (S, I):
+            sd["fq"] = fr(sd["xpos"], sd["D"], Wn * sd["Nx"])
+            sd["fk"] = fr(sd["ypos"], sd["D"], Wn * sd["Ny"])
+        ex = lambda sd: {"rope": (sd["xpos"], 2 * Cc, sd["D"]) if sd["fq"] else None, "ln": sd["xst"] if fold_in else None}
+        self._linear_pair(S["x16"] if fold_in else S["ln16"], ps + ".attn.qkv", S["qkv"], I["x16"] if fold_in else I["ln16"], pi + ".attn.qkv", I["qkv"],
+                          ex0=ex(S), ex1=ex(I))
 
         def self_attn(sd):
             v5 = sd["qkv"].view(Wn, sd["Nx"], 3, sd["heads"], sd["D"])
             q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
-            ops.rope_2d_pair(q, sd["xpos"], k, sd["xpos"], cfg.rope_freq, 1.0)
+            if sd["xpos"] is not None and not sd["fq"]:
+                ops.rope_2d_pair(q, sd["xpos"], k, sd["xpos"], cfg.rope_freq, 1.0)
             ops.attention(q, k, v, sd["att"], sd["D"] ** -0.5)
         both(self_attn)
         self._linear_pair(S["att"].view(Wn * Ns, Cc), ps + ".attn.proj", S["out"], I["att"].view(Wn * Ni, Cc), pi + ".attn.proj", I["out"],
-                          res0=S["x"], res1=I["x"])
+                          res0=S["x"], res1=I["x"], ex0=em(S), ex1=em(I))
         # ---- cross attention
-        both(lambda sd: self._ln(sd["out"], sd["p"] + ".norm2", out16=sd["ln16"]))
-        self._linear_pair(S["ln16"], ps + ".cross_attn.projq", S["q"].view(Wn * Ns, Cc), I["ln16"], pi + ".cross_attn.projq", I["q"].view(Wn * Ni, Cc))
-        self._linear_pair(S["y16"], ps + ".cross_attn.projkv", S["kv"], I["y16"], pi + ".cross_attn.projkv", I["kv"])
+        if not fold_out:
+            both(lambda sd: self._ln(sd["out"], sd["p"] + ".norm2", out16=sd["ln16"]))
+        ex = lambda sd: {"rope": (sd["xpos"], Cc, sd["D"]) if sd["fq"] else None, "ln": sd["ost"] if fold_out else None}
+        self._linear_pair(S["o16"] if fold_out else S["ln16"], ps + ".cross_attn.projq", S["q"].view(Wn * Ns, Cc),
+                          I["o16"] if fold_out else I["ln16"], pi + ".cross_attn.projq", I["q"].view(Wn * Ni, Cc), ex0=ex(S), ex1=ex(I))
+        # projk|projv of the state block reads the image tokens (a), that of the image block the state tokens (s_a): different row counts,
+        # same N and K -- one pair launch; the key half gets the fused RoPE where the heads are 64 wide
+        exk = lambda sd, other: {"rope": (sd["ypos"], Cc, sd["D"]) if sd["fk"] else None, "ln": other["xst"] if fold_in else None}
+        self._linear_pair(I["x16"] if fold_in else S["y16"], ps + ".cross_attn.projkv", S["kv"], S["x16"] if fold_in else I["y16"], pi + ".cross_attn.projkv", I["kv"],
+                          ex0=exk(S, I), ex1=exk(I, S))
 
         def cross_attn(sd):
             kv4 = sd["kv"].view(Wn, sd["Ny"], 2, sd["heads"], sd["D"])
             k, v = kv4[:, :, 0], kv4[:, :, 1]
-            ops.rope_2d_pair(sd["q"], sd["xpos"], k, sd["ypos"], cfg.rope_freq, 1.0)
+            if not sd["fq"] or not sd["fk"]:
+                qq = sd["q"] if not sd["fq"] else None
+                kk = k if not sd["fk"] else None
+                if qq is not None and kk is not None:
+                    ops.rope_2d_pair(qq, sd["xpos"], kk, sd["ypos"], cfg.rope_freq, 1.0)
+                elif qq is not None:
+                    self._rope(qq, sd["xpos"])
+                elif kk is not None:
+                    self._rope(kk, sd["ypos"])
             ops.attention(sd["q"], k, v, sd["catt"], sd["D"] ** -0.5)
         both(cross_attn)
         self._linear_pair(S["catt"].view(Wn * Ns, Cc), ps + ".cross_attn.proj", S["out"], I["catt"].view(Wn * Ni, Cc), pi + ".cross_attn.proj", I["out"],
-                          res0=S["out"], res1=I["out"])
+                          res0=S["out"], res1=I["out"], ex0=em(S), ex1=em(I))
         # ---- MLP
-        both(lambda sd: self._ln(sd["out"], sd["p"] + ".norm3", out16=sd["ln16"]))
-        self._linear_pair(S["ln16"], ps + ".mlp.fc1", S["h"], I["ln16"], pi + ".mlp.fc1", I["h"], act=1)
-        self._linear_pair(S["h"], ps + ".mlp.fc2", S["out"], I["h"], pi + ".mlp.fc2", I["out"], res0=S["out"], res1=I["out"])
+        if not fold_out:
+            both(lambda sd: self._ln(sd["out"], sd["p"] + ".norm3", out16=sd["ln16"]))
+        ex = lambda sd: {"ln": sd["ost"] if fold_out else None}
+        self._linear_pair(S["o16"] if fold_out else S["ln16"], ps + ".mlp.fc1", S["h"], I["o16"] if fold_out else I["ln16"], pi + ".mlp.fc1", I["h"], act=1,
+                          ex0=ex(S), ex1=ex(I))
+        self._linear_pair(S["h"], ps + ".mlp.fc2", S["out"], I["h"], pi + ".mlp.fc2", I["out"], res0=S["out"], res1=I["out"], ex0=em(S), ex1=em(I))
 
     def _dual_norms(self, l, a, s_a):
         """The four input norms of decoder layer l in two launches: the image tokens `a` feed norm1 of the image block and
@@ -777,7 +834,9 @@ class Cut3rModel:
             for l in range(Ld):
                 # LayerNorm fold: from the second layer of a view on, the inputs of a layer were written by the previous layer's fc2 together
                 # with their fp16 copies and slab statistics (the first layer's inputs come from decoder_embed / the state carry: LayerNorm launches)
-                use_fold = fold and not self.pair_gemm
+                small = Wn * (N + 1) <= self.pair_rows
+                pair = self.pair_gemm or small
+                use_fold = fold and (small or not pair)        # (a forced pair form on a large batch runs the plain 128 / 256 pair kernels)
                 xa, xsa = (xs_of[a.data_ptr()], xs_of[s_a.data_ptr()]) if (use_fold and l > 0) else (None, None)
                 xb, xsb = (xs_of[b.data_ptr()], xs_of[s_b.data_ptr()]) if use_fold else (None, None)
                 if dead_tail and l == Ld - 1:
@@ -785,8 +844,9 @@ class Cut3rModel:
                     s_a, s_b = s_b, s_a
                     a, b = b, a
                     continue
-                if self.pair_gemm:
-                    self._dec_layer_pair(l, a, s_a, b, s_b, pos_img, pos_state, Wn, fork=fork)
+                if pair:
+                    self._dec_layer_pair(l, a, s_a, b, s_b, pos_img, pos_state, Wn, fork=fork, xs=(xa, xsa) if xa is not None else None,
+                                         os_=(xb, xsb) if xb is not None else None)
                 else:
                     pre = self.dual_ln and D in (768, 1024, 1536) and xa is None
                     if pre:

@@ -254,7 +254,7 @@ def linear(A, W, out, bias=None, act=0, res1=None, res2=None, tile=0, rope=None,
     return out
 
 
-def _linear_desc(A, W, out, bias, act, res1, tile):
+def _linear_desc(A, W, out, bias, act, res1, tile, rope=None, ln=None, emit=None):
     _cuda(A, W, out, bias, res1)
     _req(A.dtype == F16 and W.dtype == F16 and A.dim() == 2 and W.dim() == 2, "A,W must be 2-D fp16")
     M, K = A.shape
@@ -269,15 +269,35 @@ def _linear_desc(A, W, out, bias, act, res1, tile):
     d = GemmDesc()
     _fill_common(d, A, W, out, bias, res1, None, act, tile)
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, A.stride(0), W.stride(0), out.stride(0)
+    if rope is not None:
+        pos, cols, base = rope[:3]
+        hd = rope[3] if len(rope) > 3 else 64
+        _req(pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() == 2 * M and pos.is_cuda and hd == 64 and out.dtype == F16, "pair rope: heads of 64")
+        tab = rope_table(out.device, base, 1.0, hd)
+        d.rope_pos, d.rope_table, d.rope_cols, d.rope_pmin, d.rope_npos, d.rope_d = pos.data_ptr(), tab.data_ptr(), int(cols), ROPE_PMIN, ROPE_NPOS, hd
+    if ln is not None:
+        st, cs, eps = ln
+        _cuda(st, cs)
+        _req(K % 64 == 0 and st.dtype == F32 and st.is_contiguous() and st.numel() == M * (K // 64) * 2 and cs.dtype == F32 and cs.numel() == N and bias is not None,
+             "ln: stats fp32 [K/64, M, 2], colsum fp32 [N], folded bias")
+        d.ln_stats, d.ln_colsum, d.ln_nslab, d.ln_eps = st.data_ptr(), cs.data_ptr(), K // 64, float(eps)
+    if emit is not None:
+        so, o16 = emit
+        _cuda(so, o16)
+        _req(N % 64 == 0 and so.dtype == F32 and so.is_contiguous() and so.numel() == M * (N // 64) * 2 and o16.dtype == F16 and o16.shape == (M, N)
+             and out.dtype == F32 and res1 is not None and res1.dtype == F32 and act == 0, "emit: stats_out fp32 [N/64, M, 2], out16 fp16 [M,N], fp32 out + residual")
+        d.stats_out, d.out16, d.ld16 = so.data_ptr(), o16.data_ptr(), o16.stride(0)
     return d
 
 
 def linear_pair(p0, p1, act=0, tile=0):
-    """Two independent linears in ONE launch (cut3r_gemm_f16_pair): p = (A [M,K], W [N,K], out [M,N], bias | None, res1 | None)
-    with the same N and K; rows are bit-identical to ops.linear.  The decoder runs its state-side and image-side projection of a
-    layer this way."""
-    d0 = _linear_desc(p0[0], p0[1], p0[2], p0[3], act, p0[4], tile)
-    d1 = _linear_desc(p1[0], p1[1], p1[2], p1[3], act, p1[4], tile)
+    """Two independent linears in ONE launch (cut3r_gemm_f16_pair): p = (A [M,K], W [N,K], out [M,N], bias | None, res1 | None[, extras]) with
+    the same N and K; rows are bit-identical to ops.linear.  The decoder runs its state-side and image-side projection of a layer this
+    way.  extras: dict with any of rope / ln / emit as in ops.linear (per problem)."""
+    x0 = p0[5] if len(p0) > 5 and p0[5] else {}
+    x1 = p1[5] if len(p1) > 5 and p1[5] else {}
+    d0 = _linear_desc(p0[0], p0[1], p0[2], p0[3], act, p0[4], tile, **x0)
+    d1 = _linear_desc(p1[0], p1[1], p1[2], p1[3], act, p1[4], tile, **x1)
     _req(d0.N == d1.N and d0.K == d1.K, "pair: same N and K")
     lib = _lib.load()
     check(lib.cut3r_gemm_f16_pair(C.byref(d0), C.byref(d1), _stream()), f"cut3r_gemm_f16_pair M={d0.M}+{d1.M} N={d0.N} K={d0.K}")

@@ -109,7 +109,9 @@ int cut3r_gemm_tile_for(const cut3r_gemm_desc* d);
 /* TWO independent linear problems (same N, K; own operands, row counts and epilogues) in ONE launch: the state-side and the
  * image-side GEMM of a decoder layer -- both DecoderBlocks of a layer read the previous layer's pair
  * (src/dust3r/model.py:669-692), so they are independent; one grid over both fills the chip where each alone does not.
- * Plain linears only (no convolution / pixel shuffle / fused RoPE / batch).  Rows are bit-identical to cut3r_gemm_f16. */
+ * Linears only (no convolution / pixel shuffle / batch).  Rows are bit-identical to cut3r_gemm_f16.  Tile 256 / 128 on large combined
+ * grids; below 128 tiles of 128 x 128 the 64 x 64 pair kernels (the one-window schedule: 2 x 156 tiles at M = 768 / 769), which also
+ * carry the fused RoPE and both sides of the LayerNorm fold, each problem with its own flags. */
 int cut3r_gemm_f16_pair(const cut3r_gemm_desc* d0, const cut3r_gemm_desc* d1, void* stream);
 
 /* skinny M<=64 path: Y[M,N] = act(X[M,K] (fp32, optional SiLU on load) * W[N,K]^T (fp16) + bias) (+res) */

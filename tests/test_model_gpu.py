@@ -192,3 +192,28 @@ def test_batched_windows_equal_individual_windows():
             for k in ("pts3d_in_self_view", "conf_self", "camera_pose"):
                 a, b = res[k][w * 3 + v], single[v][k][0]
                 assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), (w, v, k, float((a - b).abs().max()))
+
+
+def test_pair_launch_form_of_a_decoder_layer_gives_the_same_bits():
+    """`Cut3rModel.pair_rows`: below that many rows a decoder layer runs as pair launches (state + image projection in one grid of 64 x 64
+    tiles: cut3r_gemm_f16_pair with the LayerNorm fold, the fused RoPE of the 64-wide heads and the compile-time epilogues).  Same tile
+    body, same row arithmetic: every output equals the default form bit for bit, for one window and for three batched ones."""
+    cfg = Cut3rConfig(img_size=(64, 96), enc_embed_dim=256, enc_depth=2, enc_num_heads=4, dec_embed_dim=192, dec_depth=4,
+                      dec_num_heads=3, state_dec_num_heads=4, state_size=30, local_mem_size=16, ray_enc_depth=1, head_type="dpt")
+    sd = synth_state_dict(cfg, 5)
+    g = torch.Generator().manual_seed(1)
+    imgs = torch.randint(0, 256, (9, 3, 64, 96), generator=g, dtype=torch.uint8).to(DEV)
+    outs = []
+    for rows in (0, 10 ** 9):
+        model = Cut3rModel(cfg, sd, DEV, minimal=True)
+        model.pair_rows = rows
+        feats = model.encode_batch(imgs)
+        wins = torch.stack([feats[0:3], feats[3:6], feats[6:9]], 0)
+        res = {k: v.clone() for k, v in model.decode_windows(wins, 64, 96).items()}
+        single, _ = model.decode_window(wins[1], 64, 96)
+        outs.append((res, [{k: v.clone() for k, v in p.items()} for p in single]))
+        del model
+    for k in ("pts3d_in_self_view", "conf_self", "camera_pose"):
+        assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+        for v in range(3):
+            assert torch.equal(outs[0][1][v][k], outs[1][1][v][k]), (k, v)
