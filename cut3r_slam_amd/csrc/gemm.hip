@@ -1142,15 +1142,19 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + gnc), b1 = *reinterpret_cast<const f32x4*>(bias + gnc + 4);
         const float* rrow = (const float*)g.res1 + (size_t)z * g.sR1 + gnc;
         float* crow = (float*)g.C + (size_t)z * g.sC + gnc;
-#pragma unroll
-        for (int mp = 0; mp < 4; mp++) {
-            f32x4 ra[4], rb[4];
+        f32x4 ra[2][4], rb[2][4];           // (the next band's residual rows are requested before this one is staged: see the plain path below)
+        auto load_band = [&](int mp, f32x4 (&a_)[4], f32x4 (&b_)[4]) {
 #pragma unroll
             for (int it = 0; it < 4; it++) {
                 const int gm = min(m0 + wr * 128 + mp * 32 + it * 8 + er, M - 1);
-                ra[it] = *reinterpret_cast<const f32x4*>(rrow + (size_t)gm * g.ldr1);
-                rb[it] = *reinterpret_cast<const f32x4*>(rrow + (size_t)gm * g.ldr1 + 4);
+                a_[it] = *reinterpret_cast<const f32x4*>(rrow + (size_t)gm * g.ldr1);
+                b_[it] = *reinterpret_cast<const f32x4*>(rrow + (size_t)gm * g.ldr1 + 4);
             }
+        };
+        load_band(0, ra[0], rb[0]);
+#pragma unroll
+        for (int mp = 0; mp < 4; mp++) {
+            if (mp + 1 < 4) load_band(mp + 1, ra[(mp + 1) & 1], rb[(mp + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -1162,8 +1166,8 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
             for (int it = 0; it < 4; it++) {
                 const int rr = it * 8 + er;
                 const int gm = m0 + wr * 128 + mp * 32 + rr;
-                const f32x4 v0 = (*reinterpret_cast<const f32x4*>(cs + rr * CP + ec) + b0) + ra[it];
-                const f32x4 v1 = (*reinterpret_cast<const f32x4*>(cs + rr * CP + ec + 4) + b1) + rb[it];
+                const f32x4 v0 = (*reinterpret_cast<const f32x4*>(cs + rr * CP + ec) + b0) + ra[mp & 1][it];
+                const f32x4 v1 = (*reinterpret_cast<const f32x4*>(cs + rr * CP + ec + 4) + b1) + rb[mp & 1][it];
                 float ssum, sm2;
                 slab_stats8(v0, v1, ssum, sm2);
                 if (col_ok && gm < M) {
@@ -1184,14 +1188,22 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + gnc);
         const float* rrow = (const float*)g.res1 + (size_t)z * g.sR1 + gnc;
         float* crow = (float*)g.C + (size_t)z * g.sC + gnc;
-#pragma unroll
-        for (int mp = 0; mp < 4; mp++) {
-            f32x4 r1v[8];
+        // The residual rows of band mp + 1 are requested BEFORE band mp is staged and stored (two register sets; the accumulators a band
+        // has staged are dead, so the budget holds): a band no longer starts with an exposed HBM round trip -- this epilogue is 512 KB of
+        // traffic per tile and was latency-, not bandwidth-bound (27 GB/s per CU with 40 % of the CUs in it).  (In-place residual: a band's
+        // loads and the previous band's stores touch different rows.)
+        f32x4 r1v[2][8];
+        auto load_band = [&](int mp, f32x4 (&r)[8]) {
 #pragma unroll
             for (int it = 0; it < 8; it++) {
                 const int gm = min(m0 + wr * 128 + mp * 32 + it * 4 + er, M - 1);
-                r1v[it] = *reinterpret_cast<const f32x4*>(rrow + (size_t)gm * g.ldr1);
+                r[it] = *reinterpret_cast<const f32x4*>(rrow + (size_t)gm * g.ldr1);
             }
+        };
+        load_band(0, r1v[0]);
+#pragma unroll
+        for (int mp = 0; mp < 4; mp++) {
+            if (mp + 1 < 4) load_band(mp + 1, r1v[(mp + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -1203,7 +1215,7 @@ DEVINL void gemm256_body(const GemmArgs& g, const int bx, const int bz) {
             for (int it = 0; it < 8; it++) {
                 const int rr = it * 4 + er;
                 const int gm = m0 + wr * 128 + mp * 32 + rr;
-                const f32x4 v = (*reinterpret_cast<const f32x4*>(cs + rr * CP + ec) + b4) + r1v[it];
+                const f32x4 v = (*reinterpret_cast<const f32x4*>(cs + rr * CP + ec) + b4) + r1v[mp & 1][it];
                 if (col_ok && gm < M) *reinterpret_cast<f32x4*>(crow + (size_t)gm * g.ldc) = v;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
