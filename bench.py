@@ -286,8 +286,8 @@ def traffic_from_profile(tile, launches_in_run):
     correction of MI355X_MICROARCH.md).  PMC counters need the profiler, so this is never measured inside the run itself: it is
     emitted with its provenance.  FETCH_SIZE counts what the 8 per-XCD L2s request from the fabric, so operands every XCD reads
     (the weight panel) count 8 times although the Infinity Cache serves them."""
-    pj = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
-    if os.path.isfile(pj):
+    pj = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_traffic.json") for r in ("r04", "r03")) if os.path.isfile(q)), "")
+    if pj:
         j = json.load(open(pj))
         cand = [v for n, v in j.get("kernels", {}).items() if tile in PMC_KEYS and n.startswith(PMC_KEYS[tile]) and v.get("launches")]
         k = None
@@ -761,11 +761,19 @@ def main():
             probe = KernelProbe()
             probe.install()
             model.use_graphs = False      # events must bracket live launches, not a graph replay
+            # ... and launches that run ALONE: without the encoder look-ahead stream and the replay side stream (round 4: with the frames
+            # arriving on an upload stream the look-ahead pass overlapped the eager decoder, and every bracketed launch read 1.5 x its
+            # duration -- the rates of time-shared kernels, not of the kernels)
+            ahead_was, pipe_was = runner.encode_ahead, runner.pipelined
+            runner.flush()
+            torch.cuda.synchronize()      # (a look-ahead pass already issued has stored its features: the windows find them)
+            runner.encode_ahead, runner.pipelined, runner._ahead = False, False, None
             for _ in range(args.steps):
                 t = runner.step(frames, t, KF_EVERY, WIN, intr)
             runner.flush()
             res = probe.result()
             probe.remove()
+            runner.encode_ahead, runner.pipelined = ahead_was, pipe_was
             model.use_graphs = True
             gem = {k[1]: v for k, v in res.items() if k[0] == "gemm" and v[0]}
             if gem:

@@ -206,14 +206,44 @@ def _mono_prior_solve(C, w, H, E, v, ep, lm, dzcov):
     return dso, dz, cov, flag
 
 
+CHOL_MAXN = 192          # the in-LDS Cholesky of csrc/ba.hip (cut3r_schur_mono_prior / cut3r_ba_solve) holds systems up to this size
+
+
+def _schur_mono_prior_large(C, w, Hs, Es, vs, ep, lm, dzcov):
+    """The same solve for reduced systems LARGER than the in-LDS Cholesky (M*D > 192: ADVICE r3): dense tensor ops on the GPU, the
+    formulation of geom/chol.py:80-107 term by term (damping H + (ep + lm H) I, S = H - E C^-1 E^T, CholeskySolver's zeros on failure)."""
+    D = Hs.shape[-1]
+    B, M, HW = C.shape
+    Q = (1.0 / C).view(B, M * HW, 1)
+    w = w.reshape(B, M * HW, 1)
+    H = Hs.permute(0, 1, 3, 2, 4).reshape(B, M * D, M * D)
+    E = Es.permute(0, 1, 3, 2, 4).reshape(B, M * D, M * HW)
+    v = vs.reshape(B, M * D, 1)
+    H = H + (ep + lm * H) * torch.eye(M * D, device=H.device)
+    Et = E.transpose(1, 2)
+    S = H - torch.matmul(E, Q * Et)
+    v = v - torch.matmul(E, Q * w)
+    L, info = torch.linalg.cholesky_ex(S)
+    ok = int(info.max()) == 0
+    dso = torch.cholesky_solve(v, L) if ok else torch.zeros_like(v)
+    dz = (Q * (w - Et @ dso)).reshape(B, M, HW)
+    cov = None
+    if dzcov:
+        Fm = torch.linalg.solve_triangular(L, E * Q[..., 0], upper=False) if ok else torch.zeros_like(E)
+        cov = (torch.sum(torch.square(Fm), dim=1) + Q[..., 0]).reshape(M, HW)
+    return dso.reshape(B, M, D), dz, cov
+
+
 def schur_solve_mono_prior(C, w, Hs, Es, vs, ep=0.1, lm=1e-4, dzcov=False):
     """geom/chol.py:80-107 on the HIP kernels of csrc/ba.hip (reduction S = H + damping - E C^-1 E^T, in-LDS Cholesky, back-substitution,
-    column-wise covariance): the reduced system is M*D x M*D with D = hs*ws scale-grid nodes (M*D <= 192).
+    column-wise covariance): the reduced system is M*D x M*D with D = hs*ws scale-grid nodes (M*D <= 192; larger systems: _schur_mono_prior_large).
     C, w [1,M,HW]; Hs [1,M,M,D,D]; Es [1,M,M,D,HW]; vs [1,M,D].  Returns (dso [1,M,D], dz [1,M,HW], dzcov [M,HW] or None)."""
     D = Hs.shape[-1]
     B, M, HW = C.shape
     if B != 1:
         raise NotImplementedError("batch 1 (the only use in the reference)")
+    if M * D > CHOL_MAXN:
+        return _schur_mono_prior_large(C, w, Hs, Es, vs, ep, lm, dzcov)
     H = Hs.permute(0, 1, 3, 2, 4).reshape(M * D, M * D).float().contiguous()         # the reference's layout change, chol.py:88-89
     E = Es.permute(0, 1, 3, 2, 4).reshape(M * D, M * HW).float().contiguous()
     dso, dz, cov, _ = _mono_prior_solve(C.reshape(-1).float().contiguous(), w.reshape(-1).float().contiguous(), H, E,
@@ -252,13 +282,30 @@ def JDSA(target, weight, eta, poses, disps, intrinsics, disps_prior, dscales, ii
     rd = (disps[0, kx] - disps_bi).reshape(-1, HW).float().contiguous()
     D = hs * ws
     n = M * D
+    C = Cm.reshape(M, HW) + m * float(alpha) + (1 - m) * eta.reshape(M, HW)                     # Jd = 1
+    w = wv.reshape(M, HW) - m * float(alpha) * rd
+    if n > CHOL_MAXN:
+        # more than 192 / D source frames: H and E are block diagonal (frame k's blocks sit at (kx, kx): ba.py:213-228), and so
+        # is the damping, so the reduced system falls apart into M independent D x D systems -- one per frame, E restricted to that frame's
+        # HW columns: no dense [n, n] / [n, M*HW] buffers, no size limit.  Same kernels, same arithmetic per frame.
+        lib = _lib.load()
+        dso, dz, dzcov = torch.empty(M, D, device=dev), torch.empty(M, HW, device=dev), torch.empty(M, HW, device=dev)
+        pr, jb = prior.reshape(M, HW).float().contiguous(), Jbi.reshape(M, HW, D).float().contiguous()
+        Hk, Ek, vk = torch.empty(D, D, device=dev), torch.empty(D, HW, device=dev), torch.empty(D, device=dev)
+        for k in range(M):
+            check(lib.cut3r_jdsa_blocks(_p(pr[k]), _p(jb[k]), _p(rd[k]), float(alpha), 1, HW, D, _p(Hk), _p(Ek), _p(vk), _stream()), "cut3r_jdsa_blocks")
+            a_, b_, c_, _ = _mono_prior_solve(C[k].contiguous(), w[k].contiguous(), Hk, Ek, vk, ep, lm, True)
+            dso[k], dz[k], dzcov[k] = a_, b_, c_
+        new_disps = disps.clone()
+        new_disps[0, kx] += dz.view(M, ht, wd)
+        dscales[kx] += dso.view(-1, hs, ws)
+        new_disps = torch.where(new_disps > 10, torch.zeros_like(new_disps), new_disps).clamp(min=0.001)
+        return new_disps, dscales, dzcov
     # the scatter of the reference puts frame k's blocks on the diagonal (kx, kx): block-diagonal H [n,n] / E [n,M*HW], written by one
     # kernel (Jso = -m prior Jbi, H_k = alpha Jso^T Jso, E_k = alpha Jso^T (Jd = 1), v_k = -alpha Jso^T rd, ba.py:213-228)
     Hd, Ed, vd = torch.empty(n, n, device=dev), torch.empty(n, M * HW, device=dev), torch.empty(n, device=dev)
     check(_lib.load().cut3r_jdsa_blocks(_p(prior.reshape(M, HW).float().contiguous()), _p(Jbi.reshape(M, HW, D).float().contiguous()), _p(rd),
                                         float(alpha), M, HW, D, _p(Hd), _p(Ed), _p(vd), _stream()), "cut3r_jdsa_blocks")
-    C = Cm.reshape(M, HW) + m * float(alpha) + (1 - m) * eta.reshape(M, HW)                     # Jd = 1
-    w = wv.reshape(M, HW) - m * float(alpha) * rd
     dso, dz, dzcov, _ = _mono_prior_solve(C.reshape(-1).contiguous(), w.reshape(-1).contiguous(), Hd, Ed, vd, ep, lm, True)
     dzcov = dzcov.reshape(M, HW)
     new_disps = disps.clone()

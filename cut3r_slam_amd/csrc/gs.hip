@@ -666,26 +666,86 @@ struct KnnHdr { float minx, miny, minz, cs, inv_cs; int gx, gy, gz; };
 DEVINL unsigned knn_enc(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }     // order-preserving
 DEVINL float knn_dec(unsigned e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
 
+// bb[0..5]: order-preserving encodings of the per-axis minima / maxima; mom[0..5] (floats behind them): per-axis sum and sum of squares
+// RELATIVE TO POINT 0 (so that the squares stay small for a map far from the origin)
 __global__ __launch_bounds__(256) void knn_bbox_kernel(const float* __restrict__ pts, int P, unsigned* __restrict__ bb) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f}, d[3] = {0.f, 0.f, 0.f};
     if (i < P) {
 #pragma unroll
-        for (int a = 0; a < 3; a++) lo[a] = hi[a] = pts[3 * (size_t)i + a];
+        for (int a = 0; a < 3; a++) { lo[a] = hi[a] = pts[3 * (size_t)i + a]; d[a] = lo[a] - pts[a]; }
     }
+    float* mom = reinterpret_cast<float*>(bb + 6);
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        float l = lo[a], h = hi[a];
+        float l = lo[a], h = hi[a], s1 = d[a], s2 = d[a] * d[a];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { l = fminf(l, __shfl_xor(l, o, 64)); h = fmaxf(h, __shfl_xor(h, o, 64)); }
-        if ((threadIdx.x & 63) == 0) { atomicMin(bb + a, knn_enc(l)); atomicMax(bb + 3 + a, knn_enc(h)); }
+        for (int o = 32; o > 0; o >>= 1) {
+            l = fminf(l, __shfl_xor(l, o, 64)); h = fmaxf(h, __shfl_xor(h, o, 64));
+            s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(bb + a, knn_enc(l)); atomicMax(bb + 3 + a, knn_enc(h)); atomicAdd(mom + a, s1); atomicAdd(mom + 3 + a, s2); }
     }
 }
 
-__global__ void knn_header_kernel(const unsigned* __restrict__ bb, int G, KnnHdr* __restrict__ hdr) {
+// second moment pass: only the points inside the first pass's box count (bb[12..17]: its lo / hi as floats; mom2 = bb[18..23], count bb[24]).
+// Ten outliers at 100 x the extent among 2e5 surface points triple sigma by themselves; trimmed to the first box, sigma is the surface's.
+__global__ __launch_bounds__(256) void knn_trim_kernel(const float* __restrict__ pts, int P, unsigned* __restrict__ bb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float* box = reinterpret_cast<const float*>(bb + 12);
+    float d[3] = {0.f, 0.f, 0.f};
+    bool in = i < P;
+    if (i < P) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float x = pts[3 * (size_t)i + a];
+            in = in && x >= box[a] && x <= box[3 + a];
+            d[a] = x - pts[a];
+        }
+    }
+    float* mom = reinterpret_cast<float*>(bb + 18);
+    const float c = in ? 1.f : 0.f;
+    float cnt = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float s1 = c * d[a], s2 = c * d[a] * d[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(mom + a, s1); atomicAdd(mom + 3 + a, s2); }
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(mom + 6, cnt);
+}
+
+// The grid covers the ROBUST box: per axis [mean - 3 sigma, mean + 3 sigma] intersected with the true bounding box.  A few far outliers
+// (sky / far-depth pixels with conf > 0) would otherwise stretch the box, the surface would fall into a handful of cells and every thread
+// of the query kernel would scan them serially (O(P^2) from global memory).  Points outside the grid are clamped into its border cells
+// (knn_cell); the shell bound of the query stays valid under clamping (a clamped point is never nearer than its cell says), so the
+// result is still EXACT -- the statistics only steer the speed, which is why their atomic summation order does not matter.
+// pass 0: box from the moments of ALL points -> bb[12..17] (read by knn_trim_kernel); pass 1: box from the trimmed moments -> the header
+__global__ void knn_header_kernel(unsigned* __restrict__ bb, const float* __restrict__ pts, int P, int G, KnnHdr* __restrict__ hdr, int pass) {
     if (threadIdx.x != 0) return;
-    const float lx = knn_dec(bb[0]), ly = knn_dec(bb[1]), lz = knn_dec(bb[2]);
-    const float ex = knn_dec(bb[3]) - lx, ey = knn_dec(bb[4]) - ly, ez = knn_dec(bb[5]) - lz;
+    const float* mom = reinterpret_cast<const float*>(bb + (pass == 0 ? 6 : 18));
+    const float n = pass == 0 ? (float)P : fmaxf(mom[6], 1.f);
+    float lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float mean_d = mom[a] / n;
+        const float var = fmaxf(mom[3 + a] / n - mean_d * mean_d, 0.f);
+        const float mu = pts[a] + mean_d, sg = sqrtf(var);
+        lo[a] = fmaxf(knn_dec(bb[a]), mu - 3.f * sg);
+        hi[a] = fminf(knn_dec(bb[3 + a]), mu + 3.f * sg);
+        if (!(hi[a] >= lo[a])) { lo[a] = knn_dec(bb[a]); hi[a] = knn_dec(bb[3 + a]); }
+    }
+    if (pass == 0) {
+        float* box = reinterpret_cast<float*>(bb + 12);
+#pragma unroll
+        for (int a = 0; a < 3; a++) { box[a] = lo[a]; box[3 + a] = hi[a]; }
+        return;
+    }
+    const float lx = lo[0], ly = lo[1], lz = lo[2];
+    const float ex = hi[0] - lx, ey = hi[1] - ly, ez = hi[2] - lz;
     float cs = fmaxf(ex, fmaxf(ey, ez)) / (float)G;
     if (!(cs > 0.f)) cs = 1.f;                                   // all points identical
     KnnHdr h;
@@ -733,6 +793,22 @@ __global__ __launch_bounds__(256) void knn_query_kernel(int P, const KnnHdr* __r
     int cx, cy, cz;
     knn_cell(h, x, y, z, cx, cy, cz);
     float b0 = 3.402823466e38f, b1 = b0, b2 = b0;
+    // a query OUTSIDE the grid (an outlier clamped into a border cell: the grid covers the robust box) is far from everything: its shell
+    // search would walk every shell of the grid, one cell at a time, before the bound lets it stop (measured: 0.3 s for ten outliers).
+    // It scans the point list instead -- exact by construction, ~1 ms, and outliers are few.
+    const bool outside = x < h.minx || y < h.miny || z < h.minz || x > h.minx + h.gx * h.cs || y > h.miny + h.gy * h.cs || z > h.minz + h.gz * h.cs;
+    if (outside) {
+        for (int j = 0; j < P; j++) {
+            if (j == t) continue;
+            const float dx = spts[3 * (size_t)j] - x, dy = spts[3 * (size_t)j + 1] - y, dz = spts[3 * (size_t)j + 2] - z;
+            float d = dx * dx + dy * dy + dz * dz;
+            const float t0 = fminf(b0, d); d = fmaxf(b0, d); b0 = t0;
+            const float t1 = fminf(b1, d); d = fmaxf(b1, d); b1 = t1;
+            b2 = fminf(b2, d);
+        }
+        out[sidx[t]] = (b0 + b1 + b2) / 3.f;
+        return;
+    }
     const int rmax = max(h.gx, max(h.gy, h.gz));
     for (int R = 0; R <= rmax; R++) {
         const int z0 = max(0, cz - R), z1 = min(h.gz - 1, cz + R), y0 = max(0, cy - R), y1 = min(h.gy - 1, cy + R);
@@ -1258,12 +1334,14 @@ extern "C" int cut3r_knn3_grid_mean_dist2(const float* points, int P, float* out
     void* scan_ws = (void*)(((uintptr_t)(sidx + P) + 255) & ~(uintptr_t)255);
     size_t scan_bytes = (size_t)((char*)workspace + workspace_bytes - (char*)scan_ws);
     if (hipMemsetAsync(bb, 0xFF, 3 * sizeof(unsigned), s) != hipSuccess) return CUT3R_ERR_LAUNCH;          // encoded minima start at the top
-    if (hipMemsetAsync(bb + 3, 0, 3 * sizeof(unsigned), s) != hipSuccess) return CUT3R_ERR_LAUNCH;
+    if (hipMemsetAsync(bb + 3, 0, 22 * sizeof(unsigned), s) != hipSuccess) return CUT3R_ERR_LAUNCH;         // maxima, moments, first box, trimmed moments + count
     if (hipMemsetAsync(counts, 0, sizeof(unsigned) * (size_t)(nc + 1), s) != hipSuccess) return CUT3R_ERR_LAUNCH;
     if (hipMemsetAsync(cursor, 0, sizeof(unsigned) * (size_t)nc, s) != hipSuccess) return CUT3R_ERR_LAUNCH;
     const unsigned nb = (unsigned)((P + 255) / 256);
     hipLaunchKernelGGL(knn_bbox_kernel, dim3(nb), dim3(256), 0, s, points, P, bb);
-    hipLaunchKernelGGL(knn_header_kernel, dim3(1), dim3(64), 0, s, bb, G, hdr);
+    hipLaunchKernelGGL(knn_header_kernel, dim3(1), dim3(64), 0, s, bb, points, P, G, hdr, 0);
+    hipLaunchKernelGGL(knn_trim_kernel, dim3(nb), dim3(256), 0, s, points, P, bb);
+    hipLaunchKernelGGL(knn_header_kernel, dim3(1), dim3(64), 0, s, bb, points, P, G, hdr, 1);
     hipLaunchKernelGGL(knn_count_kernel, dim3(nb), dim3(256), 0, s, points, P, hdr, cell_of, counts);
     if (hipcub::DeviceScan::ExclusiveSum(scan_ws, scan_bytes, counts, starts, (int)(nc + 1), s) != hipSuccess) return CUT3R_ERR_ARG;
     hipLaunchKernelGGL(knn_scatter_kernel, dim3(nb), dim3(256), 0, s, points, P, cell_of, starts, cursor, spts, sidx);

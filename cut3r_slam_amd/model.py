@@ -102,7 +102,12 @@ class Cut3rModel:
         # copy of the residual stream and its per-row slab statistics; qkv / projq / projk|projv / fc1 read that copy through gamma-folded
         # weights and normalise in their epilogue (include/cut3r_hip.h, cut3r_gemm_desc).  The LayerNorm launches in front of them
         # disappear, except where the input has no producer GEMM (first encoder block, first decoder layer of a view, pose memory).
-        self.ln_fold = _os.environ.get("CUT3R_LN_FOLD", "1") != "0"
+        # Economics, measured (tools/bench_lnfold.py, bench probe passes): the producers pay for the extra fp16 stream
+        # (+7.5 us per tile round at N = 1024, HBM), the consumers for the row parameters (+1.2 us per tile).  Per DECODER block (28 windows)
+        # that is 35 us against 58 us of LayerNorm launches -- a net win, and at one window every removed launch is latency (24.4 -> 23.6 ms
+        # per window); per ENCODER block 200 us against 2 x 109 us -- nothing, while the encoder GEMMs (the dominant kernel) run 5-6 % slower.
+        # So: 1 (default) = decoder only, 2 = encoder as well, 0 = off.
+        self.ln_fold = int(_os.environ.get("CUT3R_LN_FOLD", "1"))
         self._head_stream = None
         self._side = None
         self._head_side = None
@@ -169,8 +174,9 @@ class Cut3rModel:
         def enc_block(p):
             ln(p + ".norm1"); lin(p + ".attn.qkv"); lin(p + ".attn.proj"); ln(p + ".norm2")
             lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
-            fold(p + ".attn.qkv", sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"], p + ".norm1")
-            fold(p + ".mlp.fc1", sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"], p + ".norm2")
+            if self.ln_fold >= 2:
+                fold(p + ".attn.qkv", sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"], p + ".norm1")
+                fold(p + ".mlp.fc1", sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"], p + ".norm2")
 
         def dec_block(p, folded=True):
             ln(p + ".norm1"); lin(p + ".attn.qkv"); lin(p + ".attn.proj")
@@ -360,7 +366,7 @@ class Cut3rModel:
         y, xx = torch.meshgrid(torch.arange(nh, device=self.device), torch.arange(nw, device=self.device), indexing="ij")
         pos = torch.stack([y.reshape(-1), xx.reshape(-1)], -1)[None].expand(B, -1, -1).contiguous()
         ln16 = self.buf(tag + ".ln16", (M, E), F16)
-        fold = self._folded("enc_blocks.0.attn.qkv") and E % 64 == 0
+        fold = self.ln_fold >= 2 and self._folded("enc_blocks.0.attn.qkv") and E % 64 == 0
         x16, xst = self._xs(tag, x) if fold else (None, None)
         em = (xst, x16) if fold else None
         for i in range(cfg.enc_depth):

@@ -737,7 +737,9 @@ def gen_gaussian_model_fixture():
                 fx[f"{tag}_step"] = np.float64(float(st["step"]))
         fx[f"{tag}_lr_xyz"] = np.float64([grp["lr"] for grp in gm.optimizer.param_groups if grp["name"] == "xyz"][0])
 
-    def step(gm, it, gseed):
+    def step(gm, it, gseed, between=None):
+        """one iteration; `between` runs between the statistics and optimizer.step(), where the reference's loops densify / reset
+        (gs_backend_per_frame.py:425-438, 1025-1041)"""
         gg = torch.Generator().manual_seed(gseed)
         n = gm._xyz.shape[0]
         grads = {"xyz": torch.randn(n, 3, generator=gg) * 1e-3, "f_dc": torch.randn(n, 1, 3, generator=gg) * 1e-2, "opacity": torch.randn(n, 1, generator=gg) * 1e-2,
@@ -753,6 +755,8 @@ def gen_gaussian_model_fixture():
         gm.max_radii2D[vis] = torch.max(gm.max_radii2D[vis], torch.randint(1, 30, (int(vis.sum()),), generator=gg).float())
         fx[f"radii_{it}"] = gm.max_radii2D.numpy().copy()
         gm.add_densification_stats(vs, vis)
+        if between is not None:
+            between()
         gm.optimizer.step()
         gm.optimizer.zero_grad(set_to_none=True)
         gm.update_learning_rate(it)
@@ -786,13 +790,24 @@ def gen_gaussian_model_fixture():
             gm.densify_and_prune(max_grad, min_opacity, extent, None)     # second round without the screen-size rule
             step(gm, 8, 108)
             snapshot(gm, "e")
+            # round 4: the ORDER inside the reference's training loops -- backward, statistics, densify_and_prune, THEN
+            # optimizer.step(): the re-created parameters have no .grad, so that step changes nothing (no update, no moment update, no step
+            # count); likewise reset_opacity before the step: the opacity group is skipped, the others step
+            step(gm, 9, 109, between=lambda: gm.densify_and_prune(max_grad, min_opacity, extent, None))
+            snapshot(gm, "f")
+            fx["f_steps_by_group"] = np.asarray([float(gm.optimizer.state[g_["params"][0]]["step"]) for g_ in gm.optimizer.param_groups if g_["name"] in names])
+            step(gm, 10, 110, between=gm.reset_opacity)
+            snapshot(gm, "g")
+            fx["g_steps_by_group"] = np.asarray([float(gm.optimizer.state[g_["params"][0]]["step"]) for g_ in gm.optimizer.param_groups if g_["name"] in names])
+            fx["group_names"] = np.asarray(names)
     finally:
         torch.Tensor.cuda, torch.normal = real_cuda, real_normal
     for i, d in enumerate(draws):
         fx[f"split_draws_{i}"] = d.numpy().copy()
     np.savez_compressed(os.path.join(HERE, "gaussian_model.npz"), **fx)
     print("wrote gaussian_model: P", P, "->", int(fx["n_after_densify"]), "->", fx["e_xyz"].shape[0], "| split draws", [d.shape[0] for d in draws],
-          "| steps", [float(fx[f"{t}_step"]) for t in "abcde"], "| lr_xyz", [float(fx[f"{t}_lr_xyz"]) for t in "abcde"])
+          "| steps", [float(fx[f"{t}_step"]) for t in "abcdefg"], "| lr_xyz", [float(fx[f"{t}_lr_xyz"]) for t in "abcdefg"],
+          "| steps by group after densify-then-step", fx["f_steps_by_group"], "after reset-then-step", fx["g_steps_by_group"])
 
 
 def handover_mapper_update(data):

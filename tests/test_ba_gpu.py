@@ -322,3 +322,53 @@ def test_pose_system_solve_equals_the_reference_schur_solve():
         assert err < 5e-5, (name, err)
     dz = (Q * (w.reshape(-1) - Em.T @ torch.from_numpy(got).reshape(-1))).reshape(1, M, HW).numpy()
     assert float(np.abs(dz - f["ss_dz_f64"]).max() / np.abs(f["ss_dz_f64"]).max()) < 5e-5
+
+
+def test_reduced_systems_larger_than_the_in_lds_cholesky():
+    """`M * D > 192` used to be refused.  JDSA's system is block diagonal (frame k's H / E blocks sit at (kx, kx): geom/ba.py
+    :213-228), so it is solved as M independent D x D systems -- which must equal the dense solve wherever both run; the general
+    `schur_solve_mono_prior` falls back to dense tensor ops (geom/chol.py:80-107 term by term) and must equal the kernel path on a
+    system both can take."""
+    from cut3r_slam_amd import ba as BA
+    # (1) JDSA: the per-frame solves == the dense path (forced by lowering the limit) on the scene of test_jdsa_matches_unreduced_dense_solve
+    P, ht, wd, hs, ws, alpha = 4, 6, 8, 2, 3, 0.05
+    poses, disps, intr, ii, jj, tgt, wgt, eta = _scene(P, ht, wd, 5)
+    g = np.random.default_rng(2)
+    prior = disps * g.uniform(0.8, 1.2, disps.shape)
+    prior[:, :2, :3] = 0.0
+    scales = g.uniform(0.9, 1.1, (P, hs, ws))
+    outs = []
+    for limit in (BA.CHOL_MAXN, 4):                       # 4 < M * D: every frame on its own
+        was = BA.CHOL_MAXN
+        BA.CHOL_MAXN = limit
+        try:
+            dsc = _f(scales).clone()
+            nd, ns, cov = BA.JDSA(_f(tgt)[None], _f(wgt)[None], _f(eta), SE3(_f(poses)[None]), _f(disps)[None], _f(intr)[None], _f(prior), dsc,
+                                  torch.from_numpy(ii), torch.from_numpy(jj), alpha)
+            torch.cuda.synchronize()
+            outs.append((nd.cpu(), ns.cpu(), cov.cpu()))
+        finally:
+            BA.CHOL_MAXN = was
+    for a, b, name in zip(outs[0], outs[1], ("disps", "scales", "dzcov")):
+        np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=2e-5, atol=1e-7, err_msg=name)
+    # (2) a JDSA window with more than 192 / D source frames runs (50 frames x D = 4 = 200 > 192) and moves the disparities
+    P2, hs2, ws2 = 52, 2, 2
+    poses2, disps2, intr2, ii2, jj2, tgt2, wgt2, eta2 = _scene(P2, ht, wd, 7)
+    assert len(np.unique(ii2)) * hs2 * ws2 > 192
+    prior2 = disps2 * g.uniform(0.8, 1.2, disps2.shape)
+    dsc2 = _f(g.uniform(0.9, 1.1, (P2, hs2, ws2))).clone()
+    nd2, ns2, cov2 = BA.JDSA(_f(tgt2)[None], _f(wgt2)[None], _f(eta2), SE3(_f(poses2)[None]), _f(disps2)[None], _f(intr2)[None], _f(prior2), dsc2,
+                             torch.from_numpy(ii2), torch.from_numpy(jj2), alpha)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(nd2).all()) and bool(torch.isfinite(cov2).all()) and float((nd2[0].cpu() - torch.from_numpy(disps2).float()).abs().max()) > 1e-5
+    # (3) the general solve: kernel path == dense-tensor fallback on a general (not block diagonal) system
+    gt = torch.Generator().manual_seed(4)
+    M, D, HW = 3, 6, 40
+    Es = (torch.randn(1, M, M, D, HW, generator=gt) * 0.3).to(DEV)
+    A = torch.randn(M * D, M * D, generator=gt)
+    Hs = (A @ A.T + 4.0 * torch.eye(M * D)).reshape(M, D, M, D).permute(0, 2, 1, 3)[None].contiguous().to(DEV)
+    vs, C, w = torch.randn(1, M, D, generator=gt).to(DEV), (torch.rand(1, M, HW, generator=gt) * 2 + 6.0).to(DEV), torch.randn(1, M, HW, generator=gt).to(DEV)
+    k = BA.schur_solve_mono_prior(C, w, Hs, Es, vs, dzcov=True)
+    f = BA._schur_mono_prior_large(C, w, Hs, Es, vs, 0.1, 1e-4, True)
+    for a, b in zip(k, f):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5)

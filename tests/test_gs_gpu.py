@@ -215,11 +215,20 @@ def test_grid_knn_is_exact_against_the_exhaustive_search_and_a_kdtree():
     clus[100:200] = clus[0:100]                                            # exact duplicates
     plane = torch.cat([torch.rand(50000, 2, generator=g), torch.zeros(50000, 1)], 1)
     tiny = torch.randn(9, 3, generator=g)
-    for name, pts in (("surface 250k", surf), ("clusters 210k + duplicates", clus), ("plane 50k", plane), ("tiny 9", tiny)):
+    # a few far outliers (sky / far-depth pixels that pass conf > 0) must not stretch the grid: 200 k surface points + 10 points
+    # at 100 x the extent.  The grid is built on the robust box (mean +- 3 sigma per axis), outliers are clamped into border cells
+    outl = torch.cat([surf[:200000], 300.0 * torch.randn(10, 3, generator=g)], 0)
+    times = {}
+    for name, pts in (("surface 250k", surf), ("clusters 210k + duplicates", clus), ("plane 50k", plane), ("tiny 9", tiny),
+                      ("surface 200k + 10 outliers at 100 x the extent", outl)):
         ex, gr, dt = both(pts.to(DEV).contiguous())
         err = float((ex - gr).abs().max() / ex.abs().max().clamp_min(1e-30))
         print(f"[gs knn grid] {name}: max |grid - exhaustive| / max = {err:.2e}, grid search {1e3 * dt:.2f} ms")
         assert err < 1e-6, (name, err)
+        times[name] = dt
+    # with the bounding box of ALL points the surface fell into a handful of cells and the query degenerated to O(P^2) from global memory
+    # (measured: 0.9 s; 0.33 s with the robust box alone -- the ten outlier QUERIES walked every shell of the grid; 22 ms with their list scan)
+    assert times["surface 200k + 10 outliers at 100 x the extent"] < 0.1, times
     d, _ = cKDTree(surf.double().numpy()).query(surf[:2000].double().numpy(), k=4)
     ref = (d[:, 1:] ** 2).mean(axis=1)
     np.testing.assert_allclose(both(surf.to(DEV).contiguous())[1][:2000].cpu().numpy(), ref, rtol=2e-4, atol=1e-9)

@@ -76,7 +76,7 @@ def test_gaussian_map_equals_the_reference_gaussian_model_through_adam_densify_p
     (tests/golden/gaussian_model.npz): 4 Adam steps on seeded gradients with the densification statistics of a rendered view each ->
     densify_and_prune (gradient OR absolute-gradient-quantile rule, clone / split with the reference's own normal draws replayed, prune incl.
     the degenerate-scale rule; the screen-size rule is dead after densification_postfix zeroes max_radii2D, as in the reference) -> 3 steps ->
-    reset_opacity -> step -> second densification -> step.  After every phase: every parameter, both Adam moments (zero-padded for new rows,
+    reset_opacity -> step -> second densification -> step -> an iteration that densifies BEFORE its optimiser step -> one that resets the opacities before it.  After every phase: every parameter, both Adam moments (zero-padded for new rows,
     cut for pruned ones, zeroed for the reset opacities), the shared step count and the decayed position learning rate."""
     from cut3r_slam_amd import gs_mapper as GM
     f = np.load(os.path.join(GOLD, "gaussian_model.npz"))
@@ -93,11 +93,13 @@ def test_gaussian_map_equals_the_reference_gaussian_model_through_adam_densify_p
     gm._split_noise = lambda n: draws.pop(0)
     worst = {}
 
-    def step(it):
+    def step(it, between=None, densified=False, reset=False):
         gm.theta.grad = t(f"grad_{it}").clone()
         gm.add_densification_stats(t(f"vs_{it}"), t(f"vis_{it}"))
         gm.max_radii2D = t(f"radii_{it}").clone()
-        gm.step()
+        if between is not None:                  # where the reference's training loops densify / reset: between the statistics and optimizer.step()
+            between()
+        gm.step_like_reference(densified=densified, reset=reset)
         gm.zero_grad()
         gm.lr[0, 0:3] = GM.position_lr(op, it)
 
@@ -126,5 +128,14 @@ def test_gaussian_map_equals_the_reference_gaussian_model_through_adam_densify_p
     gm.densify_and_prune(max_grad, min_opacity, extent, None)
     step(8)
     check("e")
+    # the ORDER inside the reference's loops (gs_backend_per_frame.py:1025-1041): statistics -> densify_and_prune -> optimizer.step()
+    # with no gradients on the re-created parameters (no update, no moment update, the step count stays at 9 in every group), then
+    # statistics -> reset_opacity -> optimizer.step() (the opacity group is skipped, the others step)
+    step(9, between=lambda: gm.densify_and_prune(max_grad, min_opacity, extent, None), densified=True)
+    check("f")
+    assert set(f["f_steps_by_group"].tolist()) == {9.0} and gm.steps == 9
+    step(10, between=gm.reset_opacity, reset=True)
+    check("g")
+    assert dict(zip(f["group_names"].tolist(), f["g_steps_by_group"].tolist()))["opacity"] == 9.0       # (one count per block here: declared deviation)
     assert not draws
     print(f"[GaussianMap vs reference GaussianModel] {P} -> {int(f['n_after_densify'])} -> {len(gm)} Gaussians, worst relative errors", {k: f"{v:.1e}" for k, v in worst.items()})
