@@ -209,7 +209,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
         if cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0:
-            raise NotImplementedError("GaussianRasterizer: cov3D_precomp is not built (pass scales and rotations)")
+            raise NotImplementedError("rasterize_gaussians: pass scales and rotations (GaussianRasterizer.forward converts cov3D_precomp)")
         out, radii, buf = _forward(means3D, sh, colors_precomp, opacities, scales, rotations, raster_settings)
         ctx.raster_settings = raster_settings
         ctx.buf = buf
@@ -247,13 +247,50 @@ class GaussianRasterizer(nn.Module):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         if ((scales is None or rotations is None) and cov3D_precomp is None) or ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if cov3D_precomp is not None:
+            # precomputed 3-D covariances (forward.cu:363-371 takes them instead of computeCov3D; unused by the live mapper,
+            # gaussian/renderer/__init__.py:128-143): the kernels work from the factors R, S (the ray-space plane and the inverse covariance
+            # are written from them, no eigen-solver on the device), so Sigma = R diag(s^2) R^T is factored here -- exact forward; gradients
+            # reach cov3D_precomp through torch.linalg.eigh (undefined where two eigenvalues coincide).  computeCov3D's scale_modifier does
+            # not apply to precomputed covariances (forward.cu:363-366): the call runs with modifier 1.
+            scales, rotations = cov3d_to_scale_rotation(cov3D_precomp)
+            st = self.raster_settings
+            settings = st._replace(scale_modifier=1.0) if hasattr(st, "_replace") else st
+            empty = torch.Tensor([])
+            return rasterize_gaussians(means3D, means2D, shs if shs is not None else empty, colors_precomp if colors_precomp is not None else empty,
+                                       opacities, scales, rotations, empty, settings)
         empty = torch.Tensor([])
         return rasterize_gaussians(means3D, means2D, shs if shs is not None else empty, colors_precomp if colors_precomp is not None else empty,
                                    opacities, scales if scales is not None else empty, rotations if rotations is not None else empty,
                                    cov3D_precomp if cov3D_precomp is not None else empty, self.raster_settings)
 
     def integrate(self, *args, **kwargs):
+        """RaDe-GS's `integrate` evaluates the Gaussians' opacity field at arbitrary 3-D points for mesh extraction (marching tetrahedra,
+        diff_gaussian_rasterization/__init__.py:251-298).  DECISION (round 4): not built -- no file of the reference's SLAM path calls it
+        (hislam2/gaussian/renderer/__init__.py:128-143 renders through forward() only; mesh extraction lives in the upstream RaDe-GS
+        scripts, outside this repository's scope table)."""
         raise NotImplementedError("GaussianRasterizer.integrate (mesh extraction) is not on the SLAM path and is not built")
+
+
+def cov3d_to_scale_rotation(cov6):
+    """[P,6] upper-triangular 3-D covariances (xx, xy, xz, yy, yz, zz: computeCov3D's layout, forward.cu:113-150) -> (scales [P,3],
+    rotations [P,4] real-first unit quaternions) with Sigma = R diag(s^2) R^T.  Differentiable (torch.linalg.eigh)."""
+    c = cov6.float()
+    S = torch.stack([c[:, 0], c[:, 1], c[:, 2], c[:, 1], c[:, 3], c[:, 4], c[:, 2], c[:, 4], c[:, 5]], -1).reshape(-1, 3, 3)
+    w, V = torch.linalg.eigh(S)
+    V = V * torch.where(torch.linalg.det(V) < 0, -1.0, 1.0)[:, None, None]          # a proper rotation (flipping all three axes keeps R diag R^T)
+    scales = w.clamp_min(0).sqrt()
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = [V[:, i, j] for i in range(3) for j in range(3)]
+    # quaternion (r, x, y, z) from a rotation matrix: the candidate with the largest denominator per row
+    q_abs = torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], -1).clamp_min(0).sqrt()
+    cand = torch.stack([torch.stack([q_abs[:, 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+                        torch.stack([m21 - m12, q_abs[:, 1] ** 2, m10 + m01, m02 + m20], -1),
+                        torch.stack([m02 - m20, m10 + m01, q_abs[:, 2] ** 2, m12 + m21], -1),
+                        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[:, 3] ** 2], -1)], -2)
+    cand = cand / (2.0 * q_abs[..., None].clamp_min(0.1))
+    best = q_abs.argmax(-1)
+    q = cand[torch.arange(cand.shape[0], device=cand.device), best]
+    return scales, q / q.norm(dim=-1, keepdim=True)
 
 
 def distCUDA2(points):

@@ -111,6 +111,12 @@ class Cut3rModel:
         self._head_stream = None
         self._side = None
         self._head_side = None
+        # one-window schedule: key / value branches of a decoder layer on their own capture streams (CUT3R_KV_FORK; rows <= CUT3R_KV_FORK_ROWS).
+        # OFF: measured round 4 (tools/bench_wb1.py, profiles/r04/kvfork.log) 28.2 ms per window against 23.5 ms without -- every edge between
+        # two capture streams becomes a barrier packet pair in the hipGraph and 4 more of them per layer cost more than the overlap returns
+        self.kv_fork = _os.environ.get("CUT3R_KV_FORK", "0") != "0"
+        self.kv_fork_rows = int(_os.environ.get("CUT3R_KV_FORK_ROWS", "2048"))
+        self._kv_streams = None
         self._prep(state_dict)
 
     # ------------------------------------------------------------------ reference-compatible constructors
@@ -440,7 +446,7 @@ class Cut3rModel:
         return feat, pos, im_shape
 
     # ------------------------------------------------------------------ decoder block
-    def _dec_block(self, tag, p, x, y, xpos, ypos, heads, out, B=1, pre_ln=False, xs=None, ys=None, os_=None):
+    def _dec_block(self, tag, p, x, y, xpos, ypos, heads, out, B=1, pre_ln=False, xs=None, ys=None, os_=None, kv_stream=None, kv_only=False):
         """x fp32 [B*Nx,C], y fp32 [B*Ny,C] -> out fp32 [B*Nx,C]   (dust3r/blocks.py:292-297).  B = independent
         sequences (tracking windows batched through the decoder).  pre_ln: norm1(x) and norm_y(y) are already in this
         block's `.ln16` / `.y16` buffers (`_dual_norms`).
@@ -474,6 +480,9 @@ class Cut3rModel:
             if ypos is not None and not fuse_k:
                 self._rope(k, ypos)
 
+        if kv_only:               # the key / value branch alone (it depends on y only): run by the caller on its own capture stream
+            kv_branch()
+            return None
         if xs is not None:
             self._self_attn(tag, xs[0], B, Nx, heads, xpos, p + ".attn", out, x, ln=xs[1], emit=em)
         else:
@@ -489,7 +498,10 @@ class Cut3rModel:
             self._linear(ln16, p + ".cross_attn.projq", q.view(B * Nx, Cc), skinny=(Nx == 1), rope=(xpos, Cc, D) if fuse_q else None)
         if xpos is not None and not fuse_q:
             self._rope(q, xpos)
-        kv_branch()      # (forking this onto its own capture stream was tried: nested forks crash hipGraph capture_end on ROCm 7.2)
+        if kv_stream is not None:
+            torch.cuda.current_stream().wait_stream(kv_stream)      # the branch ran beside the self-attention half (forked by the caller)
+        else:
+            kv_branch()      # (forking it from INSIDE this block's stream was tried: nested forks crash hipGraph capture_end on ROCm 7.2)
         a = self.buf(tag + ".cattn", (B, Nx, heads, D), F16)
         ops.attention(q, k, v, a, D ** -0.5)
         self._linear(a.view(B * Nx, Cc), p + ".cross_attn.proj", out, res1=out, skinny=(Nx == 1), emit=em)
@@ -859,11 +871,29 @@ class Cut3rModel:
                         self._dual_norms(l, a, s_a)
                     if fork:
                         cur = torch.cuda.current_stream()
+                        kvf = self.kv_fork and Wn * (N + 1) <= self.kv_fork_rows
+                        kS = kI = None
+                        if kvf:
+                            # one-window schedule: the key / value projections of both blocks (LayerNorm_y -> projk|projv -> RoPE: they read the
+                            # layer's INPUTS only) leave the two block chains and run on two more capture streams, forked here -- at the layer
+                            # level, siblings of the block streams -- and joined in front of each block's cross attention
+                            if self._kv_streams is None:
+                                self._kv_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+                            kS, kI = self._kv_streams
+                            kS.wait_stream(cur)
+                            kI.wait_stream(cur)
+                            with torch.cuda.stream(kS):
+                                self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre,
+                                                xs=xsa, ys=xa, os_=xsb, kv_only=True)
+                            with torch.cuda.stream(kI):
+                                self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre, xs=xa, ys=xsa,
+                                                os_=xb, kv_only=True)
                         self._side.wait_stream(cur)
                         with torch.cuda.stream(self._side):
                             self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre,
-                                            xs=xsa, ys=xa, os_=xsb)
-                        self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre, xs=xa, ys=xsa, os_=xb)
+                                            xs=xsa, ys=xa, os_=xsb, kv_stream=kS)
+                        self._dec_block("deci", f"dec_blocks.{l}", a, s_a, pos_img, pos_state, cfg.dec_num_heads, b, Wn, pre_ln=pre, xs=xa, ys=xsa, os_=xb,
+                                        kv_stream=kI)
                         cur.wait_stream(self._side)
                     else:
                         self._dec_block("decs", f"dec_blocks_state.{l}", s_a, a, pos_state, pos_img, cfg.state_dec_num_heads, s_b, Wn, pre_ln=pre,

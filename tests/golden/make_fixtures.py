@@ -810,6 +810,23 @@ def gen_gaussian_model_fixture():
           "| steps by group after densify-then-step", fx["f_steps_by_group"], "after reset-then-step", fx["g_steps_by_group"])
 
 
+def gen_tf32_budgets():
+    """tests/golden/tf32_budgets.json: the TF32 halves of the production-shape precision budgets (tests/tf32_budget.py: what they are and
+    why they are cached).  These are outputs of the CPU RESTATEMENT (oracle/), not of the reference -- the restatement itself is pinned
+    to the reference by the fixtures above; ~5 minutes of CPU on 8 cores; on request only."""
+    import json
+    root = os.path.dirname(os.path.dirname(HERE))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from tests import tf32_budget as TB
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    out = {"six_view_window": TB.six_view_window(False), "six_view_window_outliers": TB.six_view_window(True), "e2e_production_33": TB.e2e_production()}
+    out["_generated_with"] = {"threads": torch.get_num_threads(), "torch": torch.__version__}
+    with open(TB.PATH, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote tf32_budgets", {k: (v if k.startswith("six") else "...") for k, v in out.items()})
+
+
 def handover_mapper_update(data):
     """the deterministic 'mapper' of the hand-over fixture (a test double for the GS backend's interface, shared with the tests): refined
     poses, depths with a hole, full-resolution pointmaps -- simple functions of the packet it was given"""
@@ -1155,6 +1172,8 @@ if __name__ == "__main__":
         gen_nms_fixture()
     if "camera" in what:
         gen_camera_fixture()
+    if "tf32_budgets" in what:
+        gen_tf32_budgets()
     if "rope" in what:
         gen_rope_fixture()
     if "graph" in what:

@@ -32,6 +32,7 @@ from cut3r_slam_amd.eval_ate import ate_rmse  # noqa: E402
 from cut3r_slam_amd.model import Cut3rModel  # noqa: E402
 from cut3r_slam_amd.slam import Cut3rSlam  # noqa: E402
 from oracle import slam_run as SR  # noqa: E402
+from tests import tf32_budget  # noqa: E402
 
 DEV = "cuda:0"
 H, W = 384, 512
@@ -63,8 +64,9 @@ def test_three_windows_at_production_shape_match_cpu_fp32_and_stay_inside_the_tf
     traj = np.concatenate([ts.reshape(-1, 1).astype(np.float64), poses.astype(np.float64)], 1)
     # ---- CPU restatement, exact fp32 and TF32 operands
     so32 = SR.run_stream(cfg, sd, frames, INTR, mf, precision="fp32")
-    sotf = SR.run_stream(cfg, sd, frames, INTR, mf, precision="tf32")
-    ref, tf = so32.trajectory(), sotf.trajectory()
+    # the TF32 run of the restatement = the budget: cached (tests/tf32_budget.py; CUT3R_LIVE_TF32=1 recomputes it here, ~90 s of CPU)
+    tfb = tf32_budget.cached("e2e_production_33") or tf32_budget.e2e_production(so32)
+    ref, tf = so32.trajectory(), np.asarray(tfb["trajectory"], np.float64)
     assert np.isfinite(traj).all() and np.isfinite(ref).all()
     assert np.array_equal(traj[:, 0], ref[:, 0]), (traj[:, 0], ref[:, 0])
     assert len(ref) == 17 and [w[:2] for w in so32.windows] == [(0, 6), (5, 11), (10, 16), (15, 17)] and slam.tracker.t1 == so32.t1 == 17
@@ -77,7 +79,7 @@ def test_three_windows_at_production_shape_match_cpu_fp32_and_stay_inside_the_tf
     dr_hip = float(_rot_angle(traj[:, 4:8], ref[:, 4:8]).max())
     dr_tf = float(_rot_angle(tf[:, 4:8], ref[:, 4:8]).max())
     ii, jj, _ = slam.graph.edges_numpy()
-    e_gpu, e_ref, e_tf = list(zip(ii.tolist(), jj.tolist())), list(zip(so32.graph.ii, so32.graph.jj)), list(zip(sotf.graph.ii, sotf.graph.jj))
+    e_gpu, e_ref, e_tf = list(zip(ii.tolist(), jj.tolist())), list(zip(so32.graph.ii, so32.graph.jj)), [tuple(e) for e in tfb["edges"]]
     near, unexplained = [], []
     for (i, j) in sorted(set(e_gpu) ^ set(e_ref)):
         r = so32.graph.ratios.get((max(i, j), min(i, j)))
@@ -98,11 +100,11 @@ def test_three_windows_at_production_shape_match_cpu_fp32_and_stay_inside_the_tf
     k = so32.t1
     d_ref = so32.state["depth"][:k]
     e_depth = float((slam.keyframes.depth[:k].cpu() - d_ref).abs().max() / d_ref.abs().max())
-    e_depth_tf = float((sotf.state["depth"][:k] - d_ref).abs().max() / d_ref.abs().max())
+    e_depth_tf = float(tfb["e_depth_vs_fp32"])
     nsub = (k - 1) // 5
     pm_ref = so32.state["submap_ds"][:nsub]
     e_pm = float((slam.keyframes.submap_ds[:nsub].cpu() - pm_ref).abs().max() / pm_ref.abs().max())
-    e_pm_tf = float((sotf.state["submap_ds"][:nsub] - pm_ref).abs().max() / pm_ref.abs().max())
+    e_pm_tf = float(tfb["e_submaps_vs_fp32"])
     print(f"[e2e production 384x512] stored depth: hip {e_depth:.2e} tf32 {e_depth_tf:.2e} | stored stride-2 world pointmaps: hip {e_pm:.2e} tf32 {e_pm_tf:.2e} "
           "(max abs error / max abs value, vs CPU fp32)")
     assert e_depth <= 2.0 * e_depth_tf + 2e-4 and e_pm <= 2.0 * e_pm_tf + 2e-4
@@ -126,9 +128,7 @@ def test_three_windows_at_production_shape_match_cpu_fp32_and_stay_inside_the_tf
     e_hip = {"pose": rel(kfs.pose[:k].cpu().numpy(), f["pose"]), "depth": rel(kfs.depth[:k, 8::24, 8::32].cpu().numpy(), f["depth_samples"]),
              "submaps": rel(kfs.submap_ds[:nsub_f, :, 4::12, 4::16].cpu().numpy(), f["submap_samples"]),
              "conf": rel(kfs.conf_ds[:nsub_f].double().mean(dim=(2, 3)).cpu().numpy(), f["conf_mean"])}
-    e_tf = {"pose": rel(sotf.state["pose"][:k].numpy(), f["pose"]), "depth": rel(sotf.state["depth"][:k, 8::24, 8::32].numpy(), f["depth_samples"]),
-            "submaps": rel(sotf.state["submap_ds"][:nsub_f, :, 4::12, 4::16].numpy(), f["submap_samples"]),
-            "conf": rel(sotf.state["conf_ds"][:nsub_f].double().mean(dim=(2, 3)).numpy(), f["conf_mean"])}
+    e_tf = {a: float(b) for a, b in tfb["vs_reference_loop"].items()}
     print("[e2e production 384x512 vs the REFERENCE'S OWN loop] CPU restatement:", {a: f"{b:.1e}" for a, b in e_or.items()}, "| HIP:", {a: f"{b:.1e}" for a, b in e_hip.items()},
           "| CPU restatement with TF32 operands (the reference's arithmetic on its GPUs):", {a: f"{b:.1e}" for a, b in e_tf.items()})
     assert max(e_or.values()) < 1e-4, e_or                               # fp32 on both sides (different GEMM blocking at width 1024)

@@ -89,6 +89,36 @@ def test_forward_outputs_match_restatement(H, W, P, deg, ks, cam, precomp):
     _compare(mcoord, ref["mcoord"], "mcoord", 2e-5, 0.006)
 
 
+def test_precomputed_covariances_render_like_scales_and_rotations():
+    """GaussianRasterizer.forward(cov3D_precomp=...) (forward.cu:363-371): Sigma = R diag(s^2) R^T of a scene with anisotropic scales and
+    general rotations, handed over as six numbers per Gaussian, renders the same seven images; a gradient reaches the covariances"""
+    from cut3r_slam_amd.gaussian_rasterizer import cov3d_to_scale_rotation
+    H, W, P = 64, 80, 300
+    means, scales, q, op, shs = _scene(P, P + 1)
+    st = GO.camera_settings(H, W, 1.0, 1.0 * H / W, _w2c(0.15, -0.2, (0.1, -0.05, 0.3)), bg=(0.1, 0.2, 0.3), sh_degree=1)
+    f = lambda t: t.float().to(DEV)
+    qn = q / q.norm(dim=-1, keepdim=True)
+    r, x, y, z = qn.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(P, 3, 3)
+    Sig = R @ torch.diag_embed(scales ** 2) @ R.transpose(1, 2)
+    cov6 = torch.stack([Sig[:, 0, 0], Sig[:, 0, 1], Sig[:, 0, 2], Sig[:, 1, 1], Sig[:, 1, 2], Sig[:, 2, 2]], -1)
+    s_, q_ = cov3d_to_scale_rotation(f(cov6))
+    assert float((s_.sort(-1).values.cpu().double() - scales.sort(-1).values).abs().max() / scales.max()) < 1e-4
+    rast = GaussianRasterizer(_settings(st))
+    kw = dict(means3D=f(means), means2D=torch.zeros(P, 3, device=DEV), opacities=f(op), shs=f(shs))
+    a = rast(scales=f(scales), rotations=f(q), **kw)
+    c6 = f(cov6).requires_grad_(True)
+    b = rast(cov3D_precomp=c6, **kw)
+    torch.cuda.synchronize()
+    for i, name in ((0, "color"), (2, "coord"), (4, "depth"), (6, "alpha"), (7, "normal")):
+        err = float((a[i] - b[i]).abs().max() / a[i].abs().max().clamp_min(1e-9))
+        bad = float(((a[i] - b[i]).abs() > 2e-3 * a[i].abs().max()).float().mean())
+        assert bad < 0.004, (name, err, bad)                 # (a radius that rounds differently moves a few tile-border pixels)
+    b[0].sum().backward()
+    assert c6.grad is not None and bool(torch.isfinite(c6.grad).all()) and float(c6.grad.abs().max()) > 0
+
+
 def test_argument_checks_and_empty_scene():
     st = GO.camera_settings(32, 32, 1.0, 1.0, torch.eye(4, dtype=torch.float64), bg=(0.5, 0.25, 0.0))
     rast = GaussianRasterizer(_settings(st))
