@@ -57,6 +57,7 @@ SIGNATURES = {
     "cut3r_rope2d_table": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p],
     "cut3r_gemv_f16w": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                         c_void_p, c_int, c_int, c_void_p],
+    "cut3r_attention_variant": [c_int],
     "cut3r_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                             c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_float, c_void_p],
     "cut3r_im2col_patch": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],

@@ -127,6 +127,11 @@ int cut3r_attention_f16(const void* q, const void* k, const void* v, void* out, 
                         long long q_sb, long long q_sn, long long k_sb, long long k_sn, long long v_sb, long long v_sn,
                         long long o_sb, long long o_sn, float scale, void* stream);
 
+/* which kernel serves the 48- and 64-wide heads: 1 (default) the software-pipelined LDS-DMA kernel, 0 the register-staged one.
+ * Both give the same bits (tests/test_kernels_gpu.py); the switch exists for that test and for A/B timing.  v < 0 only queries.
+ * Returns the previous setting.  (No reference counterpart: a tuning knob of this library.) */
+int cut3r_attention_variant(int v);
+
 /* ---- elementwise / layout helpers of the ViT path -------------------------------------------------------------- */
 /* PatchEmbed conv 16x16/s16 as im2col (src/dust3r/patch_embed.py:18-32): img fp32 [B,C,H,W] -> fp16 [B*(H/P)*(W/P), C*P*P],
  * k ordered (c,py,px) == Conv2d weight.flatten(1).  If u8 != 0 the input is uint8 and (x/255-0.5)/0.5

@@ -263,6 +263,45 @@ def test_attention_vs_sdpa(B, H, Nq, Nk, D):
     _report(f"attention B{B} H{H} Nq{Nq} Nk{Nk} D{D}", out.float(), ref, 3e-3)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [
+    (2, 16, 768, 768, 64), (2, 12, 769, 769, 64), (2, 12, 769, 768, 64), (2, 16, 768, 768, 48), (2, 16, 768, 769, 48),
+    (3, 7, 769, 769, 48), (9, 5, 300, 129, 64), (4, 8, 200, 100, 64), (4, 8, 130, 65, 48), (5, 8, 33, 640, 64), (4, 8, 256, 64, 64),
+    (4, 8, 257, 63, 48), (4, 8, 300, 193, 48), (1, 3, 7, 12, 48), (1, 3, 1, 1, 64), (28, 12, 769, 769, 64)])
+def test_pipelined_attention_kernel_gives_the_bits_of_the_staged_one(B, H, Nq, Nk, D):
+    """attn_pipe_kernel (LDS-DMA ring, one barrier per tile, softmax of tile j beside the MFMAs of tiles j-1 and j+1; the default for
+    48- and 64-wide heads) against attn_kernel (register-staged, two barriers per tile): the same arithmetic per row in the same order,
+    so the SAME BITS -- for whole and ragged key tiles, the 64 m + 1 key counts of the decoder (key 0 folded in first), query counts that
+    leave idle waves, (batch x head) counts that do not fill the 8-wide XCD groups, and a spiked key that moves the running maximum late.
+    Either kernel is also inside the fp32-SDPA tolerance of test_attention_vs_sdpa."""
+    from cut3r_slam_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 7 + Nq + Nk + D)
+    q = (torch.randn(B, Nq, H, D, generator=g) * 1.5).half().to(DEV)
+    k = (torch.randn(B, Nk, H, D, generator=g) * 1.5).half()
+    v = torch.randn(B, Nk, H, D, generator=g).half().to(DEV)
+    k[:, min(3, Nk - 1)] *= 6.0
+    if Nk > 70:
+        k[0, 69, -1] *= 8.0
+    k = k.to(DEV)
+    outs = []
+    prev = lib.cut3r_attention_variant(-1)
+    try:
+        for variant in (0, 1):
+            lib.cut3r_attention_variant(variant)
+            o = torch.full((B, Nq, H, D), float("nan"), dtype=torch.float16, device=DEV)
+            ops.attention(q, k, v, o, D ** -0.5)
+            torch.cuda.synchronize()
+            outs.append(o.cpu())
+    finally:
+        lib.cut3r_attention_variant(prev)
+    assert prev == 1, "the pipelined kernel is the default"
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), f"{int((outs[0] != outs[1]).sum())} elements differ between the two attention kernels"
+    ref = F.scaled_dot_product_attention(q[:1].float().permute(0, 2, 1, 3), k[:1].float().permute(0, 2, 1, 3),
+                                         v[:1].float().permute(0, 2, 1, 3), scale=D ** -0.5).permute(0, 2, 1, 3)
+    _report(f"pipelined attention B{B} H{H} Nq{Nq} Nk{Nk} D{D}", outs[1][:1].float(), ref.cpu(), 3e-3)
+
+
 # ------------------------------------------------------------------------------------------------ RoPE / LN / helpers
 def test_rope_matches_reference_golden_and_oracle():
     f = np.load(os.path.join(GOLD, "rope2d.npz"))
