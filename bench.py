@@ -196,7 +196,8 @@ def probe_entries(res):
         if not n or ms <= 0 or k[0] == "shape":
             continue
         name = KernelProbe.GEMM.get(k[1], f"gemm tile {k[1]}") if k[0] == "gemm" else \
-            f"attn_kernel<{k[1]},4> ({'encoder self-attention' if k[2] == 'enc' else 'decoder self/cross attention'})"
+            (f"attn_pipe_kernel<{k[1]},1,4,4>" if k[1] in (48, 64) else f"attn_kernel<{k[1]},4>") + \
+            f" ({'encoder self-attention' if k[2] == 'enc' else 'decoder self/cross attention'})"
         out.append({"kernel": name, "bound": "mfma" if not (k[0] == "gemm" and k[1] == 16) else "hbm", "launches": n,
                     "avg_launch_us": round(ms * 1e3 / n, 2), "total_ms": round(ms, 3), "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_F16,
                     "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_F16, 4), "flops_per_launch": fl / n})
@@ -789,7 +790,8 @@ def main():
                                        "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2), "peak": PEAK_F16, "unit": "TFLOP/s",
                                        "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / PEAK_F16, 4), "share_of_large_gemm_time": round(ms2 / tot_ms, 3)})
                 for k, (n2, ms2, fl2, by2) in sorted((k, v) for k, v in res.items() if k[0] == "attn" and v[0]):
-                    others.append({"kernel": f"attn_kernel<{k[1]},4> ({'encoder self-attention [B,16,768,64]' if k[2] == 'enc' else 'decoder self/cross attention'})",
+                    others.append({"kernel": (f"attn_pipe_kernel<{k[1]},1,4,4>" if k[1] in (48, 64) else f"attn_kernel<{k[1]},4>")
+                                             + f" ({'encoder self-attention [B,16,768,64]' if k[2] == 'enc' else 'decoder self/cross attention'})",
                                    "bound": "mfma", "launches": n2, "avg_launch_us": round(ms2 * 1e3 / n2, 2), "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2),
                                    "peak": PEAK_F16, "unit": "TFLOP/s", "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / PEAK_F16, 4), "flops_per_launch": fl2 / n2})
                 roofline = {"bound": "mfma", "kernel": KernelProbe.GEMM[dom], "achieved": round(ach, 2), "peak": PEAK_F16, "unit": "TFLOP/s",
