@@ -367,17 +367,23 @@ def tracking_health(slam):
             "log_scale_absmax": round(float(st["log_scale_absmax"]), 4), "log_scale_last": round(float(st["log_scale_last"]), 4)}
 
 
-def overlap_mode_leg(model, slam_cls, dev, n_frames=800, lookahead=16, plain_frames=200):
-    """the maintained configs' schedule (kf_every=-1, skip=5, thresh=0.9; one 6-view window at a time) through
-    Cut3rSlam.run on a content-driven stream (cut3r_slam_amd.synth.slideshow_stream: one keyframe per 10 frames)"""
+def overlap_mode_leg(model, slam_cls, dev, n_frames=800, lookahead=16, plain_frames=200, deep_frames=2800, deep_lookahead=280, deep_wb=28):
+    """the maintained configs' schedule (kf_every=-1, skip=5, thresh=0.9) through Cut3rSlam.run on a content-driven stream
+    (cut3r_slam_amd.synth.slideshow_stream: one keyframe per 10 frames): frame by frame (the reference's loop), with a 16-frame look-ahead
+    of the keyframe test (one 6-view window at a time), and -- the mode's throughput form -- with `deep_lookahead` tested frames held back
+    and the keyframes they yield tracked `deep_wb` windows at a time (`Cut3rSlam.run_buffered` + `Tracking.frontend.window_batch`:
+    bit-identical keyframes, poses, depths and edges, tests/test_e2e_gpu.py)"""
     from cut3r_slam_amd import synth
-    config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": -1},
-                           "frontend": {"iteration": 0, "window_batch": 1}}}
     intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])
-    out = {"config": "kf_every=-1, skip=5, thresh=0.9, window_batch=1 (config/scannet_config.yaml:20-25)"}
-    warm = 160                          # initialisation window + first steady windows: graph captures, workspaces
-    frames = synth.slideshow_stream(warm + max(n_frames, plain_frames), H, W, hold=10, seed=0, device=dev)
-    for name, n, kw in (("buffered_lookahead", n_frames, {"lookahead": lookahead}), ("frame_by_frame", plain_frames, None)):
+    out = {"config": "kf_every=-1, skip=5, thresh=0.9 (config/scannet_config.yaml:20-25); window_batch=1 unless the entry says otherwise"}
+    legs = [("buffered_lookahead", n_frames, 160, {"lookahead": lookahead}, 1), ("frame_by_frame", plain_frames, 160, None, 1)]
+    if deep_frames > 0:
+        # (the warm-up holds two whole decoder batches: graph captures and workspaces of the batched shapes)
+        legs.append(("buffered_lookahead_window_batch", deep_frames, 2 * deep_wb * 50 + 200, {"lookahead": deep_lookahead}, deep_wb))
+    frames = synth.slideshow_stream(max(w + n for _, n, w, _, _ in legs), H, W, hold=10, seed=0, device=dev)
+    for name, n, warm, kw, wb in legs:
+        config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": -1},
+                               "frontend": {"iteration": 0, "window_batch": wb}}}
         slam = slam_cls(model, config, (H, W), buffer=(warm + n) // 10 + 16, device=dev)
         if kw is None:
             for t in range(warm):
@@ -395,10 +401,12 @@ def overlap_mode_leg(model, slam_cls, dev, n_frames=800, lookahead=16, plain_fra
         torch.cuda.synchronize()
         el = time.perf_counter() - tic
         out[name] = {"frames_per_s": round(n / el, 1), "frames": n, "keyframes": slam.keyframes.counter.value - k0,
-                     "tested_frames": n // 5, "windows": (slam.tracker.t1 - w0) // 5, "ms_per_frame": round(1e3 * el / n, 3)}
+                     "tested_frames": n // 5, "windows": (slam.tracker.t1 - w0) // 5, "ms_per_frame": round(1e3 * el / n, 3), "window_batch": wb,
+                     "health": tracking_health(slam)}
         if kw is not None:
-            out[name]["lookahead_tested_frames"] = lookahead
-            out[name]["latency_frames"] = lookahead * 5
+            out[name]["lookahead_tested_frames"] = kw["lookahead"]
+            out[name]["latency_frames"] = kw["lookahead"] * 5
+        del slam
     return out
 
 

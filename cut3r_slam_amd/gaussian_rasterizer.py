@@ -5,8 +5,9 @@ rasteriser in csrc/gs.hip.  Call site: hislam2/gaussian/renderer/__init__.py:101
 Same argument meaning, same outputs `(color, radii, coord, mcoord, depth, mdepth, alpha, normal)`, same exceptions for the
 either/or argument pairs.  Forward and backward.  The backward pass returns the exact derivatives of the forward function (forward-mode duals through
 the per-Gaussian projection); `means2D` receives the screen-space gradient in the reference's units (x, y in NDC, z = |.| sum).
-Not built: `cov3D_precomp` (the live renderer passes scales + rotations; the ray-space plane of this rasteriser is written from
-R and S directly) and `integrate` (mesh extraction, not on the SLAM path) raise NotImplementedError.
+`cov3D_precomp` is accepted (round 4): the packed covariance is factored into R and S on the host side of the call (symmetric
+eigendecomposition, differentiable), because the ray-space plane of this rasteriser is written from R and S directly.  Not built, by
+decision: `integrate` (mesh extraction; no file of the SLAM path calls it) raises NotImplementedError.
 There is no CPU fallback: without the HIP library every call raises."""
 from __future__ import annotations
 

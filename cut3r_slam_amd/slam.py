@@ -141,6 +141,36 @@ class Cut3rSlam:
                     on_frame(t_start + i, out)
 
     @torch.no_grad()
+    def run_stream(self, items, lookahead=1, on_frame=None):
+        """The look-ahead of `run_buffered` over an ITERATOR of per-frame items (tstamp, image, intrinsics, image_ds, intrinsics_ds,
+        second_last_frame, last_frame) -- demo.py's loop over `stream.mono_stream` (demo_s.py:151-160).  `lookahead * skip` items are
+        held back; in overlap mode their tested frames (every `skip`-th, plus the always-kept first / second-last / last) go through
+        the encoder as ONE batch with the keyframe decisions taken on the device, then every held item goes through `run()` in order.
+        With `Tracking.frontend.window_batch` > 1 the keyframes found this way are tracked `window_batch` windows at a time.  Keyframes,
+        poses, depths and edges are those of the frame-by-frame loop (bit-identical); the price is the latency of the held frames."""
+        f = self.filterx
+        overlap_mode = not (f.kf_every > 0)
+        chunk = max(1, int(lookahead)) * max(1, int(f.skip))
+        held = []
+
+        def flush():
+            if overlap_mode and lookahead > 1:
+                idx = [k for k, it in enumerate(held) if int(it[0]) % f.skip == 0 or it[5] or it[6] or (self.keyframes.counter.value == 0 and k == 0)]
+                if idx:
+                    f.prefetch(torch.cat([held[k][3][:1] for k in idx], 0), [int(held[k][0]) for k in idx], [bool(held[k][5] or held[k][6]) for k in idx])
+            for it in held:
+                out = self.run(it[0], it[1], it[2], it[3], it[4], second_last_frame=bool(it[5]), last_frame=bool(it[6]))
+                if on_frame is not None:
+                    on_frame(it[0], out)
+            held.clear()
+
+        for it in items:
+            held.append(it)
+            if len(held) >= chunk:
+                flush()
+        flush()
+
+    @torch.no_grad()
     def terminate(self, add_kf=False, gap=30, finalize_iters=None, gaussian_retrain=False, retrain_iters=10000):
         """hi2.py:152-229.  With the Gaussian mapper attached (`self.mapper`) the extra views go to `mapper.add_new_view`, the mapper
         finalises (`GSMapper.finalize`: a global BA of `finalize_iters` iterations, default the configured position_lr_max_steps as the

@@ -62,6 +62,9 @@ def main(argv=None):
     p.add_argument("--seed", type=int, default=0, help="seed of --synthetic-weights")
     p.add_argument("--small", action="store_true", help="debug: tiny architecture (with --synthetic-weights)")
     p.add_argument("--window-batch", type=int, default=1, help="tracking windows decoded together (1 = reference schedule)")
+    p.add_argument("--lookahead", type=int, default=1, help="overlap mode (kf_every = -1): hold back LOOKAHEAD x skip frames, encode their tested "
+                   "frames as one batch and take the keyframe decisions on the device (1 = the reference's frame-by-frame loop; identical "
+                   "results, latency LOOKAHEAD x skip frames; with --window-batch the found keyframes are tracked several windows at a time)")
     p.add_argument("--device", default="cuda:0")
     p.add_argument("--gs-final-iters", type=int, default=None, help="iterations of the mapper's closing global BA (default: the configured "
                    "position_lr_max_steps, as the reference; 0 skips it)")
@@ -95,19 +98,41 @@ def main(argv=None):
     n_files = len(os.listdir(args.imagedir))
     buffer = min(1000, n_files // 5 + 150) if args.buffer < 0 else args.buffer
     slam, t0, nframes = None, time.time(), 0
-    for t, image, intr, image_ds, intr_ds, is_last in stream.mono_stream(args.imagedir, args.calib, args.undistort, args.cropborder,
-                                                                         args.start, args.length, device=args.device):
-        if slam is None:
-            slam = Cut3rSlam(model, cfg, (image_ds.shape[2], image_ds.shape[3]), buffer=buffer, device=args.device)
-            if args.gs:
-                from cut3r_slam_amd.gs_mapper import GSMapper
-                if "Training" not in cfg or "opt_params" not in cfg:
-                    raise SystemExit("--gs needs the Training and opt_params sections in --config")
-                k = [float(v) for v in intr_ds[0].reshape(-1)[:4]]
-                slam.mapper = GSMapper(cfg, k[0], k[1], k[2], k[3], downsample_ratio=slam.downsample_ratio, device=args.device)
-        slam.run(t, image, intr[0].float(), image_ds, intr_ds[0].float(), second_last_frame=(t + args.start == n_files - 2),
-                 last_frame=(t + args.start == n_files - 1))      # demo_s.py:158-159: a --length cut does NOT flush the tail window
-        nframes += 1
+    frames = stream.mono_stream(args.imagedir, args.calib, args.undistort, args.cropborder, args.start, args.length, device=args.device)
+
+    def make_slam(image_ds, intr_ds):
+        s_ = Cut3rSlam(model, cfg, (image_ds.shape[2], image_ds.shape[3]), buffer=buffer, device=args.device)
+        if args.gs:
+            from cut3r_slam_amd.gs_mapper import GSMapper
+            if "Training" not in cfg or "opt_params" not in cfg:
+                raise SystemExit("--gs needs the Training and opt_params sections in --config")
+            k = [float(v) for v in intr_ds[0].reshape(-1)[:4]]
+            s_.mapper = GSMapper(cfg, k[0], k[1], k[2], k[3], downsample_ratio=s_.downsample_ratio, device=args.device)
+        return s_
+
+    def items():
+        # demo_s.py:158-159: a --length cut does NOT flush the tail window (the flags look at the directory, not at the cut)
+        for t, image, intr, image_ds, intr_ds, is_last in frames:
+            yield (t, image, intr[0].float(), image_ds, intr_ds[0].float(), t + args.start == n_files - 2, t + args.start == n_files - 1)
+
+    if args.lookahead > 1:
+        it = items()
+        first = next(it, None)
+        if first is not None:
+            slam = make_slam(first[3], first[4][None])
+            counted = []
+
+            def chain():
+                yield first
+                yield from it
+            slam.run_stream(chain(), lookahead=args.lookahead, on_frame=lambda t_, out_: counted.append(t_))
+            nframes = len(counted)
+    else:
+        for item in items():
+            if slam is None:
+                slam = make_slam(item[3], item[4][None])
+            slam.run(item[0], item[1], item[2], item[3], item[4], second_last_frame=item[5], last_frame=item[6])
+            nframes += 1
     if slam is None:
         raise SystemExit(f"{args.imagedir}: no frames")
     torch.cuda.synchronize()

@@ -31,14 +31,16 @@ INTR = np.array([80.0, 80.0, 47.5, 31.5], np.float32)
 NEAR = 0.02                     # half-width of the "near the 0.3 overlap threshold" band used to explain edge differences
 
 
-def _gpu_run(cfg, sd, frames, mf, buffered=False, window_batch=1):
+def _gpu_run(cfg, sd, frames, mf, buffered=False, window_batch=1, streamed=0):
     model = Cut3rModel(cfg, sd, DEV, minimal=True)
     conf = {"Tracking": {"motion_filter": dict(mf), "frontend": {"iteration": 0, "window_batch": window_batch}}}
     slam = Cut3rSlam(model, conf, (H, W), buffer=frames.shape[0] + 8, device=DEV)
     intr = torch.from_numpy(INTR)
     fr = frames.to(DEV)
     n = fr.shape[0]
-    if buffered:
+    if streamed:                               # demo.py --lookahead: an iterator of per-frame items, `streamed` tested frames held back
+        slam.run_stream(((t, fr[t:t + 1], intr, fr[t:t + 1], intr, t == n - 2, t == n - 1) for t in range(n)), lookahead=streamed)
+    elif buffered:
         slam.run_buffered(fr, intr, lookahead=6)
     else:
         for t in range(n):
@@ -123,6 +125,15 @@ def test_overlap_mode_stream_trajectory_matches_cpu_path_and_buffered_driver_is_
     k = slam.tracker.t1
     assert torch.equal(slam.keyframes.featI[:k], slam_b.keyframes.featI[:k])
     assert torch.equal(slam.keyframes.depth[:k], slam_b.keyframes.depth[:k])
+    # the reference's own mode at buffered throughput (demo.py --lookahead N --window-batch W): an item iterator with 12 tested frames held
+    # back, the keyframes they yield tracked two windows at a time -- the same keyframes, poses, depths and ordered edges, bit for bit
+    slam_s, traj_s = _gpu_run(cfg, sd, frames, mf, streamed=12, window_batch=2)
+    assert np.array_equal(traj, traj_s)
+    assert slam_s.filterx.stats["encoded"] <= 2 and slam_s.tracker.t1 == k
+    for a, b in zip(slam.graph.edges_numpy(), slam_s.graph.edges_numpy()):
+        assert np.array_equal(a, b)
+    assert torch.equal(slam.keyframes.depth[:k], slam_s.keyframes.depth[:k])
+    assert torch.equal(slam.keyframes.submap_ds[:(k - 1) // 5], slam_s.keyframes.submap_ds[:(k - 1) // 5])
 
 
 def test_overlap_decisions_at_production_encoder_shape_match_oracle_on_same_features():
