@@ -379,7 +379,7 @@ def overlap_mode_leg(model, slam_cls, dev, n_frames=800, lookahead=16, plain_fra
     legs = [("buffered_lookahead", n_frames, 160, {"lookahead": lookahead}, 1), ("frame_by_frame", plain_frames, 160, None, 1)]
     if deep_frames > 0:
         # (the warm-up holds two whole decoder batches: graph captures and workspaces of the batched shapes)
-        legs.append(("buffered_lookahead_window_batch", deep_frames, 2 * deep_wb * 50 + 200, {"lookahead": deep_lookahead}, deep_wb))
+        legs.append(("buffered_lookahead_window_batch", deep_frames, 2 * deep_wb * 50 + 200, {"lookahead": deep_lookahead, "pipeline": True}, deep_wb))
     frames = synth.slideshow_stream(max(w + n for _, n, w, _, _ in legs), H, W, hold=10, seed=0, device=dev)
     for name, n, warm, kw, wb in legs:
         config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": -1},

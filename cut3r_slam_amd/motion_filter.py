@@ -93,6 +93,63 @@ class MotionFilter:
         self._ahead = {int(t): (feats[i], bool(host[B + i]), int(host[i]), forced[i]) for i, t in enumerate(tstamps)}
         self._ahead_base = kf.counter.value
 
+    @torch.no_grad()
+    def prefetch_launch(self, images_u8, tstamps, forced=None, feat_last=None, stream=None):
+        """`prefetch` in two halves, the first one asynchronous: encode the tested frames and run the decision chain on `stream` (a side stream:
+        the pass then runs BESIDE whatever the caller issues next on the current stream -- the previous chunk's tracking windows), with the
+        decisions copied to pinned host memory behind an event.  `feat_last`: the features the chain starts from when they are not the
+        store's last keyframe (the caller knows the last keyframe of the chunk still being consumed).  Returns the handle for
+        `prefetch_collect`; nothing of the filter's state changes until then."""
+        if self.kf_every > 0 or len(tstamps) == 0:
+            return None
+        kf = self.keyframes
+        B = len(tstamps)
+        cur = torch.cuda.current_stream()
+        st = stream if stream is not None else cur
+        if st is not cur:
+            st.wait_stream(cur)                      # frames, keyframe store: everything issued so far
+        with torch.cuda.stream(st):
+            imgs = images_u8.to(self.device, non_blocking=True)
+            feats = self.model.encode_batch(imgs)                                         # [B,N,C] fp32, a fresh tensor
+            N, C = feats.shape[1:]
+            P = self.model.cfg.patch_size
+            nh, nw = imgs.shape[2] // P, imgs.shape[3] // P
+            if self._pos_grid is None or self._pos_grid.shape[1] != nh * nw:
+                y, x = torch.meshgrid(torch.arange(nh, device=self.device), torch.arange(nw, device=self.device), indexing="ij")
+                self._pos_grid = torch.stack([y.reshape(-1), x.reshape(-1)], -1)[None]
+            forced = [bool(f) for f in forced] if forced is not None else [False] * B
+            if feat_last is None:
+                if kf.counter.value == 0:
+                    forced[0] = True
+                    feat_last = feats[0]
+                else:
+                    feat_last = kf.feat_slice(kf.counter.value - 1, kf.counter.value)[0]
+            need = (B + 1) * (N - 1) * C + N
+            if self._chain_ws is None or self._chain_ws[0].numel() < need or self._chain_ws[1].numel() < 2 * B + 1:
+                self._chain_ws = (torch.empty(need, device=self.device), torch.zeros(2 * B + 1, dtype=torch.int32, device=self.device))
+            ws, ints = self._chain_ws
+            ops.patch_overlap_chain(feat_last.contiguous(), feats, 0.7, float(self.thresh), forced, ws, ints[2 * B:2 * B + 1], ints[:B], ints[B:2 * B])
+            host = torch.empty(2 * B, dtype=torch.int32).pin_memory()
+            host.copy_(ints[:2 * B], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self.stats["prefetched"] += B
+        return {"feats": feats, "host": host, "event": ev, "tstamps": [int(t) for t in tstamps], "forced": forced}
+
+    def prefetch_collect(self, handle, base=None):
+        """second half of `prefetch_launch`: wait for the decisions (THE device round trip of the batch) and install them.  `base`: the keyframe
+        counter the decisions are valid against (default: now).  Returns (number of frames the scan keeps, features of the last kept one | None)."""
+        if handle is None:
+            return 0, None
+        handle["event"].synchronize()
+        host = handle["host"].numpy()
+        feats, ts, forced = handle["feats"], handle["tstamps"], handle["forced"]
+        B = len(ts)
+        self._ahead = {t: (feats[i], bool(host[B + i]), int(host[i]), forced[i]) for i, t in enumerate(ts)}
+        self._ahead_base = self.keyframes.counter.value if base is None else int(base)
+        kept = [i for i in range(B) if bool(host[B + i]) or forced[i]]
+        return len(kept), (feats[kept[-1]] if kept else None)
+
     def _cached(self, tstamp):
         """cached (features, decision, count) of a tested frame, if the scan that produced them still holds"""
         ent = self._ahead.get(int(tstamp))

@@ -45,6 +45,7 @@ class Cut3rSlam:
         # hi2.py:103 keeps EVERY full-resolution frame (`self.images[tstamp] = image`) for terminate(); here that is opt-in
         # (frames stay on the device, 0.6 MB each at 384x512): demo.py switches it on when --add_kf semantics are wanted
         self.keep_images = False
+        self._ahead_stream = None              # run_buffered(pipeline=True): the look-ahead encoder pass of the next chunk
         self.images = {}
         # dist.ShardedTracker registers keyframes ahead of the tracker (encoder look-ahead): it sets this, and the trajectory writers
         # then stop at tracker.t1 instead of the reference's counter - 1 (demo_s.py:97-100)
@@ -111,29 +112,58 @@ class Cut3rSlam:
         return viz_idx, submap_idx, lc_did
 
     @torch.no_grad()
-    def run_buffered(self, frames_u8, intrinsics, t_start=0, lookahead=16, mark_tail=True, on_frame=None):
+    def run_buffered(self, frames_u8, intrinsics, t_start=0, lookahead=16, mark_tail=True, on_frame=None, pipeline=False):
         """Buffered-stream driver: the same per-frame `run()` sequence as demo_s.py:151-160 over frames_u8 [n,3,H,W] (time
         stamps t_start..), but in overlap mode the next `lookahead` tested frames (every `skip`-th, plus the always-kept
         second-last / last frame when mark_tail) go through the encoder as ONE batch and their keyframe decisions are taken
-        on the device (MotionFilter.prefetch) -- identical keyframes and features, latency lookahead*skip frames."""
+        on the device (MotionFilter.prefetch) -- identical keyframes and features, latency lookahead*skip frames.
+        pipeline=True: the encoder pass + decision chain of chunk c+1 run on a side stream BESIDE the per-frame loop (tracking windows) of
+        chunk c -- the chain of c+1 starts from the last keyframe chunk c is known to yield -- and only their read-back waits."""
         n = frames_u8.shape[0]
         f = self.filterx
         overlap_mode = not (f.kf_every > 0)
         chunk = max(1, int(lookahead)) * max(1, int(f.skip))
+
+        def tested(c0, c1, first_ever):
+            idx, forced = [], []
+            for i in range(c0, c1):
+                t = t_start + i
+                tail = mark_tail and i >= n - 2
+                if t % f.skip == 0 or tail or (first_ever and i == c0):
+                    idx.append(i)
+                    forced.append(tail)
+            return idx, forced
+
+        def select(idx, forced):
+            return frames_u8[idx[0]:idx[-1] + 1:f.skip] if (not any(forced) and len(idx) > 1 and idx[-1] - idx[0] == f.skip * (len(idx) - 1)) \
+                else frames_u8[torch.as_tensor(idx, device=frames_u8.device)]
+
+        pipe = bool(pipeline) and overlap_mode
+        if pipe and self._ahead_stream is None:
+            self._ahead_stream = torch.cuda.Stream()
+        pending = None                         # (handle, base) of a chunk whose look-ahead pass is already running
         for c0 in range(0, n, chunk):
             c1 = min(n, c0 + chunk)
             if overlap_mode:
-                idx, forced = [], []
-                for i in range(c0, c1):
-                    t = t_start + i
-                    tail = mark_tail and i >= n - 2
-                    if t % f.skip == 0 or tail or (self.keyframes.counter.value == 0 and i == c0):
-                        idx.append(i)
-                        forced.append(tail)
-                if idx:
-                    sel = frames_u8[idx[0]:idx[-1] + 1:f.skip] if (not any(forced) and len(idx) > 1 and idx[-1] - idx[0] == f.skip * (len(idx) - 1)) \
-                        else frames_u8[torch.as_tensor(idx, device=frames_u8.device)]
-                    f.prefetch(sel, [t_start + i for i in idx], forced)
+                if pending is not None:
+                    kept, last_feat = f.prefetch_collect(pending[0], base=pending[1])
+                    pending = None
+                else:
+                    idx, forced = tested(c0, c1, self.keyframes.counter.value == 0)
+                    kept, last_feat = 0, None
+                    if idx and pipe:
+                        kept, last_feat = f.prefetch_collect(f.prefetch_launch(select(idx, forced), [t_start + i for i in idx], forced))
+                    elif idx:
+                        f.prefetch(select(idx, forced), [t_start + i for i in idx], forced)
+                if pipe and c1 < n:
+                    idx2, forced2 = tested(c1, min(n, c1 + chunk), False)
+                    if idx2:
+                        base2 = self.keyframes.counter.value + kept
+                        if last_feat is None and self.keyframes.counter.value > 0:
+                            last_feat = self.keyframes.feat_slice(self.keyframes.counter.value - 1, self.keyframes.counter.value)[0]
+                        if last_feat is not None:
+                            pending = (f.prefetch_launch(select(idx2, forced2), [t_start + i for i in idx2], forced2, feat_last=last_feat,
+                                                         stream=self._ahead_stream), base2)
             for i in range(c0, c1):
                 out = self.run(t_start + i, frames_u8[i:i + 1], intrinsics, frames_u8[i:i + 1], intrinsics,
                                second_last_frame=mark_tail and i == n - 2, last_frame=mark_tail and i == n - 1)

@@ -41,7 +41,7 @@ def _gpu_run(cfg, sd, frames, mf, buffered=False, window_batch=1, streamed=0):
     if streamed:                               # demo.py --lookahead: an iterator of per-frame items, `streamed` tested frames held back
         slam.run_stream(((t, fr[t:t + 1], intr, fr[t:t + 1], intr, t == n - 2, t == n - 1) for t in range(n)), lookahead=streamed)
     elif buffered:
-        slam.run_buffered(fr, intr, lookahead=6)
+        slam.run_buffered(fr, intr, lookahead=6, pipeline=(buffered == "pipeline"))
     else:
         for t in range(n):
             slam.run(t, fr[t:t + 1], intr, fr[t:t + 1], intr, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
@@ -125,6 +125,14 @@ def test_overlap_mode_stream_trajectory_matches_cpu_path_and_buffered_driver_is_
     k = slam.tracker.t1
     assert torch.equal(slam.keyframes.featI[:k], slam_b.keyframes.featI[:k])
     assert torch.equal(slam.keyframes.depth[:k], slam_b.keyframes.depth[:k])
+    # ... and with the next chunk's encoder pass + decision chain running on a side stream beside the current chunk's windows
+    slam_p, traj_p = _gpu_run(cfg, sd, frames, mf, buffered="pipeline", window_batch=2)
+    assert np.array_equal(traj, traj_p) and slam_p.tracker.t1 == k
+    assert slam_p.filterx.stats["encoded"] <= 2 and slam_p.filterx.stats["cache_hits"] >= len(tested) - 2
+    for a, b in zip(slam.graph.edges_numpy(), slam_p.graph.edges_numpy()):
+        assert np.array_equal(a, b)
+    assert torch.equal(slam.keyframes.featI[:k], slam_p.keyframes.featI[:k])
+    assert torch.equal(slam.keyframes.depth[:k], slam_p.keyframes.depth[:k])
     # the reference's own mode at buffered throughput (demo.py --lookahead N --window-batch W): an item iterator with 12 tested frames held
     # back, the keyframes they yield tracked two windows at a time -- the same keyframes, poses, depths and ordered edges, bit for bit
     slam_s, traj_s = _gpu_run(cfg, sd, frames, mf, streamed=12, window_batch=2)

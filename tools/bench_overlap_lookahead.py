@@ -18,15 +18,15 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 2800
 warm = 1600
 frames = synth.slideshow_stream(warm + N, H, W, hold=10, seed=0, device=dev)
 ref = None
-for la, wb in [(16, 1), (56, 4), (140, 14), (280, 28), (280, 14)]:
+for la, wb, pipe in [(16, 1, False), (56, 4, False), (140, 14, False), (280, 28, False), (280, 28, True), (140, 28, True), (560, 28, True)]:
     config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": -1},
                            "frontend": {"iteration": 0, "window_batch": wb}}}
     slam = Cut3rSlam(model, config, (H, W), buffer=(warm + N) // 10 + 16, device=dev)
-    slam.run_buffered(frames[:warm], intr, mark_tail=False, lookahead=la)
+    slam.run_buffered(frames[:warm], intr, mark_tail=False, lookahead=la, pipeline=pipe)
     torch.cuda.synchronize()
     k0, w0 = slam.keyframes.counter.value, slam.tracker.t1
     tic = time.perf_counter()
-    slam.run_buffered(frames[warm:warm + N], intr, t_start=warm, mark_tail=False, lookahead=la)
+    slam.run_buffered(frames[warm:warm + N], intr, t_start=warm, mark_tail=False, lookahead=la, pipeline=pipe)
     torch.cuda.synchronize()
     el = time.perf_counter() - tic
     k = slam.tracker.t1
@@ -37,5 +37,5 @@ for la, wb in [(16, 1), (56, 4), (140, 14), (280, 28), (280, 14)]:
     kk = min(k, ref[0].shape[0])
     same_kf = bool((ts[:min(len(ts), len(ref[1]))] == ref[1][:min(len(ts), len(ref[1]))]).all())
     dpose = float((pose[:kk] - ref[0][:kk]).abs().max())
-    print(f"lookahead {la:4d} tested frames, window_batch {wb:3d}: {N / el:8.1f} frames/s ({1e3 * el / N:.3f} ms/frame), keyframes {slam.keyframes.counter.value - k0}, "
+    print(f"lookahead {la:4d} tested frames, window_batch {wb:3d}, pipeline {int(pipe)}: {N / el:8.1f} frames/s ({1e3 * el / N:.3f} ms/frame), keyframes {slam.keyframes.counter.value - k0}, "
           f"tracked to {k}, same keyframes as the first run: {same_kf}, max |pose diff| over the common prefix {dpose:.2e}", flush=True)
