@@ -303,6 +303,65 @@ def traffic_from_profile(tile, launches_in_run):
     return None
 
 
+class PowerSampler:
+    """Package power and shader clock of the GPU this process runs on, read from the amdgpu hwmon files (power1_input in uW, freq1_input
+    in Hz, power1_cap) by a thread every 20 ms while a leg runs.  A measurement aid: if the files are not there (or the card cannot be
+    matched by PCI address) the sampler reports nothing and the bench line is unaffected.  No subprocess, no GPU call."""
+
+    def __init__(self, device_index=0):
+        self.dir, self.samples, self._stop, self._thr = None, [], False, None
+        try:
+            import glob
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+                pci = os.path.basename(os.path.realpath(os.path.join(hw, "..", "..")))
+                if pci.lower().startswith(want) and os.path.isfile(os.path.join(hw, "power1_input")):
+                    self.dir = hw
+                    break
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as f:
+            return float(f.read().strip())
+
+    def start(self):
+        if self.dir is None:
+            return self
+        import threading
+        self.samples, self._stop = [], False
+
+        def loop():
+            while not self._stop:
+                try:
+                    self.samples.append((self._read("power1_input") * 1e-6, self._read("freq1_input") * 1e-6))
+                except Exception:
+                    break
+                time.sleep(0.02)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        if self._thr is None:
+            return None
+        self._stop = True
+        self._thr.join(timeout=1.0)
+        self._thr = None
+        if len(self.samples) < 3:
+            return None
+        pw, ck = [a for a, _ in self.samples], [b for _, b in self.samples]
+        try:
+            cap = self._read("power1_cap") * 1e-6
+        except Exception:
+            cap = None
+        return {"package_w_mean": round(sum(pw) / len(pw), 1), "package_w_max": round(max(pw), 1), "power_cap_w": cap,
+                "frac_of_cap": round(sum(pw) / len(pw) / cap, 3) if cap else None,
+                "sclk_mhz_mean": round(sum(ck) / len(ck), 0), "sclk_mhz_min": round(min(ck), 0), "sclk_mhz_max": round(max(ck), 0), "samples": len(pw),
+                "source": "amdgpu hwmon (power1_input, freq1_input, power1_cap), sampled every 20 ms over the timed region"}
+
+
 # ------------------------------------------------------------------------------------------------------------------ legs
 def fixed_cadence_leg(model, slam_cls, cdist, dev, wb, steps, warmup, world=1, rank=0, dist_on=False, emu=0, probe_steps=0, barrier=None,
                       seq_windows=0, frame_source="host"):
@@ -345,13 +404,15 @@ def fixed_cadence_leg(model, slam_cls, cdist, dev, wb, steps, warmup, world=1, r
     for k in runner.stats:
         runner.stats[k] = 0
     up0 = getattr(frames, "bytes_uploaded", 0)
+    sampler = PowerSampler(torch.device(dev).index or 0).start() if (world == 1 and emu <= 1) else None
     tic = time.perf_counter()
     for _ in range(steps):
         t = runner.step(frames, t, KF_EVERY, WIN, intr)
     runner.flush()                       # the timed region holds exactly K network passes and K replays
     barrier()
     elapsed = time.perf_counter() - tic
-    return {"elapsed": elapsed, "slam": slam, "runner": runner, "frames": frames, "t": t, "intr": intr,
+    power = sampler.stop() if sampler is not None else None
+    return {"elapsed": elapsed, "slam": slam, "runner": runner, "frames": frames, "t": t, "intr": intr, "power": power,
             "frames_per_step": KF_EVERY * WIN * wb, "health": tracking_health(slam),
             "h2d_bytes_per_step": (getattr(frames, "bytes_uploaded", 0) - up0) / max(1, steps)}
 
@@ -736,6 +797,7 @@ def main():
     elapsed, slam, runner, frames, t, intr = (leg[k] for k in ("elapsed", "slam", "runner", "frames", "t", "intr"))
     frames_per_step = leg["frames_per_step"]
     leg_h2d = leg["h2d_bytes_per_step"]
+    leg_power = leg.get("power")
     health = leg["health"]
     if not health["poses_finite"] or health["nonfinite_windows"]:
         raise SystemExit(f"bench: the headline leg produced non-finite poses: {health}")      # never report a throughput for it
@@ -827,7 +889,7 @@ def main():
         op_points["fixed_cadence_window_batch_1"] = {
             "config": "kf_every=10, window_batch=1: the reference's one-window-at-a-time schedule (50 frames of buffering)",
             "frames_per_s": round(16 * l1["frames_per_step"] / l1["elapsed"], 1), "ms_per_window": round(1e3 * l1["elapsed"] / 16, 3), "windows": 16,
-            "health": l1["health"]}
+            "health": l1["health"], "power": l1.get("power")}
         if not args.no_roofline:
             # the M = 769 / 768 shapes of ONE window (decoder GEMMs of 4 x 7 row tiles of 128^2, encoder batch 5): HIP events around
             # every GEMM / attention launch of four eager windows
@@ -907,7 +969,7 @@ def main():
                                    + (" [DEBUG --small]" if args.small else ""),
                        "frames_per_step": frames_per_step, "window_views": 6, "window_batch": WB, "sequence_windows": SEQ, "parallelism": f"window-sharded x{world}",
                        "frame_source": args.frames, "h2d_mb_per_step": round(leg_h2d / 1e6, 2)},
-            "roofline": roofline, "cpu_baseline": cpu_base, "operating_points": op_points, "trajectory_parity": traj,
+            "power": leg_power, "roofline": roofline, "cpu_baseline": cpu_base, "operating_points": op_points, "trajectory_parity": traj,
             "ate_rmse_m": (traj or {}).get("fixed_cadence_kf_every_2", {}).get("ate_rmse_m"),
             "ate_rmse_m_production_384x512": (traj or {}).get("production_384x512_kf_every_2", {}).get("ate_rmse_m"),
             "ate_rmse_m_production_384x512_vs_reference_loop": (traj or {}).get("production_384x512_vs_reference_loop", {}).get("ate_rmse_m"),
