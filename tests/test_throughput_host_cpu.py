@@ -192,3 +192,22 @@ def test_bench_launcher_relays_rank0_line_and_exit_code(tmp_path, monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     seen["rc"] = 7
     assert bench.launch_ranks(2) == 7
+
+
+def test_power_sampler_is_silent_without_the_hwmon_files(tmp_path):
+    """bench.PowerSampler is a measurement aid: with no GPU / no matching hwmon directory it reports nothing and never raises; pointed at a
+    directory with the three files it averages what it reads."""
+    import time
+    import bench
+    s = bench.PowerSampler(0)
+    if s.dir is None:                          # (this container: no GPU)
+        assert s.start() is s and s.stop() is None
+    (tmp_path / "power1_input").write_text("1300000000\n")
+    (tmp_path / "freq1_input").write_text("2000000000\n")
+    (tmp_path / "power1_cap").write_text("1400000000\n")
+    s.dir = str(tmp_path)
+    s.start()
+    time.sleep(0.15)
+    out = s.stop()
+    assert out is not None and out["package_w_mean"] == 1300.0 and out["sclk_mhz_mean"] == 2000.0 and out["power_cap_w"] == 1400.0
+    assert abs(out["frac_of_cap"] - 0.929) < 1e-3 and out["samples"] >= 3
