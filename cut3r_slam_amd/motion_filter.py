@@ -37,10 +37,14 @@ class MotionFilter:
         self._pos_grid = None
         self._ahead_base = None          # keyframe counter the cached decisions were taken against
         self.last_ratio = None
+        self._inflight = None            # event of a prefetch_launch whose result has not been collected
         self.stats = {"encoded": 0, "prefetched": 0, "cache_hits": 0}
 
     def encode(self, image_u8):
         """image_u8 [1,3,H,W] uint8 (host or device) -> (feat [N,C] fp32, pos [1,N,2])"""
+        if self._inflight is not None:       # a look-ahead pass on its side stream uses the encoder's static buffers: never beside it
+            self._inflight.synchronize()
+            self._inflight = None
         img = image_u8.to(self.device, non_blocking=True)
         feat, pos, _ = self.model.encode_image({"img": img})       # uint8: normalisation fused into the patch loader
         self.stats["encoded"] += 1
@@ -134,6 +138,7 @@ class MotionFilter:
             ev = torch.cuda.Event()
             ev.record(st)
         self.stats["prefetched"] += B
+        self._inflight = ev
         return {"feats": feats, "host": host, "event": ev, "tstamps": [int(t) for t in tstamps], "forced": forced}
 
     def prefetch_collect(self, handle, base=None):
@@ -142,6 +147,8 @@ class MotionFilter:
         if handle is None:
             return 0, None
         handle["event"].synchronize()
+        if self._inflight is handle["event"]:
+            self._inflight = None
         host = handle["host"].numpy()
         feats, ts, forced = handle["feats"], handle["tstamps"], handle["forced"]
         B = len(ts)
