@@ -73,6 +73,9 @@ class MotionFilter:
             return
         kf = self.keyframes
         B = len(tstamps)
+        if self._inflight is not None:
+            self._inflight.synchronize()
+            self._inflight = None
         imgs = images_u8.to(self.device, non_blocking=True)
         feats = self.model.encode_batch(imgs)                                             # [B,N,C] fp32, one batched pass
         self.stats["prefetched"] += B
