@@ -136,3 +136,27 @@ opt_params: {pose_lr: 0.0001, position_lr_init: 0.0005, feature_lr: 0.005, opaci
     from safetensors.torch import load_file
     m = load_file(str(out / "gaussians.safetensors"))
     assert m["theta"].shape[1] == 14 and m["theta"].shape[0] > 1000 and torch.isfinite(m["theta"]).all()
+
+
+def test_demo_lookahead_gives_the_frame_by_frame_trajectory(tmp_path):
+    """demo.py --lookahead L --window-batch W in the reference's overlap mode (kf_every = -1): the keyframe test runs L tested frames ahead
+    (one batched encoder pass + on-device decision chain per chunk), the keyframes are tracked W windows at a time -- and traj_kf.txt is the
+    file of the frame-by-frame run, byte for byte."""
+    import demo
+    d = tmp_path / "colors"
+    d.mkdir()
+    _write_sequence(str(d), 48)
+    calib = tmp_path / "calib.txt"
+    calib.write_text("600.0 600.0 320.0 240.0")
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text("Tracking:\n  motion_filter:\n    thresh: 0.9999\n    skip: 2\n    kf_every: -1\n")      # (a random tiny network: nearly every tested frame is a keyframe)
+    outs = []
+    for tag, extra in (("plain", []), ("ahead", ["--lookahead", "5", "--window-batch", "2"])):
+        out = tmp_path / tag
+        rc = demo.main(["--imagedir", str(d), "--calib", str(calib), "--config", str(cfg), "--output", str(out), "--synthetic-weights", "--small",
+                        "--seed", "1"] + extra)
+        assert rc == 0
+        outs.append((out / "traj_kf.txt").read_bytes())
+    rows = np.loadtxt(tmp_path / "plain" / "traj_kf.txt")
+    assert rows.ndim == 2 and rows.shape[0] >= 12, "the sequence must yield enough keyframes for two batched windows"
+    assert outs[0] == outs[1]
