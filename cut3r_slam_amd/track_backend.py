@@ -28,6 +28,7 @@ class TrackBackend:
         self.model = slam.model
         self.graph = slam.graph
         self.loop_iters = int(config.get("iteration", 0))
+        self._chain_ws = None
         self.downsample_ratio = slam.downsample_ratio
         self.conf_th = 0.05
         self.lc_initialized = False
@@ -42,10 +43,21 @@ class TrackBackend:
         need = 2 * (N - 1) * C + N
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, device=self.device)
-        counts = torch.zeros(len(f1s), dtype=torch.int32, device=self.device)
-        for i, f1 in enumerate(f1s):
-            ops.patch_overlap_count(f0.contiguous(), f1.contiguous(), thr, self._ws, counts[i:i + 1])
-        return counts.float() / float(N - 1)
+        B = len(f1s)
+        if B == 1:
+            counts = torch.zeros(1, dtype=torch.int32, device=self.device)
+            ops.patch_overlap_count(f0.contiguous(), f1s[0].contiguous(), thr, self._ws, counts)
+            return counts.float() / float(N - 1)
+        # every candidate against the SAME current keyframe in one call: the look-ahead chain of the motion filter with a ratio threshold
+        # nobody passes (no candidate ever becomes the "last keyframe"): rows normalised once, two launches per candidate issued from C,
+        # bit-identical counts (tests/test_backend_golden_gpu.py: the reference's values and the per-pair launches)
+        feats = torch.stack([f.contiguous() for f in f1s], 0)
+        need = (B + 1) * (N - 1) * C + N
+        if self._chain_ws is None or self._chain_ws[0].numel() < need or self._chain_ws[1].numel() < 2 * B + 1:
+            self._chain_ws = (torch.empty(need, device=self.device), torch.zeros(2 * B + 1, dtype=torch.int32, device=self.device))
+        ws, ints = self._chain_ws
+        ops.patch_overlap_chain(f0.contiguous(), feats, thr, -1.0, None, ws, ints[2 * B:2 * B + 1], ints[:B], ints[B:2 * B])
+        return ints[:B].float() / float(N - 1)
 
     def nms_scores(self, ids_matched, idx_current, K4):
         """scores [B] of the loop candidates `ids_matched` for keyframe idx_current (factor_graph.py:561-577):

@@ -44,6 +44,10 @@ def test_nms_scores_and_choice_equal_the_reference():
             assert (-1 if k is None else k) == int(f[f"{name}_k_th{int(th * 100)}"]), (name, th)
         feat = be._feat_overlap(kf.featI[cur], [kf.featI[int(i)] for i in ids]).cpu().numpy()
         np.testing.assert_allclose(feat, f[f"{name}_feat_sim"], rtol=0, atol=1e-6)
+        # the batched form (round 4: all candidates through the motion filter's look-ahead chain, nobody taken) counts what the per-pair
+        # launches count
+        pair = torch.cat([be._feat_overlap(kf.featI[cur], [kf.featI[int(i)]]) for i in ids]).cpu().numpy()
+        assert np.array_equal(feat, pair), name
 
 
 def test_pose_helpers_and_aligned_pointmap_equal_the_reference():
