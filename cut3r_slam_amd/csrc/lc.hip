@@ -128,7 +128,18 @@ __global__ __launch_bounds__(64) void lc_adam_kernel(const float* __restrict__ p
         const float* ra = partial + (size_t)b * nblk * LC_ROW + e;
         const float* rc = partial + (size_t)(b - 1) * nblk * LC_ROW + 12 + e;
         float g = 0.f;
-        for (int k = 0; k < nblk; k++) g += ra[(size_t)k * LC_ROW] + rc[(size_t)k * LC_ROW];
+        for (int k0 = 0; k0 < nblk; k0 += 8) {       // (same sums, eight rows' loads in flight: see lc_terms_adam_kernel)
+            float va[8], vc[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = k0 + j < nblk ? k0 + j : nblk - 1;
+                va[j] = ra[(size_t)k * LC_ROW];
+                vc[j] = rc[(size_t)k * LC_ROW];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (k0 + j < nblk) g += va[j] + vc[j];
+        }
 #pragma unroll
         for (int k = 0; k < 12; k++) G[k] = __shfl(g, k);
     }
@@ -235,9 +246,24 @@ __global__ __launch_bounds__(64) void lc_terms_adam_kernel(const LcTerm* __restr
             const int ia = terms[t].ia, ic = terms[t].ic;
             if (ia != b && ic != b) continue;
             const float* row = partial + (size_t)t * nblk * LC_ROW + e;
-            for (int k = 0; k < nblk; k++) {
-                if (ia == b) g += row[(size_t)k * LC_ROW];
-                if (ic == b) g += row[(size_t)k * LC_ROW + 12];
+            // the same additions in the same order (row k: the 'a' entry, then the 'c' entry), with the loads of eight rows requested
+            // before the first of them is added: the gather was a chain of ~3 x nblk dependent L2 round trips per iteration
+            const bool ua = ia == b, uc = ic == b;
+            for (int k0 = 0; k0 < nblk; k0 += 8) {
+                float va[8], vc[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = k0 + j < nblk ? k0 + j : nblk - 1;
+                    va[j] = ua ? row[(size_t)k * LC_ROW] : 0.f;
+                    vc[j] = uc ? row[(size_t)k * LC_ROW + 12] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (k0 + j < nblk) {
+                        if (ua) g += va[j];
+                        if (uc) g += vc[j];
+                    }
+                }
             }
         }
 #pragma unroll
