@@ -126,24 +126,19 @@ class TrackBackend:
         block = kf.submap_ds[sub0:sub1 + 1]
         ops.transform_submaps(block, T34.reshape(B, 12).contiguous())
         Th = T34.detach().cpu().numpy()
-        new = []
-        for b in range(B):
+        # the keyframes of submaps sub0..sub1 are the contiguous range [5 sub0, 5 (sub1 + 1)) (+ the first keyframe of the next submap, moved
+        # by the last transform): one batched host pass -- per keyframe the same arithmetic as the former loop (4x4 product per keyframe,
+        # scipy's Rotation on the stack) -- and ONE upload of the world->camera rows
+        i0, n = sub0 * 5, B * 5 + (1 if include_last else 0)
+        c2w = gh.pose_vec_to_matrix(kf.pose[i0:i0 + n].numpy())
+        out = np.empty_like(c2w)
+        for j in range(n):
             Ts = np.eye(4, dtype=np.float32)
-            Ts[:3, :4] = Th[b]
-            for n in range(5):
-                i = (sub0 + b) * 5 + n
-                c2w = gh.pose_vec_to_matrix(kf.pose[i].numpy()[None])[0]
-                p7 = gh.matrix_to_pose_vec(Ts @ c2w)
-                kf.set_pose(i, p7)
-                new.append(p7)
-        if include_last:
-            i = (sub1 + 1) * 5
-            Ts = np.eye(4, dtype=np.float32)
-            Ts[:3, :4] = Th[-1]
-            p7 = gh.matrix_to_pose_vec(Ts @ gh.pose_vec_to_matrix(kf.pose[i].numpy()[None])[0])
-            kf.set_pose(i, p7)
-            new.append(p7)
-        return np.stack(new)
+            Ts[:3, :4] = Th[min(j // 5, B - 1)]
+            out[j] = Ts @ c2w[j]
+        new = gh.matrices_to_pose_vecs(out)
+        kf.set_poses(i0, new)
+        return new
 
     def loop_closure_init(self, pointmap_current_lc, idx_matched, idx_current, return_loss=False):
         kf = self.keyframes
