@@ -798,6 +798,9 @@ def main():
     frames_per_step = leg["frames_per_step"]
     leg_h2d = leg["h2d_bytes_per_step"]
     leg_power = leg.get("power")
+    if leg_power:                              # energy of the timed region: mean package power x time
+        leg_power["joules_per_step"] = round(leg_power["package_w_mean"] * elapsed / max(1, args.steps), 1)
+        leg_power["joules_per_frame"] = round(leg_power["package_w_mean"] * elapsed / max(1, args.steps * frames_per_step), 4)
     health = leg["health"]
     if not health["poses_finite"] or health["nonfinite_windows"]:
         raise SystemExit(f"bench: the headline leg produced non-finite poses: {health}")      # never report a throughput for it
