@@ -471,7 +471,7 @@ def overlap_mode_leg(model, slam_cls, dev, n_frames=800, lookahead=16, plain_fra
     return out
 
 
-def loop_closure_leg(cfg, slam_cls, dev, iters=2000, n_frames=1000, warm=160):
+def loop_closure_leg(cfg, slam_cls, dev, iters=2000, n_frames=1000, warm=160, wb=1):
     """BASELINE configs[2]: the tracking loop WITH the loop-closure backend (hislam2/hi2.py:112-121, track_backend.py:527-586), one window
     at a time, Tracking.frontend.iteration = 2000 (config/scannet_config.yaml:33).  A random-weight network recognises no place, so the
     weights are synth.loop_state_dict (pose head damped: every keyframe stays covisible with the early ones) -- the backend then fires by
@@ -481,17 +481,18 @@ def loop_closure_leg(cfg, slam_cls, dev, iters=2000, n_frames=1000, warm=160):
     sd = synth.loop_state_dict(cfg, seed=0, enc_residual_gain=0.1, depth_relief=0.02)
     model = Cut3rModel(cfg, sd, dev, minimal=True)
     config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": KF_EVERY},
-                           "frontend": {"iteration": int(iters), "window_batch": 1}}}
+                           "frontend": {"iteration": int(iters), "window_batch": int(wb)}}}
     intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])
+    warm = max(warm, (2 * 5 * int(wb) + 8) * KF_EVERY)      # two whole decoder batches before the clock starts (graph captures, workspaces)
     frames = synth_frames(warm + n_frames, H, W, dev, seed=0)
     slam = slam_cls(model, config, (H, W), buffer=(warm + n_frames) // KF_EVERY + 16, device=dev)
     closures = []
     real_run = slam.backend.run
 
-    def timed_run():
+    def timed_run(*a, **k):
         torch.cuda.synchronize()
         tic = time.perf_counter()
-        out = real_run()
+        out = real_run(*a, **k)
         torch.cuda.synchronize()
         if out[0]:
             closures.append(time.perf_counter() - tic)
@@ -509,7 +510,7 @@ def loop_closure_leg(cfg, slam_cls, dev, iters=2000, n_frames=1000, warm=160):
     el = time.perf_counter() - tic
     timed = closures[n_warm:]
     be = slam.backend
-    out = {"config": f"kf_every={KF_EVERY}, window_batch=1, Tracking.frontend.iteration={iters} (config/scannet_config.yaml:33), {n_frames} frames; weights = "
+    out = {"config": f"kf_every={KF_EVERY}, window_batch={wb}, Tracking.frontend.iteration={iters} (config/scannet_config.yaml:33), {n_frames} frames; weights = "
                      "synth.loop_state_dict (every keyframe covisible with the early ones: the backend fires by itself every other eligible window)",
            "frames_per_s": round(n_frames / el, 1), "ms_per_frame": round(1e3 * el / n_frames, 3), "windows": (slam.tracker.t1 - w0) // 5,
            "closures": len(timed), "ms_per_closure": round(1e3 * sum(timed) / max(1, len(timed)), 2),
@@ -939,6 +940,9 @@ def main():
         op_points["overlap_mode"] = guarded("overlap mode leg", overlap_mode_leg, model, Cut3rSlam, dev)
         log("operating points: loop closure on (BASELINE configs[2])")
         op_points["loop_closure_on"] = guarded("loop closure leg", loop_closure_leg, cfg, Cut3rSlam, dev)
+        # the same loop with the windows decoded four at a time: the backend takes its turn after every window of a batch (identical
+        # closures and stores, tests/test_e2e_gpu.py), latency 200 frames
+        op_points["loop_closure_on_window_batch_4"] = guarded("loop closure leg, window batch 4", loop_closure_leg, cfg, Cut3rSlam, dev, wb=4)
         log("operating points: GS mapper on a synthetic window (rasteriser forward + backward, pose refinement, mapping)")
         op_points["gs_mapper_synthetic_window"] = guarded("GS mapper leg", synth.gs_mapper_window_leg, H, W, dev)
     if single and not args.no_trajectory_parity:

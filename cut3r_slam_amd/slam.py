@@ -89,8 +89,23 @@ class Cut3rSlam:
             self.images[int(tstamp)] = image
         self.filterx.kfFilter(tstamp, image_ds, intrinsics=intrinsics_ds, second_last_frame=second_last_frame,
                               last_frame=last_frame)
-        run_backend, viz_idx, submap_idx = self.tracker.run(tstamp, last_frame=last_frame)
         lc_did = False
+        hook, done = None, []
+        if self.tracker.window_batch > 1 and self.do_lc and self.backend is not None and self.mapper is None:
+            # windows decoded several at a time WITH the loop-closure backend: its turn comes after every window of the batch, exactly
+            # where the one-window loop gives it (the backend then looks at the keyframes tracked so far, not at the ones still waiting)
+            def hook(t0, t1):
+                if t1 > 10:
+                    if self.freeze_counter > 0:
+                        did, _ = self.backend.run(t1=t1)
+                        if did:
+                            self.freeze_counter = 0
+                            done.append(t1)
+                    else:
+                        self.freeze_counter += 1
+        run_backend, viz_idx, submap_idx = self.tracker.run(tstamp, last_frame=last_frame, after_window=hook)
+        if hook is not None and done:
+            lc_did = True
         if run_backend and not last_frame and self.do_lc and self.backend is not None:
             if self.freeze_counter > 0:
                 lc_did, updates = self.backend.run()

@@ -199,11 +199,11 @@ class TrackBackend:
         return lc_all[-1], updates
 
     # ------------------------------------------------------------------ entry point (track_backend.py:527-586)
-    def run(self):
+    def run(self, t1=None):
         kf = self.keyframes
         intr = kf.intrinsic[0].numpy() / self.downsample_ratio
         K4 = [float(intr[0]), float(intr[1]), float(intr[2]), float(intr[3])]
-        t1 = kf.counter.value - 1
+        t1 = kf.counter.value - 1 if t1 is None else int(t1)
         t0 = t1 - 6
         ids_matched, idx_current = None, None
         for idx_current in range(t0, t1 - 1):

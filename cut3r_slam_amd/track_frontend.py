@@ -480,9 +480,13 @@ class TrackFrontend:
         finish()
         return None
 
-    def track_batch(self, ranges):
+    def track_batch(self, ranges, after_window=None):
         """several consecutive 6-keyframe windows: ONE batched decoder/head inference, then the reference's sequential
-        chaining + graph update window by window (identical results to calling track() per window)."""
+        chaining + graph update window by window (identical results to calling track() per window).
+        after_window(t0, t1): called after EACH window's sequential part with the tracker at that window (`self.t1 = t1`) -- the place the
+        per-frame loop runs the loop-closure backend (hi2.py:112-121).  A closure rewrites stored pointmaps and poses; the network
+        outputs of the later windows of the batch do not depend on them (every window re-initialises state and memory), their
+        chaining does and runs afterwards: the results are those of one window at a time."""
         kf = self.keyframes
         self.window_features(ranges[0][0], ranges[-1][1])                                 # ONE batched encode of every new keyframe
         feats = torch.stack([self.window_features(a, b) for a, b in ranges], 0)          # [Wb,6,N,E] (all cached now)
@@ -490,11 +494,17 @@ class TrackFrontend:
         V = ranges[0][1] - ranges[0][0]
         outs = [(res["pts3d_in_self_view"][j * V:(j + 1) * V], res["conf_self"][j * V:(j + 1) * V], res["camera_pose"][j * V:(j + 1) * V])
                 for j in range(len(ranges))]
-        self.track_many(ranges, outs)
-        self.t1 = ranges[-1][1]
+        if after_window is None:
+            self.track_many(ranges, outs)
+            self.t1 = ranges[-1][1]
+            return
+        for rng, out in zip(ranges, outs):
+            self.track_many([rng], [out])
+            self.t1 = rng[1]
+            after_window(rng[0], rng[1])
 
     # ------------------------------------------------------------------ scheduling (track_frontend.py:285-330)
-    def run(self, tstamp, last_frame=False):
+    def run(self, tstamp, last_frame=False, after_window=None):
         kf = self.keyframes
         if not kf.is_initialized and kf.counter.value - 1 == self.warmup:
             t1 = kf.counter.value - 1
@@ -506,15 +516,19 @@ class TrackFrontend:
             Wb = self.window_batch
             if self.t1 < kf.counter.value - 5 * Wb:
                 first = self.t1 - 1
-                self.track_batch([(first + 5 * j, first + 5 * j + 6) for j in range(Wb)])
+                self.track_batch([(first + 5 * j, first + 5 * j + 6) for j in range(Wb)], after_window=after_window)
                 t1 = self.t1
-                return (t1 > 10), range(first, t1), (t1 - 6) // 5
+                # (with the per-window hook the caller has already had its turn after every window of the batch)
+                return (t1 > 10) and after_window is None, range(first, t1), (t1 - 6) // 5
             if last_frame:
                 while self.t1 < kf.counter.value - 1:
                     t0 = self.t1 - 1
                     t1 = min(t0 + 6, kf.counter.value - 1)
                     self.track(t0, t1)
                     self.t1 = t1
+                    # (the one-window loop tracked -- and handed to the caller -- every full window whose keyframes existed BEFORE the last frame)
+                    if after_window is not None and t1 == t0 + 6 and t1 <= kf.counter.value - 2:
+                        after_window(t0, t1)
                 return False, None, None
             return False, None, None
         elif kf.is_initialized and self.t1 < kf.counter.value - 5:

@@ -271,3 +271,19 @@ def test_loop_closure_fires_inside_the_loop_and_matches_the_cpu_restatement():
     # the closures did something: poses of early keyframes differ from a run with the backend off
     so_off = SR.run_stream(cfg, sd, frames, INTR, mf, precision="fp32", iteration=0)
     assert np.abs(so_off.trajectory()[:, 1:4] - ref[:, 1:4]).max() > 10 * e_t
+    # ---- the same loop with the windows decoded THREE at a time (round 4): the backend takes its turn after every window of a batch, looking
+    # at the keyframes tracked so far -- the same closures, and every store the same bits as one window at a time
+    for wb in (3, 2):
+        conf_b = {"Tracking": {"motion_filter": dict(mf), "frontend": {"iteration": iters, "window_batch": wb}}}
+        slam_b = Cut3rSlam(model, conf_b, (H, W), buffer=frames.shape[0] + 8, device=DEV)
+        for t in range(n):
+            slam_b.run(t, fr[t:t + 1], intr, fr[t:t + 1], intr, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+        torch.cuda.synchronize()
+        bb = slam_b.backend
+        assert bb.closed_loop["idx_current"] == be.closed_loop["idx_current"] and bb.closed_loop["idx_matched"] == be.closed_loop["idx_matched"], wb
+        ts_b, poses_b = slam_b.trajectory()
+        assert np.array_equal(ts_b, ts) and np.array_equal(poses_b, poses), wb
+        for a_, b_ in zip(slam.graph.edges_numpy(), slam_b.graph.edges_numpy()):
+            assert np.array_equal(a_, b_), wb
+        assert slam_b.tracker.t1 == slam.tracker.t1
+        assert torch.equal(slam.keyframes.submap_ds[:nsub], slam_b.keyframes.submap_ds[:nsub]) and torch.equal(slam.keyframes.depth[:k], slam_b.keyframes.depth[:k]), wb

@@ -13,9 +13,10 @@ dev = "cuda:0"
 cfg = production_config()
 sd = synth.loop_state_dict(cfg, seed=0, enc_residual_gain=0.1, depth_relief=0.02)
 model = Cut3rModel(cfg, sd, dev, minimal=True)
-config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": KF_EVERY}, "frontend": {"iteration": 2000, "window_batch": 1}}}
+config = {"Tracking": {"motion_filter": {"thresh": 0.9, "skip": 5, "skip_blur": False, "kf_every": KF_EVERY}, "frontend": {"iteration": 2000, "window_batch": int(os.environ.get("LC_WB", "1"))}}}
 intr = torch.tensor([600.0 * W / 1200.0, 600.0 * H / 680.0, 599.5 * W / 1200.0, 339.5 * H / 680.0])
-warm, n = 160, 1000
+WB = int(os.environ.get('LC_WB', '1'))
+warm, n = max(160, (10 * WB + 8) * KF_EVERY), 1000
 frames = synth_frames(warm + n, H, W, dev, seed=0)
 slam = Cut3rSlam(model, config, (H, W), buffer=(warm + n) // KF_EVERY + 16, device=dev)
 T = {}
