@@ -400,3 +400,41 @@ def test_terminate_add_kf_densifies_wide_keyframe_gaps():
         assert torch.isfinite(v["pose"]).all() and v["pointmap"].shape == (H // 2, W // 2, 3)
     _, none = slam.terminate(add_kf=False)
     assert none == []
+
+
+@pytest.mark.parametrize("n,skip,lookahead,wb,mode", [
+    (83, 2, 7, 2, "buffered"), (83, 2, 7, 2, "pipeline"), (83, 2, 40, 3, "pipeline"), (61, 3, 4, 1, "pipeline"),
+    (83, 2, 5, 2, "stream"), (47, 1, 9, 2, "stream"), (83, 2, 1, 2, "stream")])
+def test_overlap_mode_lookahead_drivers_equal_the_frame_by_frame_loop(n, skip, lookahead, wb, mode):
+    """Overlap mode (kf_every = -1) through every look-ahead driver -- run_buffered, run_buffered(pipeline=True: the next chunk's encoder pass +
+    decision chain on a side stream), run_stream (an item iterator) -- with window batches, chunk sizes that do and do not divide the stream,
+    a look-ahead longer than the stream's tested frames, and the always-kept second-last / last frames: keyframes, poses, depths and ordered
+    edges are those of the frame-by-frame loop, bit for bit."""
+    from cut3r_slam_amd import synth
+    frames = synth.slideshow_stream(n, H, W, hold=3, seed=n).to(DEV)      # a new texture every third frame: some tested frames are keyframes, some are not
+    intr = torch.tensor([40.0, 40.0, 23.5, 15.5])
+    cfg = tiny_config("dpt")
+    model = Cut3rModel(cfg, synth.tracking_state_dict(cfg, 3, enc_residual_gain=0.1), DEV, minimal=True)
+    mf = {"thresh": 0.9, "skip": skip, "kf_every": -1}
+    out = []
+    for drv in ("plain", mode):
+        cfgd = {"Tracking": {"motion_filter": dict(mf), "frontend": {"iteration": 0, "window_batch": 1 if drv == "plain" else wb}}}
+        slam = Cut3rSlam(model, cfgd, (H, W), buffer=n + 8, device=DEV)
+        if drv == "plain":
+            for t in range(n):
+                slam.run(t, frames[t:t + 1], intr, frames[t:t + 1], intr, second_last_frame=(t == n - 2), last_frame=(t == n - 1))
+        elif drv == "stream":
+            slam.run_stream(((t, frames[t:t + 1], intr, frames[t:t + 1], intr, t == n - 2, t == n - 1) for t in range(n)), lookahead=lookahead)
+        else:
+            slam.run_buffered(frames, intr, lookahead=lookahead, pipeline=(drv == "pipeline"))
+        torch.cuda.synchronize()
+        k = slam.tracker.t1
+        out.append((k, slam.keyframes.counter.value, slam.keyframes.tstamp[:slam.keyframes.counter.value].clone(), slam.keyframes.pose[:k].clone(),
+                    slam.keyframes.depth[:k].clone(), slam.graph.edges_numpy(), dict(slam.filterx.stats)))
+    a, b = out
+    assert a[0] == b[0] and a[1] == b[1] and a[1] >= 8, (a[0], b[0], a[1], b[1])
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    for x, y in zip(a[5], b[5]):
+        np.testing.assert_array_equal(x, y)
+    if lookahead > 1:
+        assert b[6]["encoded"] <= 2, b[6]          # (everything else came from the batched look-ahead passes)
