@@ -106,6 +106,7 @@ class PinnedFrames:
         self._slot = 0
         self.upload_every_frame = bool(upload_every_frame)
         self._uploaded_upto = 0
+        self._scratch = None
         self.bytes_uploaded = 0
 
     def fetch(self, f: int) -> torch.Tensor:
@@ -123,12 +124,24 @@ class PinnedFrames:
         too, into a scratch slot, and are dropped -- nothing reads a non-keyframe of a fixed-cadence stream"""
         if not self.upload_every_frame:
             return
-        scratch = self.ring[-1:]
+        # consecutive unclaimed frames are consecutive in the pinned recording: ONE asynchronous copy per run (a fixed-cadence stream has runs of
+        # kf_every - 1 frames; 1260 single-frame copies per step cost the issuing thread ~25 ms of a 246-ms step), into a scratch buffer nobody reads
+        if self._scratch is None:
+            self._scratch = torch.empty((32,) + tuple(self.base.shape[1:]), dtype=torch.uint8, device=self.device)
+        cap = self._scratch.shape[0]
         with torch.cuda.stream(self.stream):
-            for f in range(max(a, self._uploaded_upto), b):
-                if not keep(f):
-                    scratch.copy_(self.base[f % self.period][None], non_blocking=True)
-                    self.bytes_uploaded += scratch.numel()
+            f = max(a, self._uploaded_upto)
+            while f < b:
+                if keep(f):
+                    f += 1
+                    continue
+                g = f + 1                        # the run [f, g): unclaimed, inside one period of the recording, at most `cap` frames
+                while g < b and not keep(g) and g - f < cap and (g % self.period) > (f % self.period):
+                    g += 1
+                src = self.base[f % self.period:f % self.period + (g - f)]
+                self._scratch[:g - f].copy_(src, non_blocking=True)
+                self.bytes_uploaded += src.numel()
+                f = g
         self._uploaded_upto = max(self._uploaded_upto, b)
 
     def event(self) -> torch.cuda.Event:

@@ -160,3 +160,25 @@ def test_demo_lookahead_gives_the_frame_by_frame_trajectory(tmp_path):
     rows = np.loadtxt(tmp_path / "plain" / "traj_kf.txt")
     assert rows.ndim == 2 and rows.shape[0] >= 12, "the sequence must yield enough keyframes for two batched windows"
     assert outs[0] == outs[1]
+
+
+def test_pinned_frames_every_frame_upload_counts_and_wraps():
+    """dist.PinnedFrames(upload_every_frame=True): every frame nobody claims crosses the link once (runs of consecutive frames as one copy,
+    cut at the end of the recording's period and at the scratch buffer's size), claimed frames are fetched by their consumer."""
+    from cut3r_slam_amd.dist import PinnedFrames
+    g = torch.Generator().manual_seed(0)
+    rec = torch.randint(0, 256, (50, 12, 16, 3), generator=g, dtype=torch.uint8)
+    pf = PinnedFrames(rec, virtual_len=500, device=DEV, ring=4, upload_every_frame=True)
+    keep = lambda f: f % 10 == 0
+    pf.upload_range(0, 137, keep)
+    n_unclaimed = sum(1 for f in range(137) if not keep(f))
+    assert pf.bytes_uploaded == n_unclaimed * rec[0].numel()
+    pf.upload_range(100, 260, keep)                   # overlapping call: only the new frames 137..259
+    n2 = sum(1 for f in range(137, 260) if not keep(f))
+    assert pf.bytes_uploaded == (n_unclaimed + n2) * rec[0].numel()
+    got = pf.fetch(120)                               # frame 120 of the virtual stream = frame 20 of the recording
+    pf.event().synchronize()
+    assert torch.equal(got[0].cpu(), rec[20])
+    # the last run of a call lands in the scratch buffer intact (frames 251..259 -> recording 1..9)
+    torch.cuda.synchronize()
+    assert torch.equal(pf._scratch[:9].cpu(), rec[1:10])
