@@ -21,7 +21,9 @@ for rep in range(3):
     l1 = bench.fixed_cadence_leg(model, Cut3rSlam, cdist, dev, 1, n, 4, barrier=lambda: torch.cuda.synchronize())
     ms = 1e3 * l1["elapsed"] / n
     best = ms if best is None else min(best, ms)
-    print(f"rep {rep}: {ms:.3f} ms / window ({n * l1['frames_per_step'] / l1['elapsed']:.0f} frames/s)", flush=True)
+    st = l1["runner"].stats
+    print(f"rep {rep}: {ms:.3f} ms / window ({n * l1['frames_per_step'] / l1['elapsed']:.0f} frames/s); host wall-clock per window [ms]: "
+          + ", ".join(f"{k[:-2]} {1e3 * v / max(1, st['steps']):.2f}" for k, v in st.items() if k != "steps"), flush=True)
     del l1
     torch.cuda.empty_cache()
 sw = {k: v for k, v in os.environ.items() if k.startswith("CUT3R_")}
